@@ -1,0 +1,215 @@
+/*
+ * slideo_amd.h — C ABI of the MI355X-native slide <-> video-frame matcher.
+ *
+ * This is the drop-in boundary for the hot path of hediet/slideo's
+ * crates/matching-opencv.  The reference has no C ABI of its own (its only FFI
+ * is the `opencv` crate's generated shims into OpenCV 4.5.2); each entry point
+ * below names the reference call it replaces.  Paths are relative to the
+ * reference repository root, shorthand `mo/` = crates/matching-opencv/src/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns int32_t status (SLIDEO_OK == 0); the message for
+ *     the last failure on a handle is slideo_last_error(handle);
+ *   - the reference surface has no Result anywhere (it panics, mo/lib.rs:95-104,
+ *     mo/flann.rs:15-46); a binding mirrors that by panicking on status != 0;
+ *   - no C++ exception crosses the ABI;
+ *   - images are 8-bit, 3 channels, BGR interleaved, row-major with a byte
+ *     stride (the cv::Mat 8UC3 layout the reference holds, mo/lib.rs:77-83);
+ *   - "page" = one rasterised PDF page, "frame" = one decoded video frame,
+ *     page indices are 0-based positions in the order pages were added.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with SLIDEO_ERR_NO_DEVICE.
+ */
+#ifndef SLIDEO_AMD_H
+#define SLIDEO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIDEO_ABI_VERSION 1
+
+enum {
+    SLIDEO_OK = 0,
+    SLIDEO_ERR_INVALID_ARG = 1,   /* null pointer, bad size, bad config        */
+    SLIDEO_ERR_NO_DEVICE = 2,     /* no HIP device / not gfx950                */
+    SLIDEO_ERR_HIP = 3,           /* a HIP runtime call failed                 */
+    SLIDEO_ERR_STATE = 4,         /* call order violated (e.g. match before finalize) */
+    SLIDEO_ERR_UNSUPPORTED = 5,   /* config outside what the kernels implement */
+    SLIDEO_ERR_EMPTY_INDEX = 6,   /* no page produced a descriptor (reference: FLANN train on empty set throws, mo/flann.rs:45-47) */
+    SLIDEO_ERR_CAPACITY = 7       /* caller-provided output buffer too small   */
+};
+
+/* Every literal the reference hard-codes on the hot path, as one struct whose
+ * defaults (slideo_config_default) equal those literals. */
+typedef struct slideo_config {
+    /* cv::ORB::create arguments, mo/feature_extractor.rs:13-23 */
+    int32_t nfeatures;            /* 2000 */
+    float   scale_factor;         /* 1.2f */
+    int32_t nlevels;              /* 8    */
+    int32_t edge_threshold;       /* 62   */
+    int32_t patch_size;           /* 62   */
+    int32_t fast_threshold;       /* 20   */
+    /* matcher: k of knn_match, mo/lib.rs:266 */
+    int32_t knn_k;                /* 30   */
+    /* tolerance vote, mo/lib.rs:275 */
+    float   vote_tolerance;       /* 1.05f */
+    /* candidate pages kept, mo/lib.rs:295 */
+    int32_t max_candidate_pages;  /* 40   */
+    /* estimate_affine_partial_2d arguments, mo/image_utils.rs:52 */
+    double  ransac_threshold;     /* 3.0  */
+    int32_t ransac_max_iters;     /* 2000 */
+    double  ransac_confidence;    /* 0.99 */
+    int32_t refine_iters;         /* 10   */
+    /* rating filter, mo/lib.rs:330,333 */
+    int32_t max_rated;            /* 10   */
+    double  min_rating;           /* 50.0 (strict >) */
+    double  min_rating_ratio;     /* 0.2  (strict >) */
+    /* verdict, mo/lib.rs:381 */
+    float   min_similarity;       /* 0.5f (strict >) */
+    /* to_small_image, mo/image_utils.rs:11 */
+    int32_t small_area;           /* 300*400 */
+    /* MarkSimilarIter, mo/video_capture.rs:98 */
+    float   changed_similarity;   /* 0.98f (changed <=> similarity < this) */
+} slideo_config;
+
+/* cv::KeyPoint as the reference consumes it (pt, size, angle, response,
+ * octave); class_id is never read (mo/lib.rs:299-302). 24 bytes. */
+typedef struct slideo_keypoint {
+    float   x, y;       /* level-0 pixel coordinates                         */
+    float   size;       /* patch_size * scale(octave)                        */
+    float   angle;      /* degrees, [0,360)                                  */
+    float   response;   /* FAST score                                        */
+    int32_t octave;     /* pyramid level                                     */
+} slideo_keypoint;
+
+/* One per-frame verdict = the `image: Option<I>` of matching::Matching
+ * (crates/matching/src/lib.rs:35-40) plus the two numbers that decided it. */
+typedef struct slideo_verdict {
+    int32_t page_idx;     /* -1 = None                                        */
+    float   similarity;   /* of the winning page, 0 when page_idx == -1       */
+    int32_t inliers;      /* RANSAC inlier count of the winning page, else 0  */
+    int32_t n_keypoints;  /* ORB keypoints found in the frame                 */
+} slideo_verdict;
+
+typedef struct slideo_matcher slideo_matcher;
+
+/* matching::ProgressReporter (crates/matching/src/progress.rs:3-17).  May be
+ * invoked from any thread; the reference invokes it from rayon workers
+ * (mo/lib.rs:49-53,192-203). */
+typedef void (*slideo_progress_fn)(void* user, uint64_t done, uint64_t total, const char* msg);
+
+uint32_t    slideo_abi_version(void);
+
+/* Fills *cfg with the reference's literals (table above). */
+void        slideo_config_default(slideo_config* cfg);
+
+/* Replaces OpenCVImageVideoMatcher::default() + FeatureExtractor::default()
+ * (crates/app/src/main.rs:69; mo/feature_extractor.rs:12-27).
+ * device: HIP device ordinal. */
+int32_t     slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_matcher** out);
+void        slideo_matcher_destroy(slideo_matcher* m);
+
+/* Message of the last failure on `m` (or of the last failed create when m is
+ * NULL).  Never NULL; valid until the next call on the same handle. */
+const char* slideo_last_error(const slideo_matcher* m);
+
+/* Replaces ProcessedImage::compute over all pages (mo/lib.rs:45-56,92-131):
+ * ORB detect+describe and to_small_image per page.  Host buffers.  May be
+ * called repeatedly before finalize; pages keep their add order. */
+int32_t     slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages,
+                                          const uint8_t* const* data,
+                                          const int32_t* width, const int32_t* height,
+                                          const int32_t* stride_bytes);
+
+/* Replaces FlannMatcher::new (mo/flann.rs:65-71; add :28-34, train :45-47):
+ * freezes the page descriptor set into the device-resident train matrix. */
+int32_t     slideo_matcher_finalize_pages(slideo_matcher* m);
+
+int32_t     slideo_matcher_page_count(const slideo_matcher* m);
+/* Total descriptors over all pages (M).  -1 before finalize. */
+int64_t     slideo_matcher_descriptor_count(const slideo_matcher* m);
+/* Copies page `page_idx`'s keypoints/descriptors (canonical order) to host. */
+int32_t     slideo_matcher_get_page_features(const slideo_matcher* m, int32_t page_idx,
+                                             slideo_keypoint* kp, uint8_t* desc32,
+                                             int32_t capacity, int32_t* n_out);
+
+/* Replaces OpenCVVideoMatcherTask::match_images_with_frame (mo/lib.rs:249-413)
+ * for a batch of equally sized frames held in HOST memory; verdicts to host. */
+int32_t     slideo_match_frames_bgr8(slideo_matcher* m, int32_t n_frames,
+                                     const uint8_t* frames, int32_t width, int32_t height,
+                                     int32_t stride_bytes, int64_t frame_stride_bytes,
+                                     slideo_verdict* verdicts_out);
+
+/* Same, frames already resident in HBM (device pointer); verdicts to host.
+ * `hip_stream` is a hipStream_t (NULL = the matcher's own stream). */
+int32_t     slideo_match_frames_bgr8_dev(slideo_matcher* m, int32_t n_frames,
+                                         const uint8_t* frames_dev, int32_t width, int32_t height,
+                                         int32_t stride_bytes, int64_t frame_stride_bytes,
+                                         slideo_verdict* verdicts_out, void* hip_stream);
+
+/* Replaces MarkSimilarIter (mo/video_capture.rs:86-98) for a run of sampled
+ * frames in host memory: changed[i] = 1 iff similarity(small(frame i-1),
+ * small(frame i)) < cfg.changed_similarity; the first frame compares against
+ * `prev_small` (w*h*3 small image returned by an earlier call) or, when that
+ * is NULL, is always changed.  similarity_out may be NULL. */
+int32_t     slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames,
+                                     const uint8_t* frames, int32_t width, int32_t height,
+                                     int32_t stride_bytes, int64_t frame_stride_bytes,
+                                     const uint8_t* prev_small, uint8_t* last_small_out,
+                                     uint8_t* changed_out, float* similarity_out);
+
+/* Optional progress sink for add_pages / match_frames. */
+int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user);
+
+/* ---- debug taps used by the parity tests ------------------------------ */
+
+/* FeatureExtractor::find_keypoints_and_descriptors (mo/feature_extractor.rs:29-46)
+ * on one host image.  Output in canonical order (octave, y, x).  *n_out is the
+ * number found even when it exceeds `capacity` (then SLIDEO_ERR_CAPACITY). */
+int32_t     slideo_orb_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width, int32_t height,
+                            int32_t stride_bytes, slideo_keypoint* kp, uint8_t* desc32,
+                            int32_t capacity, int32_t* n_out);
+
+/* Pyramid level `level` (gray, unblurred or blurred) of one host image; out is
+ * lw*lh bytes, dimensions returned in *lw,*lh. */
+int32_t     slideo_pyramid_level_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
+                                      int32_t height, int32_t stride_bytes, int32_t level,
+                                      int32_t blurred, uint8_t* out, int64_t out_capacity,
+                                      int32_t* lw, int32_t* lh);
+
+/* Exact Hamming k-NN (replaces FlannMatcher::knn_match, mo/flann.rs:73-89 with
+ * the brute-force search north_star asks for).  q: nq*32 bytes, t: nt*32 bytes
+ * (host).  Out: idx[nq*k] (global train row, -1 padding when nt<k) and
+ * dist[nq*k] (65535 padding), ascending by (distance, train row). */
+int32_t     slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq,
+                               const uint8_t* t, int32_t nt, int32_t k,
+                               int32_t* idx_out, uint16_t* dist_out);
+
+/* to_small_image (mo/image_utils.rs:8-20) of one host image. */
+int32_t     slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
+                                    int32_t height, int32_t stride_bytes, uint8_t* out,
+                                    int64_t out_capacity, int32_t* sw, int32_t* sh);
+
+/* Per-frame trace of the decision steps for one frame of the LAST
+ * slideo_match_frames_* call (parity tests compare these with the oracle). */
+typedef struct slideo_candidate {
+    int32_t page_idx;
+    int32_t n_votes;      /* matches surviving the tolerance vote (mo/lib.rs:268-282) */
+    int32_t inliers;      /* rating (mo/lib.rs:310)                                    */
+    int32_t survived;     /* passed the rating filter (mo/lib.rs:333)                  */
+    float   similarity;   /* mo/lib.rs:351, 0 when not computed                        */
+    double  transform[6]; /* 2x3 row-major, slide -> frame (mo/image_utils.rs:52)      */
+} slideo_candidate;
+
+int32_t     slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_batch,
+                                         slideo_candidate* out, int32_t capacity, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIDEO_AMD_H */
