@@ -1,0 +1,251 @@
+"""ctypes binding of include/slideo_amd.h (libslideo_amd.so).
+
+The product path.  It fails loudly when the HIP library is missing or no gfx950
+device is present; there is no CPU fallback and nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK = 0
+ERR_NAMES = {1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "STATE", 5: "UNSUPPORTED",
+             6: "EMPTY_INDEX", 7: "CAPACITY"}
+
+
+class Config(C.Structure):
+    """slideo_config (include/slideo_amd.h); defaults = the reference's literals."""
+    _fields_ = [
+        ("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+        ("edge_threshold", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
+        ("knn_k", C.c_int32), ("vote_tolerance", C.c_float), ("max_candidate_pages", C.c_int32),
+        ("ransac_threshold", C.c_double), ("ransac_max_iters", C.c_int32),
+        ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
+        ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
+        ("small_area", C.c_int32), ("changed_similarity", C.c_float),
+    ]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4")])
+VERDICT_DTYPE = np.dtype([("page_idx", "<i4"), ("similarity", "<f4"), ("inliers", "<i4"),
+                          ("n_keypoints", "<i4")])
+CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers", "<i4"),
+                            ("survived", "<i4"), ("similarity", "<f4"), ("_pad", "<i4"),
+                            ("transform", "<f8", (6,))])
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p)
+
+EXPORTS = [
+    "slideo_abi_version", "slideo_config_default", "slideo_matcher_create", "slideo_matcher_destroy",
+    "slideo_last_error", "slideo_matcher_add_pages_bgr8", "slideo_matcher_finalize_pages",
+    "slideo_matcher_page_count", "slideo_matcher_descriptor_count", "slideo_matcher_get_page_features",
+    "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
+    "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
+    "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
+]
+
+_lib = None
+
+
+class SlideoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("slideo_amd error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+def lib():
+    """Loads libslideo_amd.so (building it in-tree if the sources are newer)."""
+    global _lib
+    if _lib is None:
+        path = _build.HIP_LIB
+        if not os.path.exists(path) or os.environ.get("SLIDEO_REBUILD"):
+            path = _build.build_hip()
+        if not os.path.exists(path):
+            raise RuntimeError("libslideo_amd.so is missing and could not be built; the HIP "
+                               "extension is required (no fallback path exists)")
+        L = C.CDLL(path)
+        L.slideo_abi_version.restype = C.c_uint32
+        L.slideo_last_error.restype = C.c_char_p
+        L.slideo_last_error.argtypes = [C.c_void_p]
+        L.slideo_matcher_descriptor_count.restype = C.c_int64
+        L.slideo_matcher_descriptor_count.argtypes = [C.c_void_p]
+        L.slideo_matcher_page_count.argtypes = [C.c_void_p]
+        L.slideo_matcher_destroy.argtypes = [C.c_void_p]
+        L.slideo_matcher_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def default_config(**over):
+    c = Config()
+    lib().slideo_config_default(C.byref(c))
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _img3(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected an HxWx3 uint8 BGR image")
+    return a
+
+
+class Matcher:
+    """Owns one slideo_matcher handle (page database + workspace on one GPU)."""
+
+    def __init__(self, cfg=None, device=0):
+        self.cfg = cfg if cfg is not None else default_config()
+        self._h = C.c_void_p()
+        self._cb = None
+        rc = lib().slideo_matcher_create(C.byref(self.cfg), int(device), C.byref(self._h))
+        if rc != OK:
+            raise SlideoError(rc, lib().slideo_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SlideoError(rc, lib().slideo_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().slideo_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_progress(self, fn):
+        """fn(done, total, msg) or None."""
+        if fn is None:
+            self._cb = None
+            self._check(lib().slideo_matcher_set_progress(self._h, None, None))
+            return
+        self._cb = PROGRESS_FN(lambda user, d, t, msg: fn(int(d), int(t), (msg or b"").decode()))
+        self._check(lib().slideo_matcher_set_progress(self._h, self._cb, None))
+
+    # ---- pages -------------------------------------------------------------------
+    def add_pages(self, pages):
+        pages = [_img3(p) for p in pages]
+        n = len(pages)
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+        w = (C.c_int32 * n)(*[p.shape[1] for p in pages])
+        h = (C.c_int32 * n)(*[p.shape[0] for p in pages])
+        s = (C.c_int32 * n)(*[p.shape[1] * 3 for p in pages])
+        self._check(lib().slideo_matcher_add_pages_bgr8(self._h, n, ptrs, w, h, s))
+
+    def finalize(self):
+        self._check(lib().slideo_matcher_finalize_pages(self._h))
+
+    @property
+    def page_count(self):
+        return int(lib().slideo_matcher_page_count(self._h))
+
+    @property
+    def descriptor_count(self):
+        return int(lib().slideo_matcher_descriptor_count(self._h))
+
+    def page_features(self, page):
+        n = C.c_int32()
+        rc = lib().slideo_matcher_get_page_features(self._h, page, None, None, 0, C.byref(n))
+        if rc not in (OK, 7):
+            self._check(rc)
+        kp = np.zeros(n.value, KEYPOINT_DTYPE)
+        desc = np.zeros((n.value, 32), np.uint8)
+        self._check(lib().slideo_matcher_get_page_features(self._h, page, _p(kp), _p(desc), n.value, C.byref(n)))
+        return kp, desc
+
+    # ---- frames ------------------------------------------------------------------
+    def match_frames(self, frames):
+        """frames: uint8 [n, h, w, 3] in host memory -> verdict records."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, c = frames.shape
+        assert c == 3
+        out = np.zeros(n, VERDICT_DTYPE)
+        self._check(lib().slideo_match_frames_bgr8(self._h, n, _p(frames), w, h, w * 3,
+                                                   C.c_int64(w * h * 3), _p(out)))
+        return out
+
+    def match_frames_dev(self, dev_ptr, n, w, h, stride=None, frame_stride=None, stream=0):
+        """Frames already resident in HBM (raw device pointer)."""
+        stride = stride or w * 3
+        frame_stride = frame_stride or stride * h
+        out = np.zeros(n, VERDICT_DTYPE)
+        self._check(lib().slideo_match_frames_bgr8_dev(self._h, n, C.c_void_p(dev_ptr), w, h, stride,
+                                                       C.c_int64(frame_stride), _p(out),
+                                                       C.c_void_p(stream)))
+        return out
+
+    def last_candidates(self, frame_in_batch):
+        cands = np.zeros(64, CANDIDATE_DTYPE)
+        n = C.c_int32()
+        self._check(lib().slideo_last_frame_candidates(self._h, frame_in_batch, _p(cands), 64, C.byref(n)))
+        return cands[: n.value].copy()
+
+    def changed_mask(self, frames, prev_small=None):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, _ = frames.shape
+        changed = np.zeros(n, np.uint8)
+        sims = np.zeros(n, np.float32)
+        sw, sh = small_size(w, h, self.cfg.small_area)
+        last = np.zeros((sh, sw, 3), np.uint8)
+        if prev_small is not None:
+            prev_small = np.ascontiguousarray(prev_small, np.uint8)
+        self._check(lib().slideo_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
+                                                   _p(prev_small), _p(last), _p(changed), _p(sims)))
+        return changed.astype(bool), sims, last
+
+    # ---- debug taps -----------------------------------------------------------------
+    def orb(self, bgr, cap=None):
+        bgr = _img3(bgr)
+        h, w, _ = bgr.shape
+        cap = cap or 8192
+        kp = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32()
+        self._check(lib().slideo_orb_bgr8(self._h, _p(bgr), w, h, w * 3, _p(kp), _p(desc), cap, C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def pyramid_level(self, bgr, level, blurred):
+        bgr = _img3(bgr)
+        h, w, _ = bgr.shape
+        out = np.empty(h * w, np.uint8)
+        lw = C.c_int32(); lh = C.c_int32()
+        self._check(lib().slideo_pyramid_level_bgr8(self._h, _p(bgr), w, h, w * 3, level, int(blurred), _p(out),
+                                                    C.c_int64(out.size), C.byref(lw), C.byref(lh)))
+        return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+    def knn(self, q, t, k):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.uint16)
+        self._check(lib().slideo_knn_hamming(self._h, _p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist)))
+        return idx, dist
+
+    def small_image(self, bgr):
+        bgr = _img3(bgr)
+        h, w, _ = bgr.shape
+        sw, sh = small_size(w, h, self.cfg.small_area)
+        out = np.empty((max(sh, 1), max(sw, 1), 3), np.uint8)
+        a = C.c_int32(); b = C.c_int32()
+        self._check(lib().slideo_small_image_bgr8(self._h, _p(bgr), w, h, w * 3, _p(out), C.c_int64(out.size),
+                                                  C.byref(a), C.byref(b)))
+        return out
+
+
+def small_size(w, h, small_area=120000):
+    """to_small_image target size (crates/matching-opencv/src/image_utils.rs:11-16), f32 arithmetic."""
+    factor = np.sqrt(np.float32(small_area) / np.float32(w * h), dtype=np.float32)
+    return int(np.float32(w) * factor), int(np.float32(h) * factor)

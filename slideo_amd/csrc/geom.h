@@ -1,0 +1,261 @@
+// geom.h — host-side geometry and constant tables for the ORB / verify kernels.
+//
+// Everything here is a pure function of the config and the image size and is
+// computed once per (matcher, frame size) on the host in the same double /
+// float arithmetic OpenCV 4.5.2 uses, then uploaded.
+// Shared POD structs below are passed to kernels by value.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "slideo_amd.h"
+
+namespace slideo {
+
+constexpr int MAX_LEVELS = 16;
+constexpr int MAX_DIM = 4096;            // x,y packed in 12 bits each
+constexpr int FAST_TW = 64, FAST_TH = 32;  // FAST tile (outputs)
+constexpr int BLUR_TW = 64, BLUR_TH = 16;  // blur tile (outputs)
+constexpr int KP_CAP_PER_FRAME = 8192;     // sort capacity (LDS), loud error beyond
+constexpr int RNG_TABLE = 16384;           // pre-drawn cv::RNG outputs for RANSAC
+
+struct LevelGeom {
+    int32_t w, h, pitch;       // level image
+    int32_t quota;             // retainBest n for this level
+    int64_t ofs;               // byte offset of the level inside one frame's pyramid
+    int32_t rx0, ry0, rx1, ry1;  // FAST keep-region [rx0,rx1) x [ry0,ry1)  (empty if rx1<=rx0)
+    int32_t ftx, fty, ftile0;  // FAST tiles in x / y, first tile id of this level
+    int32_t btx, bty, btile0;  // blur tiles
+    int32_t cand_ofs, cand_cap;  // candidate list slice (entries) inside one frame's list
+    int32_t xtab_ofs, ytab_ofs;  // resize coefficient tables (entries), valid for level >= 1
+    float scale;               // (float)pow(scale_factor, level)
+    int32_t _pad;
+};
+
+struct PyrGeom {
+    int32_t nlevels, w, h;
+    int32_t fast_tiles, blur_tiles;
+    int32_t cand_per_frame;       // entries
+    int64_t frame_bytes;          // pyramid bytes per frame (multiple of 256)
+    int32_t edge, fast_thr, half_patch, patch_size;
+    LevelGeom lv[MAX_LEVELS];
+};
+
+inline int cv_round_d(double v) { return (int)std::lrint(v); }
+
+// [OCV A.2] level sizes and scales (orb.cpp getScale / detectAndCompute)
+inline void pyramid_dims(int w, int h, const slideo_config& c, int* ws, int* hs, float* sc) {
+    for (int l = 0; l < c.nlevels; ++l) {
+        float s = (float)std::pow((double)c.scale_factor, (double)l);
+        sc[l] = s;
+        ws[l] = cv_round_d((double)((float)w / s));
+        hs[l] = cv_round_d((double)((float)h / s));
+    }
+}
+
+// [OCV A.4] per-level feature quotas (orb.cpp computeKeyPoints)
+inline void level_quotas(const slideo_config& c, int* q) {
+    float factor = (float)(1.0 / (double)c.scale_factor);
+    float nd = (float)c.nfeatures * (1.0f - factor) / (1.0f - (float)std::pow((double)factor, (double)c.nlevels));
+    int sum = 0;
+    for (int l = 0; l < c.nlevels - 1; ++l) {
+        q[l] = cv_round_d((double)nd);
+        sum += q[l];
+        nd *= factor;
+    }
+    q[c.nlevels - 1] = std::max(c.nfeatures - sum, 0);
+}
+
+// [OCV A.5] umax (orb.cpp)
+inline void umax_table(int half, int* umax /* half+2 */) {
+    for (int i = 0; i < half + 2; ++i) umax[i] = 0;
+    int vmax = (int)std::floor(half * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(half * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = cv_round_d(std::sqrt((double)half * half - (double)v * v));
+    for (int v = half, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+// [OCV A.7] cv::RNG (64-bit multiply-with-carry)
+struct CvRng {
+    uint64_t state;
+    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    uint32_t next() {
+        state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a)) + a; }
+};
+
+// [OCV A.7] makeRandomPattern(patchSize, 512)
+inline void brief_pattern(int patch_size, int8_t* xy /* 1024 */) {
+    CvRng rng(0x34985739);
+    for (int i = 0; i < 512; ++i) {
+        xy[2 * i] = (int8_t)rng.uniform(-patch_size / 2, patch_size / 2 + 1);
+        xy[2 * i + 1] = (int8_t)rng.uniform(-patch_size / 2, patch_size / 2 + 1);
+    }
+}
+
+// [OCV A.6] 7-tap sigma-2 fixed-point Gaussian (getGaussianKernelFixedPoint_ED)
+inline void gauss7_fixed(int* k) {
+    double kd[7], sum = 0;
+    for (int i = 0; i < 7; ++i) { double x = i - 3.0; kd[i] = std::exp(-0.5 / 4.0 * x * x); sum += kd[i]; }
+    for (int i = 0; i < 7; ++i) kd[i] *= 1.0 / sum;
+    double err = 0; int acc = 0;
+    for (int i = 0; i < 3; ++i) {
+        double adj = kd[i] * 256.0 + err;
+        int v0 = cv_round_d(adj);
+        err = adj - (double)v0;
+        k[i] = k[6 - i] = v0;
+        acc += v0;
+    }
+    k[3] = 256 - 2 * acc;
+}
+
+// [OCV A.2] INTER_LINEAR_EXACT per-axis coefficients: entry = ofs | c1 << 16
+// (value = (256 - c1) * src[ofs] + c1 * src[min(ofs+1, n-1)])
+inline void linear_exact_table(int ssize, int dsize, std::vector<uint32_t>& out) {
+    double inv_scale = (double)dsize / (double)ssize, scale = 1.0 / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        double f = scale * ((double)d + 0.5) - 0.5;
+        int i = (int)std::floor(f);
+        uint32_t ofs, c1;
+        if (i >= 0 && ssize > 1) {
+            if (i < ssize - 1) { ofs = (uint32_t)i; c1 = (uint32_t)cv_round_d((f - (double)i) * 256.0); }
+            else { ofs = (uint32_t)(ssize - 1); c1 = 0; }
+        } else { ofs = 0; c1 = 0; }
+        out.push_back(ofs | (c1 << 16));
+    }
+}
+
+inline bool config_supported(const slideo_config& c, const char** why) {
+    int half = c.patch_size / 2;
+    int desc_r = (int)std::ceil(half * std::sqrt(2.0));
+    *why = "";
+    if (c.nlevels < 1 || c.nlevels > MAX_LEVELS) { *why = "nlevels must be 1..16"; return false; }
+    if (c.nfeatures < 1) { *why = "nfeatures must be >= 1"; return false; }
+    if (c.patch_size == 31) { *why = "patch_size 31 selects OpenCV's learned pattern, which is not restated; the reference uses 62"; return false; }
+    if (c.patch_size < 2 || half > 63) { *why = "patch_size out of range"; return false; }
+    if (c.edge_threshold < desc_r + 3 || c.edge_threshold < half || c.edge_threshold < 4) {
+        *why = "edge_threshold must cover the rotated BRIEF radius + blur support"; return false;
+    }
+    if (!(c.scale_factor > 1.0f)) { *why = "scale_factor must be > 1"; return false; }
+    if (c.fast_threshold < 1 || c.fast_threshold > 254) { *why = "fast_threshold out of range"; return false; }
+    if (c.knn_k < 1 || c.knn_k > 32) { *why = "knn_k must be 1..32"; return false; }
+    if (c.max_candidate_pages < 1 || c.max_candidate_pages > 64) { *why = "max_candidate_pages must be 1..64"; return false; }
+    if (c.max_rated < 1 || c.max_rated > 16) { *why = "max_rated must be 1..16"; return false; }
+    if (c.ransac_max_iters < 1 || c.ransac_max_iters > 5000) { *why = "ransac_max_iters must be 1..5000"; return false; }
+    if (c.small_area < 64) { *why = "small_area too small"; return false; }
+    return true;
+}
+
+// Builds the pyramid geometry + resize tables for a w x h input.
+inline void build_pyr_geom(int w, int h, const slideo_config& c, PyrGeom& g, std::vector<uint32_t>& lin_tab) {
+    int ws[MAX_LEVELS], hs[MAX_LEVELS], quota[MAX_LEVELS];
+    float sc[MAX_LEVELS];
+    pyramid_dims(w, h, c, ws, hs, sc);
+    level_quotas(c, quota);
+    g = PyrGeom();
+    g.nlevels = c.nlevels; g.w = w; g.h = h;
+    g.edge = c.edge_threshold; g.fast_thr = c.fast_threshold;
+    g.half_patch = c.patch_size / 2; g.patch_size = c.patch_size;
+    lin_tab.clear();
+    int64_t ofs = 0; int ftile = 0, btile = 0, cand = 0;
+    for (int l = 0; l < c.nlevels; ++l) {
+        LevelGeom& L = g.lv[l];
+        L.w = std::max(ws[l], 0); L.h = std::max(hs[l], 0);
+        L.pitch = (L.w + 15) & ~15;
+        L.quota = quota[l]; L.scale = sc[l];
+        L.ofs = ofs;
+        ofs += ((int64_t)L.pitch * L.h + 255) & ~(int64_t)255;
+        const int e = c.edge_threshold;
+        if (L.w > 2 * e && L.h > 2 * e) { L.rx0 = e; L.ry0 = e; L.rx1 = L.w - e; L.ry1 = L.h - e; }
+        else { L.rx0 = L.ry0 = L.rx1 = L.ry1 = 0; }
+        int rw = L.rx1 - L.rx0, rh = L.ry1 - L.ry0;
+        L.ftx = rw > 0 ? (rw + FAST_TW - 1) / FAST_TW : 0;
+        L.fty = rh > 0 ? (rh + FAST_TH - 1) / FAST_TH : 0;
+        L.ftile0 = ftile; ftile += L.ftx * L.fty;
+        L.btx = L.w > 0 ? (L.w + BLUR_TW - 1) / BLUR_TW : 0;
+        L.bty = L.h > 0 ? (L.h + BLUR_TH - 1) / BLUR_TH : 0;
+        L.btile0 = btile; btile += L.btx * L.bty;
+        // NMS survivors are strict 3x3 maxima: at most one per 2x2 block of the keep-region
+        L.cand_ofs = cand;
+        L.cand_cap = rw > 0 ? ((rw + 1) / 2) * ((rh + 1) / 2) : 0;
+        cand += L.cand_cap;
+        if (l >= 1 && L.w > 0 && L.h > 0 && g.lv[l - 1].w > 0) {
+            L.xtab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].w, L.w, lin_tab);
+            L.ytab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].h, L.h, lin_tab);
+        }
+    }
+    g.frame_bytes = ofs; g.fast_tiles = ftile; g.blur_tiles = btile; g.cand_per_frame = cand;
+}
+
+// ---- INTER_AREA tap tables ([OCV A.11] computeResizeAreaTab) -----------------
+struct AreaTap { int32_t si; float alpha; };
+
+struct AreaGeom {        // one per distinct (source size -> small size) class
+    int32_t sw, sh;      // source (page / frame) size
+    int32_t dw, dh;      // small size
+    int32_t fast;        // integer-scale fast path (ResizeAreaFast)
+    int32_t iscale_x, iscale_y;
+    float fast_scale;    // 1/(iscale_x*iscale_y)
+    int32_t xtap_ofs, xidx_ofs;   // taps (AreaTap) and per-dx start indices (dw+1 ints), generic path
+    int32_t ytap_ofs, yidx_ofs;
+    int32_t max_xtaps, max_ytaps;
+};
+
+inline void area_taps(int ssize, int dsize, double scale, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int& max_taps) {
+    max_taps = 0;
+    for (int dx = 0; dx < dsize; ++dx) {
+        idx.push_back((int32_t)taps.size());
+        size_t before = taps.size();
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) taps.push_back({sx1 - 1, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; ++sx) taps.push_back({sx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) taps.push_back({sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)});
+        max_taps = std::max(max_taps, (int)(taps.size() - before));
+    }
+    idx.push_back((int32_t)taps.size());
+}
+
+// to_small_image target size (crates/matching-opencv/src/image_utils.rs:8-16)
+inline void small_size(int w, int h, int small_area, int& sw, int& sh) {
+    float factor = std::sqrt((float)small_area / (float)(w * h));
+    sw = (int)((float)w * factor);
+    sh = (int)((float)h * factor);
+}
+
+// Returns false when the resize is not a shrink (INTER_AREA would fall back to bilinear).
+inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vector<AreaTap>& taps, std::vector<int32_t>& idx) {
+    a = AreaGeom();
+    a.sw = w; a.sh = h;
+    small_size(w, h, small_area, a.dw, a.dh);
+    if (a.dw <= 0 || a.dh <= 0 || a.dw > w || a.dh > h) return false;
+    double scale_x = 1. / ((double)a.dw / w), scale_y = 1. / ((double)a.dh / h);
+    a.iscale_x = (int)std::llrint(scale_x); a.iscale_y = (int)std::llrint(scale_y);
+    a.fast = std::fabs(scale_x - a.iscale_x) < DBL_EPSILON && std::fabs(scale_y - a.iscale_y) < DBL_EPSILON;
+    a.fast_scale = 1.f / (float)(a.iscale_x * a.iscale_y);
+    a.xidx_ofs = (int32_t)idx.size(); a.xtap_ofs = (int32_t)taps.size();
+    {
+        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(w, a.dw, scale_x, t, i, a.max_xtaps);
+        taps.insert(taps.end(), t.begin(), t.end()); idx.insert(idx.end(), i.begin(), i.end());
+    }
+    a.yidx_ofs = (int32_t)idx.size(); a.ytap_ofs = (int32_t)taps.size();
+    {
+        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(h, a.dh, scale_y, t, i, a.max_ytaps);
+        taps.insert(taps.end(), t.begin(), t.end()); idx.insert(idx.end(), i.begin(), i.end());
+    }
+    return true;
+}
+
+}  // namespace slideo

@@ -1,0 +1,488 @@
+// orb.hip.h — ORB detect + describe kernels for gfx950.
+//
+// Replaces FeatureExtractor::find_keypoints_and_descriptors
+// (crates/matching-opencv/src/feature_extractor.rs:29-46), i.e. OpenCV 4.5.2
+// ORB_Impl::detectAndCompute as restated in SURVEY.md Appendix A.1-A.7.
+// All stages are batched over the frames of a batch (blockIdx.y / .z = frame)
+// so that one launch covers >> 256 workgroups.
+//
+//   gray_kernel        BGR8 -> level 0                      (HBM: 3wh in, wh out)
+//   resize_kernel      level l-1 -> l, INTER_LINEAR_EXACT   (7 dependent launches)
+//   fast_kernel        FAST-9/16 score + 3x3 NMS + border filter -> candidate
+//                      list + per-(frame,level) score histogram   (all levels, one launch)
+//   blur_kernel        7x7 sigma-2 fixed-point Gaussian     (all levels, one launch)
+//   threshold_kernel   retainBest: per-level score threshold from the histogram
+//                      (ties kept => order independent, deterministic)
+//   scan_kernel        per-frame keypoint offsets
+//   compact_kernel     candidates >= threshold -> per-frame keypoint items
+//   sort_kernel        canonical order (octave, y, x) — bitonic sort in LDS
+//   describe_kernel    IC angle (unblurred level) + rotated BRIEF-256 (blurred level)
+//
+// Keypoints sit >= edge_threshold (62) px from the level edge, the IC disc has
+// radius 31 and the rotated BRIEF samples radius <= 44 (+3 blur taps), so
+// neither stage ever reads outside the level: no reflected border is
+// materialised (OpenCV stores one of 63 px; it is never sampled).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geom.h"
+
+namespace slideo {
+
+struct OrbTables {             // device-resident constants (per matcher)
+    int32_t umax[68];
+    int32_t gk[8];             // 7-tap kernel, sums to 256
+    int8_t pattern[1024];      // 512 (x,y)
+};
+
+// ---------------------------------------------------------------------------
+// [OCV A.1] gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+// grid (ceil(w/4/256), h, B)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
+}
+
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride,
+                                                   int stride, uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
+                                                   int w, int h, int pitch, int aligned4) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* src = frames + (int64_t)blockIdx.z * frame_stride + (int64_t)y * stride + (int64_t)x * 3;
+    uint8_t* dst = pyr + (int64_t)blockIdx.z * pyr_frame_bytes + (int64_t)y * pitch + x;
+    if (aligned4 && x + 3 < w) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+        uint32_t a = s[0], b = s[1], c = s[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+        uint32_t g0 = gray_of(a & 255, (a >> 8) & 255, (a >> 16) & 255);
+        uint32_t g1 = gray_of(a >> 24, b & 255, (b >> 8) & 255);
+        uint32_t g2 = gray_of((b >> 16) & 255, b >> 24, c & 255);
+        uint32_t g3 = gray_of((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+        *reinterpret_cast<uint32_t*>(dst) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (int i = 0; i < 4 && x + i < w; ++i)
+            dst[i] = (uint8_t)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.2] INTER_LINEAR_EXACT: out = (cy0*(cx0*p00+cx1*p01) + cy1*(cx0*p10+cx1*p11) + 2^15) >> 16
+// grid (ceil(dw/4/256), dh, B)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
+                                                     LevelGeom src, LevelGeom dst,
+                                                     const uint32_t* __restrict__ lin_tab) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x0 >= dst.w) return;
+    uint8_t* base = pyr + (int64_t)blockIdx.z * pyr_frame_bytes;
+    const uint32_t ye = lin_tab[dst.ytab_ofs + y];
+    const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
+    const uint8_t* r0 = base + src.ofs + (int64_t)yo * src.pitch;
+    const uint8_t* r1 = base + src.ofs + (int64_t)min(yo + 1, src.h - 1) * src.pitch;
+    uint32_t outv = 0;
+    const int nx = min(4, dst.w - x0);
+    for (int i = 0; i < nx; ++i) {
+        const uint32_t xe = lin_tab[dst.xtab_ofs + x0 + i];
+        const int xo = xe & 0xffff, cx1 = xe >> 16, cx0 = 256 - cx1;
+        const int xo1 = min(xo + 1, src.w - 1);
+        uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
+        uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
+        uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
+        outv |= v << (8 * i);
+    }
+    uint8_t* d = base + dst.ofs + (int64_t)y * dst.pitch + x0;
+    if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
+    else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.3] FAST-9/16 score + NMS + runByImageBorder, all levels in one launch.
+// grid (fast_tiles, B), block 256.  Candidate entry = score << 24 | y << 12 | x.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool run9(uint32_t m) {   // 9 contiguous set bits, circular over 16
+    m |= m << 16;
+    m &= m >> 1; m &= m >> 2; m &= m >> 4; m &= m >> 1;
+    return m != 0;
+}
+
+__device__ __forceinline__ int level_of_tile(const PyrGeom& g, int tile, bool blur) {
+    int l = 0;
+    for (int i = 1; i < g.nlevels; ++i) {
+        int t0 = blur ? g.lv[i].btile0 : g.lv[i].ftile0;
+        int n = blur ? g.lv[i].btx * g.lv[i].bty : g.lv[i].ftx * g.lv[i].fty;
+        if (n > 0 && tile >= t0) l = i;
+    }
+    return l;
+}
+
+constexpr int FAST_RW = FAST_TW + 8, FAST_RH = FAST_TH + 8;   // raw tile (halo 4)
+constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (halo 1)
+
+__global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+                                                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
+                                                   uint32_t* __restrict__ hist) {
+    __shared__ uint8_t raw[FAST_RH][FAST_RW];
+    __shared__ uint8_t sc[FAST_SH][FAST_SW + 2];
+    const int f = blockIdx.y;
+    const int l = level_of_tile(g, blockIdx.x, false);
+    const LevelGeom L = g.lv[l];
+    const int tile = blockIdx.x - L.ftile0;
+    const int ty = tile / L.ftx, tx = tile - ty * L.ftx;
+    const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH;
+    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    const int t = g.fast_thr;
+
+    for (int i = threadIdx.x; i < FAST_RW * FAST_RH; i += 256) {
+        int ry = i / FAST_RW, rx = i - ry * FAST_RW;
+        int gx = min(max(x0 - 4 + rx, 0), L.w - 1), gy = min(max(y0 - 4 + ry, 0), L.h - 1);
+        raw[ry][rx] = img[(int64_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    // scores for positions (x0-1+sx, y0-1+sy); positions past the keep-region's
+    // 1-px halo are not needed (score 0).  All needed positions are >= 3 px inside the level.
+    for (int i = threadIdx.x; i < FAST_SW * FAST_SH; i += 256) {
+        int sy = i / FAST_SW, sx = i - sy * FAST_SW;
+        int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        int score = 0;
+        if (gx <= L.rx1 && gy <= L.ry1) {
+            const int cx = sx + 3, cy = sy + 3;   // raw coords
+            const int v = raw[cy][cx];
+            int p[16];
+            p[0] = raw[cy + 3][cx];     p[1] = raw[cy + 3][cx + 1]; p[2] = raw[cy + 2][cx + 2];
+            p[3] = raw[cy + 1][cx + 3]; p[4] = raw[cy][cx + 3];     p[5] = raw[cy - 1][cx + 3];
+            p[6] = raw[cy - 2][cx + 2]; p[7] = raw[cy - 3][cx + 1]; p[8] = raw[cy - 3][cx];
+            p[9] = raw[cy - 3][cx - 1]; p[10] = raw[cy - 2][cx - 2]; p[11] = raw[cy - 1][cx - 3];
+            p[12] = raw[cy][cx - 3];    p[13] = raw[cy + 1][cx - 3]; p[14] = raw[cy + 2][cx - 2];
+            p[15] = raw[cy + 3][cx - 1];
+            uint32_t bm = 0, dm = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bm |= (uint32_t)(p[k] < v - t) << k;   // centre brighter by > t
+                dm |= (uint32_t)(p[k] > v + t) << k;   // centre darker by > t
+            }
+            if (run9(bm) || run9(dm)) {
+                // cornerScore<16>: max over the 16 arcs of 9 of min(d) and min(-d), minus 1
+                int d[16], mn[16], mx[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) d[k] = v - p[k];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+                int m2n[16], m2x[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { m2n[k] = min(mn[k], mn[(k + 2) & 15]); m2x[k] = max(mx[k], mx[(k + 2) & 15]); }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { mn[k] = min(m2n[k], m2n[(k + 4) & 15]); mx[k] = max(m2x[k], m2x[(k + 4) & 15]); }
+                int best = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    int a = min(mn[k], d[(k + 8) & 15]);        // min over 9-arc starting at k
+                    int b = max(mx[k], d[(k + 8) & 15]);        // max over the same arc
+                    best = max(best, max(a, -b));
+                }
+                score = best - 1;
+            }
+        }
+        sc[sy][sx] = (uint8_t)score;
+    }
+    __syncthreads();
+    // NMS (strictly greater than all 8 neighbours) + emit
+    const int lane = threadIdx.x & 63;
+    uint32_t* ccount = cand_count + (size_t)f * g.nlevels + l;
+    uint32_t* clist = cand + (size_t)f * g.cand_per_frame + L.cand_ofs;
+    uint32_t* h = hist + ((size_t)f * g.nlevels + l) * 256;
+    for (int i = threadIdx.x; i < FAST_TW * FAST_TH; i += 256) {
+        int py = i / FAST_TW, px = i - py * FAST_TW;
+        int gx = x0 + px, gy = y0 + py;
+        int s = sc[py + 1][px + 1];
+        bool keep = s > 0 && gx < L.rx1 && gy < L.ry1 &&
+                    s > sc[py][px] && s > sc[py][px + 1] && s > sc[py][px + 2] &&
+                    s > sc[py + 1][px] && s > sc[py + 1][px + 2] &&
+                    s > sc[py + 2][px] && s > sc[py + 2][px + 1] && s > sc[py + 2][px + 2];
+        uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) {
+                uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < (uint32_t)L.cand_cap)
+                    clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+                atomicAdd(h + s, 1u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.6] GaussianBlur 7x7 sigma 2, 8-bit fixed point, BORDER_REFLECT_101:
+// out = (sum_j k_j * sum_i k_i * p + 2^15) >> 16.  grid (blur_tiles, B), block 256.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+                                                   uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab) {
+    __shared__ uint8_t raw[BLUR_TH + 6][BLUR_TW + 8];
+    __shared__ uint16_t hp[BLUR_TH + 6][BLUR_TW];
+    const int f = blockIdx.y;
+    const int l = level_of_tile(g, blockIdx.x, true);
+    const LevelGeom L = g.lv[l];
+    const int tile = blockIdx.x - L.btile0;
+    const int ty = tile / L.btx, tx = tile - ty * L.btx;
+    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TH;
+    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    uint8_t* out = blur + (int64_t)f * g.frame_bytes + L.ofs;
+    int k[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) k[i] = tab->gk[i];
+    for (int i = threadIdx.x; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+        int ry = i / (BLUR_TW + 6), rx = i - ry * (BLUR_TW + 6);
+        int gx = reflect101(x0 - 3 + rx, L.w), gy = reflect101(y0 - 3 + ry, L.h);
+        raw[ry][rx] = img[(int64_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+        int ry = i / BLUR_TW, rx = i - ry * BLUR_TW;
+        uint32_t a = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a += (uint32_t)k[j] * raw[ry][rx + j];
+        hp[ry][rx] = (uint16_t)a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BLUR_TH * BLUR_TW; i += 256) {
+        int py = i / BLUR_TW, px = i - py * BLUR_TW;
+        int gx = x0 + px, gy = y0 + py;
+        if (gx < L.w && gy < L.h) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a += (uint32_t)k[j] * hp[py + j][px];
+            out[(int64_t)gy * L.pitch + gx] = (uint8_t)((a + (1u << 15)) >> 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.4] retainBest(n): threshold = score of the n-th best; every keypoint
+// with score >= threshold is kept (ties kept).  grid B, block 64 * nlevels.
+// counters layout per frame: see OrbCounters in slideo_capi.hip.
+// ---------------------------------------------------------------------------
+__global__ void threshold_kernel(PyrGeom g, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ cand_count,
+                                 uint32_t* __restrict__ thr, uint32_t* __restrict__ lvl_ofs,
+                                 uint32_t* __restrict__ kp_count, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t kept_s[MAX_LEVELS];
+    const int f = blockIdx.x;
+    const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t* h = hist + ((size_t)f * g.nlevels + l) * 256;
+    // lane i owns bins [4i, 4i+4)
+    uint4 b = reinterpret_cast<const uint4*>(h)[lane];
+    uint32_t mine = b.x + b.y + b.z + b.w;
+    // inclusive suffix sum over lanes (lane 63 = highest scores)
+    uint32_t suf = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_down(suf, d);
+        if (lane + d < 64) suf += o;
+    }
+    const uint32_t total = __shfl(suf, 0);
+    const uint32_t n = (uint32_t)g.lv[l].quota;
+    uint32_t T = 0, kept = total;
+    if (total > n) {
+        if (n == 0) { T = 256; kept = 0; }
+        else {
+            uint32_t above = suf - mine;           // count in bins of higher lanes
+            bool here = above < n && suf >= n;     // the n-th best lies in my 4 bins
+            uint32_t myT = 0, myKept = 0;
+            if (here) {
+                uint32_t c = above;
+                uint32_t bins[4] = {b.x, b.y, b.z, b.w};
+                for (int j = 3; j >= 0; --j) {
+                    c += bins[j];
+                    if (c >= n) { myT = 4 * lane + j; myKept = c; break; }
+                }
+            }
+            uint64_t m = __builtin_amdgcn_ballot_w64(here);
+            int src = __ffsll((long long)m) - 1;
+            T = __shfl(myT, src); kept = __shfl(myKept, src);
+        }
+    }
+    if (lane == 0) {
+        thr[(size_t)f * g.nlevels + l] = T;
+        kept_s[l] = kept;
+        if (cand_count[(size_t)f * g.nlevels + l] > (uint32_t)g.lv[l].cand_cap) atomicOr(flags, 1u);  // impossible by construction
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t o = 0;
+        for (int i = 0; i < g.nlevels; ++i) { lvl_ofs[(size_t)f * g.nlevels + i] = o; o += kept_s[i]; }
+        kp_count[f] = o;
+        if (o > (uint32_t)KP_CAP_PER_FRAME) atomicOr(flags, 2u);
+    }
+}
+
+// Exclusive scan of kp_count over frames -> qofs[B+1]; info = {Qtot, max count}.  One block of 1024.
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ kp_count, int nframes,
+                                                    uint32_t* __restrict__ qofs, uint32_t* __restrict__ info) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t mx[1024];
+    const int per = (nframes + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(nframes, b + per);
+    uint32_t s = 0, m = 0;
+    for (int i = b; i < e; ++i) { s += kp_count[i]; m = max(m, kp_count[i]); }
+    part[threadIdx.x] = s; mx[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, mm = 0;
+        for (int i = 0; i < 1024; ++i) { uint32_t v = part[i]; part[i] = run; run += v; mm = max(mm, mx[i]); }
+        qofs[nframes] = run; info[0] = run; info[1] = mm;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int i = b; i < e; ++i) { qofs[i] = run; run += kp_count[i]; }
+}
+
+// Candidates with score >= threshold -> items.  item = (level << 24 | y << 12 | x) << 8 | score.
+// grid (nlevels, B), block 256.
+__global__ __launch_bounds__(256) void compact_kernel(PyrGeom g, const uint32_t* __restrict__ cand,
+                                                      const uint32_t* __restrict__ cand_count,
+                                                      const uint32_t* __restrict__ thr, const uint32_t* __restrict__ lvl_ofs,
+                                                      const uint32_t* __restrict__ qofs, uint32_t* __restrict__ cursor,
+                                                      uint64_t* __restrict__ items) {
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeom L = g.lv[l];
+    const uint32_t n = min(cand_count[(size_t)f * g.nlevels + l], (uint32_t)L.cand_cap);
+    const uint32_t T = thr[(size_t)f * g.nlevels + l];
+    const uint32_t* clist = cand + (size_t)f * g.cand_per_frame + L.cand_ofs;
+    uint32_t* cur = cursor + (size_t)f * g.nlevels + l;
+    const uint32_t f_kp = qofs[f + 1] - qofs[f];
+    const uint32_t lo = lvl_ofs[(size_t)f * g.nlevels + l];
+    uint64_t* dst = items + qofs[f];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        uint32_t e = clist[i];
+        if ((e >> 24) >= T) {
+            uint32_t slot = lo + atomicAdd(cur, 1u);
+            if (slot < f_kp)
+                dst[slot] = ((uint64_t)(((uint32_t)l << 24) | (e & 0xFFFFFFu)) << 8) | (e >> 24);
+        }
+    }
+}
+
+// Canonical order (octave, y, x): bitonic sort of each frame's items in LDS.
+// grid B, block 1024, dynamic LDS = npow2 * 8 bytes.
+__global__ __launch_bounds__(1024) void sort_kernel(const uint32_t* __restrict__ qofs, uint64_t* __restrict__ items, int npow2) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sbuf[];
+    const int f = blockIdx.x;
+    const uint32_t o = qofs[f], n = qofs[f + 1] - o;
+    if (n <= 1) return;
+    int np = 2;
+    while ((uint32_t)np < n) np <<= 1;     // np <= npow2
+    for (int i = threadIdx.x; i < np; i += 1024) sbuf[i] = (uint32_t)i < n ? items[o + i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += 1024) {
+                int p = i ^ j;
+                if (p > i) {
+                    uint64_t a = sbuf[i], b = sbuf[p];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { sbuf[i] = b; sbuf[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) items[o + i] = sbuf[i];
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.5] fastAtan2 (f32) ; [OCV A.5] ICAngles ; [OCV A.7] rotated BRIEF-256
+// One wave per keypoint, 4 keypoints per block.  grid ceil(Qtot/4).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2f_cv(float y, float x) {
+    const float s = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
+                p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+                                                       const uint8_t* __restrict__ blur,
+                                                       const OrbTables* __restrict__ tab,
+                                                       const uint32_t* __restrict__ qofs, int nframes,
+                                                       const uint64_t* __restrict__ items, uint32_t qtot,
+                                                       slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc) {
+    const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gi >= qtot) return;
+    // frame of this keypoint: last f with qofs[f] <= gi (wave-uniform binary search)
+    int lo = 0, hi = nframes;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
+    const int f = lo;
+    const uint64_t it = items[gi];
+    const int score = (int)(it & 255), px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
+    const LevelGeom L = g.lv[l];
+    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    const uint8_t* bl = blur + (int64_t)f * g.frame_bytes + L.ofs;
+    const int half = g.half_patch;
+    // intensity centroid over the disc |u| <= umax[|v|], lanes across u
+    int m10 = 0, m01 = 0;
+    for (int u0 = -half; u0 <= half; u0 += 64) {
+        const int u = u0 + lane;
+        if (u <= half) {
+            for (int v = -half; v <= half; ++v) {
+                const int av = v < 0 ? -v : v;
+                if ((u < 0 ? -u : u) <= tab->umax[av]) {
+                    int p = img[(int64_t)(py + v) * L.pitch + px + u];
+                    m10 += u * p; m01 += v * p;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    const float angle = fast_atan2f_cv((float)m01, (float)m10);
+    const float sf = L.scale;
+    const float kx = (float)px * sf, ky = (float)py * sf;
+    // computeOrbDescriptors: centre = cvRound(pt * (1/scale)) on the blurred level
+    const float inv = 1.f / sf;
+    const float ang = angle * (float)(3.14159265358979323846 / 180.f);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const int cx = (int)rintf(kx * inv), cy = (int)rintf(ky * inv);
+    uint64_t bits[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int pair = lane + 64 * w;          // descriptor bit index
+        const int i0 = 2 * pair, i1 = i0 + 1;
+        const float p0x = (float)tab->pattern[2 * i0], p0y = (float)tab->pattern[2 * i0 + 1];
+        const float p1x = (float)tab->pattern[2 * i1], p1y = (float)tab->pattern[2 * i1 + 1];
+        const float x0 = p0x * a - p0y * b, y0 = p0x * b + p0y * a;
+        const float x1 = p1x * a - p1y * b, y1 = p1x * b + p1y * a;
+        const int t0 = bl[(int64_t)(cy + (int)rintf(y0)) * L.pitch + cx + (int)rintf(x0)];
+        const int t1 = bl[(int64_t)(cy + (int)rintf(y1)) * L.pitch + cx + (int)rintf(x1)];
+        bits[w] = __builtin_amdgcn_ballot_w64(t0 < t1);
+    }
+    if (lane < 4) reinterpret_cast<uint64_t*>(desc + (size_t)gi * 32)[lane] = bits[lane];
+    if (lane == 0) {
+        slideo_keypoint k;
+        k.x = kx; k.y = ky; k.size = (float)g.patch_size * sf; k.angle = angle;
+        k.response = (float)score; k.octave = l;
+        kp[gi] = k;
+    }
+}
+
+}  // namespace slideo

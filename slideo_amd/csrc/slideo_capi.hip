@@ -1,0 +1,741 @@
+// slideo_capi.hip — implementation of include/slideo_amd.h for gfx950.
+//
+// Host-side runtime of the matcher: device-resident page database, per-frame-size
+// geometry cache, growing workspace, batched kernel pipeline on one HIP stream.
+// No CPU fallback exists: every compute entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "geom.h"
+#include "knn.hip.h"
+#include "orb.hip.h"
+#include "slideo_amd.h"
+#include "verify.hip.h"
+
+using namespace slideo;
+
+namespace {
+
+constexpr int KLIST = 32;
+
+struct GeomEntry {
+    int w = 0, h = 0;
+    PyrGeom g;
+    DevBuf lin_tab;
+};
+
+struct HostPage {
+    int w = 0, h = 0, sw = 0, sh = 0, area_idx = -1;
+    std::vector<slideo_keypoint> kp;
+    std::vector<uint8_t> desc;
+    std::vector<uint8_t> small_img;
+};
+
+struct OrbOut {            // where the last run_orb left its results (device)
+    uint32_t qtot = 0, max_count = 0;
+    int nframes = 0;
+    std::vector<uint32_t> qofs;   // host copy, nframes+1
+};
+
+}  // namespace
+
+struct slideo_matcher {
+    slideo_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    slideo_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
+    size_t ws_budget = (size_t)12 << 30;
+
+    DevBuf d_tables, d_rng;
+    std::vector<std::unique_ptr<GeomEntry>> geoms;
+
+    // INTER_AREA size classes
+    std::vector<AreaGeom> area_geoms;
+    std::vector<AreaTap> area_taps;
+    std::vector<int32_t> area_idx;
+    DevBuf d_area_geoms, d_area_taps, d_area_idx;
+    bool area_dirty = true;
+
+    // pages
+    std::vector<HostPage> pages;
+    bool finalized = false;
+    int64_t M = -1;
+    DevBuf d_train, d_train_page, d_page_xy, d_pageinfo, d_page_small;
+
+    // workspace
+    DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_prev_small, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_small, d_ssd;
+    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist;
+    PinBuf h_info, h_verdicts;
+    OrbOut orb;
+
+    // trace of the last match call
+    std::vector<FrameCands> last_fcs;
+    std::vector<slideo_verdict> last_verdicts;
+};
+
+namespace {
+
+std::string g_create_error;
+std::mutex g_err_mutex;
+
+VerifyParams make_vp(const slideo_config& c) {
+    VerifyParams v{};
+    v.k = c.knn_k; v.klist = KLIST; v.max_cand = c.max_candidate_pages; v.max_rated = c.max_rated;
+    v.tol = c.vote_tolerance; v.min_similarity = c.min_similarity;
+    v.thr = c.ransac_threshold; v.conf = c.ransac_confidence; v.min_rating = c.min_rating;
+    v.min_rating_ratio = c.min_rating_ratio; v.max_iters = c.ransac_max_iters; v.refine_iters = c.refine_iters;
+    return v;
+}
+
+void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail(SLIDEO_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+}
+
+GeomEntry& geom_for(slideo_matcher* m, int w, int h) {
+    for (auto& g : m->geoms) if (g->w == w && g->h == h) return *g;
+    if (w < 1 || h < 1 || w > MAX_DIM || h > MAX_DIM)
+        fail(SLIDEO_ERR_UNSUPPORTED, "image size %dx%d outside 1..%d", w, h, MAX_DIM);
+    auto e = std::make_unique<GeomEntry>();
+    e->w = w; e->h = h;
+    std::vector<uint32_t> tab;
+    build_pyr_geom(w, h, m->cfg, e->g, tab);
+    if (tab.empty()) tab.push_back(0);
+    e->lin_tab.reserve(tab.size() * 4);
+    HIP_CHECK(hipMemcpyAsync(e->lin_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->geoms.push_back(std::move(e));
+    return *m->geoms.back();
+}
+
+int area_class_for(slideo_matcher* m, int w, int h) {
+    for (size_t i = 0; i < m->area_geoms.size(); ++i)
+        if (m->area_geoms[i].sw == w && m->area_geoms[i].sh == h) return (int)i;
+    AreaGeom a;
+    if (!build_area_geom(w, h, m->cfg.small_area, a, m->area_taps, m->area_idx))
+        fail(SLIDEO_ERR_UNSUPPORTED, "image %dx%d has area below small_area=%d: to_small_image would upscale (INTER_AREA falls back to bilinear in OpenCV), not implemented",
+             w, h, m->cfg.small_area);
+    m->area_geoms.push_back(a);
+    m->area_dirty = true;
+    return (int)m->area_geoms.size() - 1;
+}
+
+void upload_area(slideo_matcher* m) {
+    if (!m->area_dirty) return;
+    m->d_area_geoms.reserve(m->area_geoms.size() * sizeof(AreaGeom));
+    m->d_area_taps.reserve(m->area_taps.size() * sizeof(AreaTap));
+    m->d_area_idx.reserve(m->area_idx.size() * 4);
+    HIP_CHECK(hipMemcpyAsync(m->d_area_geoms.p, m->area_geoms.data(), m->area_geoms.size() * sizeof(AreaGeom), hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->d_area_taps.p, m->area_taps.data(), m->area_taps.size() * sizeof(AreaTap), hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->d_area_idx.p, m->area_idx.data(), m->area_idx.size() * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->area_dirty = false;
+}
+
+// max frames of size (w,h) per sub-batch under the workspace budget
+int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
+    size_t per = (size_t)g.frame_bytes * 2 + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
+    size_t fit = std::max<size_t>(1, m->ws_budget / std::max<size_t>(per, 1));
+    return (int)std::min<size_t>({(size_t)n, fit, (size_t)4096});
+}
+
+// ---- ORB over `n` equally sized frames already on the device -------------------
+// Leaves: d_qofs[n+1], d_kp[qtot], d_desc[qtot*32]; m->orb filled.  `blurred_needed` always true.
+void run_orb(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+             hipStream_t st, bool keep_host_qofs) {
+    GeomEntry& ge = geom_for(m, w, h);
+    const PyrGeom& g = ge.g;
+    const int L = g.nlevels;
+    m->d_pyr.reserve((size_t)g.frame_bytes * n);
+    m->d_blur.reserve((size_t)g.frame_bytes * n);
+    m->d_cand.reserve(std::max<size_t>((size_t)g.cand_per_frame * n * 4, 16));
+    const size_t n_cc = (size_t)n * L;
+    m->d_hist.reserve(n_cc * 256 * 4);
+    m->d_candcount.reserve(n_cc * 2 * 4);
+    m->d_flags.reserve(16);
+    uint32_t* hist = m->d_hist.as<uint32_t>();
+    uint32_t* cand_count = m->d_candcount.as<uint32_t>();
+    uint32_t* cursor = cand_count + n_cc;
+    uint32_t* flags = m->d_flags.as<uint32_t>();
+    HIP_CHECK(hipMemsetAsync(hist, 0, n_cc * 256 * 4, st));
+    HIP_CHECK(hipMemsetAsync(cand_count, 0, n_cc * 2 * 4, st));
+    HIP_CHECK(hipMemsetAsync(flags, 0, 16, st));
+    m->d_thr.reserve(n_cc * 4); m->d_lvlofs.reserve(n_cc * 4); m->d_kpcount.reserve((size_t)n * 4);
+    m->d_qofs.reserve((size_t)(n + 1) * 4); m->d_info.reserve(64);
+    m->h_info.reserve(64);
+
+    const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
+    {
+        dim3 grid(cdiv(cdiv(w, 4), 256), h, n);
+        gray_kernel<<<grid, 256, 0, st>>>(frames_dev, frame_stride, stride, m->d_pyr.as<uint8_t>(), g.frame_bytes, w, h,
+                                          g.lv[0].pitch, aligned4);
+        check_launch("gray_kernel");
+    }
+    for (int l = 1; l < L; ++l) {
+        if (g.lv[l].w <= 0 || g.lv[l].h <= 0) continue;
+        dim3 grid(cdiv(cdiv(g.lv[l].w, 4), 256), g.lv[l].h, n);
+        resize_kernel<<<grid, 256, 0, st>>>(m->d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>());
+        check_launch("resize_kernel");
+    }
+    if (g.fast_tiles > 0) {
+        fast_kernel<<<dim3(g.fast_tiles, n), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_cand.as<uint32_t>(), cand_count, hist);
+        check_launch("fast_kernel");
+    }
+    if (g.blur_tiles > 0) {
+        blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+        check_launch("blur_kernel");
+    }
+    threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, m->d_thr.as<uint32_t>(), m->d_lvlofs.as<uint32_t>(),
+                                           m->d_kpcount.as<uint32_t>(), flags);
+    check_launch("threshold_kernel");
+    scan_kernel<<<1, 1024, 0, st>>>(m->d_kpcount.as<uint32_t>(), n, m->d_qofs.as<uint32_t>(), m->d_info.as<uint32_t>());
+    check_launch("scan_kernel");
+    HIP_CHECK(hipMemcpyAsync(m->h_info.p, m->d_info.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(m->h_info.as<uint32_t>() + 2, flags, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t qtot = m->h_info.as<uint32_t>()[0], maxc = m->h_info.as<uint32_t>()[1], fl = m->h_info.as<uint32_t>()[2];
+    if (fl & 1u) fail(SLIDEO_ERR_HIP, "internal: FAST candidate list overflow");
+    if (fl & 2u)
+        fail(SLIDEO_ERR_CAPACITY, "a frame produced %u keypoints (ties at the retainBest threshold are kept, as in OpenCV); the in-LDS canonical sort holds %d",
+             maxc, KP_CAP_PER_FRAME);
+    m->orb.qtot = qtot; m->orb.max_count = maxc; m->orb.nframes = n;
+    m->d_items.reserve(std::max<size_t>((size_t)qtot * 8, 16));
+    m->d_kp.reserve(std::max<size_t>((size_t)qtot * sizeof(slideo_keypoint), 16));
+    m->d_desc.reserve(std::max<size_t>((size_t)qtot * 32, 32));
+    if (qtot > 0) {
+        compact_kernel<<<dim3(L, n), 256, 0, st>>>(g, m->d_cand.as<uint32_t>(), cand_count, m->d_thr.as<uint32_t>(),
+                                                   m->d_lvlofs.as<uint32_t>(), m->d_qofs.as<uint32_t>(), cursor,
+                                                   m->d_items.as<uint64_t>());
+        check_launch("compact_kernel");
+        int np2 = 2;
+        while ((uint32_t)np2 < maxc) np2 <<= 1;
+        sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(m->d_qofs.as<uint32_t>(), m->d_items.as<uint64_t>(), np2);
+        check_launch("sort_kernel");
+        describe_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_blur.as<uint8_t>(),
+                                                            m->d_tables.as<OrbTables>(), m->d_qofs.as<uint32_t>(), n,
+                                                            m->d_items.as<uint64_t>(), qtot, m->d_kp.as<slideo_keypoint>(),
+                                                            m->d_desc.as<uint8_t>());
+        check_launch("describe_kernel");
+    }
+    if (keep_host_qofs) {
+        m->orb.qofs.resize(n + 1);
+        HIP_CHECK(hipMemcpyAsync(m->orb.qofs.data(), m->d_qofs.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+}
+
+// ---- exact Hamming kNN: keys into d_keys[0 .. nq*KLIST) -------------------------------
+void run_knn(slideo_matcher* m, const uint32_t* q_dev, int nq, const uint32_t* t_dev, int nt, hipStream_t st) {
+    if (nq <= 0) return;
+    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    const int qblocks = cdiv(nq, KNN_BLOCK);
+    int nseg = 1;
+    if (qblocks < 1024) nseg = std::min(cdiv(1024, qblocks), std::max(1, nt / 4096));
+    nseg = std::max(1, std::min(nseg, 256));
+    const int seg_len = cdiv(std::max(nt, 1), nseg);
+    m->d_keys.reserve((size_t)nseg * nq * KLIST * 4);
+    knn_hamming_kernel<KLIST><<<dim3(qblocks, nseg), KNN_BLOCK, 0, st>>>(q_dev, nq, t_dev, nt, seg_len, m->d_keys.as<uint32_t>());
+    check_launch("knn_hamming_kernel");
+    if (nseg > 1) {
+        knn_merge_kernel<KLIST><<<qblocks, KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg);
+        check_launch("knn_merge_kernel");
+    }
+}
+
+// ---- to_small_image of n equally sized device images into d_small ----------------------
+void run_small(slideo_matcher* m, const uint8_t* imgs_dev, int n, int w, int h, int stride, int64_t img_stride,
+               int& sw, int& sh, hipStream_t st) {
+    int ac = area_class_for(m, w, h);
+    upload_area(m);
+    const AreaGeom& ag = m->area_geoms[ac];
+    sw = ag.dw; sh = ag.dh;
+    m->d_small.reserve((size_t)n * sw * sh * 3);
+    int tiles = cdiv(sw, SM_TW) * cdiv(sh, SM_TH);
+    small_image_kernel<<<dim3(tiles, n), 256, 0, st>>>(ag, m->d_area_taps.as<AreaTap>(), m->d_area_idx.as<int32_t>(), imgs_dev,
+                                                       img_stride, stride, m->d_small.as<uint8_t>(), (int64_t)sw * sh * 3);
+    check_launch("small_image_kernel");
+}
+
+void upload_frames(slideo_matcher* m, const uint8_t* host, int n, int h, int stride, int64_t frame_stride, hipStream_t st) {
+    // copies n frames so that the device layout keeps (stride, frame_stride') with frame_stride' = h*stride
+    const size_t fb = (size_t)h * stride;
+    m->d_stage.reserve(fb * n + 16);
+    if ((size_t)frame_stride == fb) {
+        HIP_CHECK(hipMemcpyAsync(m->d_stage.p, host, fb * n, hipMemcpyHostToDevice, st));
+    } else {
+        for (int i = 0; i < n; ++i)
+            HIP_CHECK(hipMemcpyAsync(m->d_stage.as<uint8_t>() + fb * i, host + (size_t)frame_stride * i, fb, hipMemcpyHostToDevice, st));
+    }
+}
+
+void validate_image(int w, int h, int stride) {
+    if (w < 1 || h < 1 || stride < w * 3) fail(SLIDEO_ERR_INVALID_ARG, "bad image geometry w=%d h=%d stride=%d", w, h, stride);
+}
+
+// ---- the per-frame hot path over one sub-batch of device frames ------------------------
+void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+                     slideo_verdict* out_host, hipStream_t st) {
+    const slideo_config& c = m->cfg;
+    run_orb(m, frames_dev, n, w, h, stride, frame_stride, st, false);
+    const uint32_t qtot = m->orb.qtot;
+    const VerifyParams vp = make_vp(c);
+    const int P = (int)m->pages.size();
+    m->d_fcs.reserve((size_t)n * sizeof(FrameCands));
+    m->d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
+    HIP_CHECK(hipMemsetAsync(m->d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
+    uint32_t* flags = m->d_flags.as<uint32_t>();   // zeroed by run_orb
+    if (qtot > 0) {
+        run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), (int)m->M, st);
+        m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
+        m->d_gpts.reserve((size_t)qtot * c.knn_k * sizeof(float4));
+        m->d_gmask.reserve((size_t)qtot * c.knn_k);
+        const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
+        vote_kernel<<<n, 256, lds, st>>>(vp, m->d_keys.as<uint32_t>(), m->d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
+                                         m->d_fcs.as<FrameCands>(), m->d_votes.as<uint2>());
+        check_launch("vote_kernel");
+        ransac_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(vp, m->d_qofs.as<uint32_t>(), m->d_kp.as<slideo_keypoint>(),
+                                                                     m->d_page_xy.as<float2>(), m->d_votes.as<uint2>(),
+                                                                     m->d_rng.as<uint32_t>(), m->d_fcs.as<FrameCands>(),
+                                                                     m->d_gpts.as<float4>(), m->d_gmask.as<uint8_t>(), flags);
+        check_launch("ransac_kernel");
+        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_fcs.as<FrameCands>());
+        check_launch("rate_kernel");
+        int max_tiles = 0;
+        for (const AreaGeom& ag : m->area_geoms) max_tiles = std::max(max_tiles, cdiv(ag.dw, SM_TW) * cdiv(ag.dh, SM_TH));
+        reproject_kernel<<<dim3(max_tiles, c.max_rated, n), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
+                                                                          m->d_area_idx.as<int32_t>(), m->d_pageinfo.as<PageInfo>(),
+                                                                          m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
+                                                                          stride, w, h, m->d_fcs.as<FrameCands>());
+        check_launch("reproject_kernel");
+    }
+    verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), m->d_fcs.as<FrameCands>(),
+                                               m->d_verdicts.as<slideo_verdict>());
+    check_launch("verdict_kernel");
+    m->h_verdicts.reserve((size_t)n * sizeof(slideo_verdict) + 16);
+    HIP_CHECK(hipMemcpyAsync(m->h_verdicts.p, m->d_verdicts.p, (size_t)n * sizeof(slideo_verdict), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), flags, 4, hipMemcpyDeviceToHost, st));
+    const size_t base = m->last_fcs.size();
+    m->last_fcs.resize(base + n);
+    HIP_CHECK(hipMemcpyAsync(m->last_fcs.data() + base, m->d_fcs.p, (size_t)n * sizeof(FrameCands), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    uint32_t fl;
+    std::memcpy(&fl, m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), 4);
+    if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
+    std::memcpy(out_host, m->h_verdicts.p, (size_t)n * sizeof(slideo_verdict));
+}
+
+void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_device, int w, int h, int stride,
+                       int64_t frame_stride, slideo_verdict* out, hipStream_t st) {
+    if (!m->finalized) fail(SLIDEO_ERR_STATE, "slideo_matcher_finalize_pages must be called before matching");
+    if (m->M <= 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
+    if (n < 0 || (n > 0 && (!frames || !out))) fail(SLIDEO_ERR_INVALID_ARG, "null frames/verdicts");
+    validate_image(w, h, stride);
+    if (frame_stride < (int64_t)h * stride) fail(SLIDEO_ERR_INVALID_ARG, "frame_stride smaller than one frame");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->last_fcs.clear();
+    GeomEntry& ge = geom_for(m, w, h);
+    area_class_for(m, w, h);   // frames never need a small image here, but keep classes warm for the changed mask
+    upload_area(m);
+    const int sub = sub_batch_for(m, ge.g, n);
+    for (int i = 0; i < n; i += sub) {
+        const int cnt = std::min(sub, n - i);
+        const uint8_t* dev;
+        int64_t fs = frame_stride;
+        if (on_device) dev = frames + (int64_t)i * frame_stride;
+        else {
+            upload_frames(m, frames + (int64_t)i * frame_stride, cnt, h, stride, frame_stride, st);
+            dev = m->d_stage.as<uint8_t>(); fs = (int64_t)h * stride;
+        }
+        match_sub_batch(m, dev, cnt, w, h, stride, fs, out + i, st);
+        if (m->progress) m->progress(m->progress_user, (uint64_t)(i + cnt), (uint64_t)n, "Processing frames...");
+    }
+    m->last_verdicts.assign(out, out + n);
+}
+
+void set_err(slideo_matcher* m, const char* what) {
+    if (m) m->err = what;
+    else { std::lock_guard<std::mutex> lk(g_err_mutex); g_create_error = what; }
+}
+
+}  // namespace
+
+#define API_TRY try {
+#define API_CATCH(m)                                                          \
+    }                                                                         \
+    catch (const slideo::Error& e) { set_err(m, e.what()); return e.code; }   \
+    catch (const std::exception& e) { set_err(m, e.what()); return SLIDEO_ERR_HIP; } \
+    catch (...) { set_err(m, "unknown error"); return SLIDEO_ERR_HIP; }       \
+    return SLIDEO_OK;
+
+extern "C" {
+
+uint32_t slideo_abi_version(void) { return SLIDEO_ABI_VERSION; }
+
+void slideo_config_default(slideo_config* c) {
+    if (!c) return;
+    c->nfeatures = 2000; c->scale_factor = 1.2f; c->nlevels = 8; c->edge_threshold = 62;
+    c->patch_size = 62; c->fast_threshold = 20;
+    c->knn_k = 30; c->vote_tolerance = 1.05f; c->max_candidate_pages = 40;
+    c->ransac_threshold = 3.0; c->ransac_max_iters = 2000; c->ransac_confidence = 0.99; c->refine_iters = 10;
+    c->max_rated = 10; c->min_rating = 50.0; c->min_rating_ratio = 0.2;
+    c->min_similarity = 0.5f; c->small_area = 300 * 400; c->changed_similarity = 0.98f;
+}
+
+const char* slideo_last_error(const slideo_matcher* m) {
+    if (m) return m->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_create_error;
+    return copy.c_str();
+}
+
+int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_matcher** out) {
+    slideo_matcher* m = nullptr;
+    API_TRY
+    if (!cfg || !out) fail(SLIDEO_ERR_INVALID_ARG, "null cfg/out");
+    *out = nullptr;
+    const char* why = "";
+    if (!config_supported(*cfg, &why)) fail(SLIDEO_ERR_UNSUPPORTED, "unsupported config: %s", why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(SLIDEO_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) fail(SLIDEO_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        fail(SLIDEO_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<slideo_matcher> mm(new slideo_matcher());
+    mm->cfg = *cfg; mm->device = device;
+    if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
+    HIP_CHECK(hipStreamCreateWithFlags(&mm->stream, hipStreamNonBlocking));
+    OrbTables t{};
+    umax_table(cfg->patch_size / 2, t.umax);
+    gauss7_fixed(t.gk);
+    brief_pattern(cfg->patch_size, t.pattern);
+    mm->d_tables.reserve(sizeof(OrbTables));
+    HIP_CHECK(hipMemcpy(mm->d_tables.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    std::vector<uint32_t> rng(RNG_TABLE);
+    CvRng r((uint64_t)-1);
+    for (auto& v : rng) v = r.next();
+    mm->d_rng.reserve(rng.size() * 4);
+    HIP_CHECK(hipMemcpy(mm->d_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    m = mm.release();
+    *out = m;
+    API_CATCH(nullptr)
+}
+
+void slideo_matcher_destroy(slideo_matcher* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    delete m;
+}
+
+int32_t slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    m->progress = fn; m->progress_user = user;
+    return SLIDEO_OK;
+}
+
+int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const uint8_t* const* data, const int32_t* width,
+                                      const int32_t* height, const int32_t* stride_bytes) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (m->finalized) fail(SLIDEO_ERR_STATE, "pages cannot be added after finalize");
+    if (n_pages < 0 || (n_pages > 0 && (!data || !width || !height || !stride_bytes))) fail(SLIDEO_ERR_INVALID_ARG, "null page arrays");
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const uint64_t total = (uint64_t)n_pages;
+    if (m->progress) m->progress(m->progress_user, 0, total, "Analyzing PDF pages...");     // lib.rs:43
+    int i = 0;
+    while (i < n_pages) {
+        // group a run of equally sized pages into one batch
+        const int w = width[i], h = height[i], stride = stride_bytes[i];
+        if (!data[i]) fail(SLIDEO_ERR_INVALID_ARG, "page %d is null", i);
+        validate_image(w, h, stride);
+        GeomEntry& ge = geom_for(m, w, h);
+        int cap = std::min(sub_batch_for(m, ge.g, n_pages - i), 64), cnt = 1;
+        while (cnt < cap && width[i + cnt] == w && height[i + cnt] == h && stride_bytes[i + cnt] == stride && data[i + cnt]) ++cnt;
+        const size_t fb = (size_t)h * stride;
+        m->d_stage.reserve(fb * cnt + 16);
+        for (int j = 0; j < cnt; ++j)
+            HIP_CHECK(hipMemcpyAsync(m->d_stage.as<uint8_t>() + fb * j, data[i + j], fb, hipMemcpyHostToDevice, st));
+        run_orb(m, m->d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, st, true);
+        const uint32_t qtot = m->orb.qtot;
+        std::vector<slideo_keypoint> kp(qtot);
+        std::vector<uint8_t> desc((size_t)qtot * 32);
+        if (qtot) {
+            HIP_CHECK(hipMemcpyAsync(kp.data(), m->d_kp.p, (size_t)qtot * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(desc.data(), m->d_desc.p, (size_t)qtot * 32, hipMemcpyDeviceToHost, st));
+        }
+        int sw = 0, sh = 0;
+        run_small(m, m->d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, sw, sh, st);
+        std::vector<uint8_t> smalls((size_t)cnt * sw * sh * 3);
+        HIP_CHECK(hipMemcpyAsync(smalls.data(), m->d_small.p, smalls.size(), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const int ac = area_class_for(m, w, h);
+        for (int j = 0; j < cnt; ++j) {
+            HostPage pg;
+            pg.w = w; pg.h = h; pg.sw = sw; pg.sh = sh; pg.area_idx = ac;
+            const uint32_t a = m->orb.qofs[j], b = m->orb.qofs[j + 1];
+            pg.kp.assign(kp.begin() + a, kp.begin() + b);
+            pg.desc.assign(desc.begin() + (size_t)a * 32, desc.begin() + (size_t)b * 32);
+            pg.small_img.assign(smalls.begin() + (size_t)j * sw * sh * 3, smalls.begin() + (size_t)(j + 1) * sw * sh * 3);
+            m->pages.push_back(std::move(pg));
+            if (m->progress) m->progress(m->progress_user, (uint64_t)(i + j + 1), total, "Analyzing PDF pages...");   // lib.rs:49-53
+        }
+        i += cnt;
+    }
+    if (m->progress) m->progress(m->progress_user, total, total, "PDF page analysis successful.");   // lib.rs:58
+    API_CATCH(m)
+}
+
+int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (m->finalized) fail(SLIDEO_ERR_STATE, "already finalized");
+    HIP_CHECK(hipSetDevice(m->device));
+    const int P = (int)m->pages.size();
+    if (P > 16384) fail(SLIDEO_ERR_UNSUPPORTED, "%d pages exceed the 16384 the vote kernel's LDS layout holds", P);
+    int64_t M = 0, small_bytes = 0;
+    for (const HostPage& p : m->pages) { M += (int64_t)p.kp.size(); small_bytes += (int64_t)p.small_img.size(); }
+    if (M >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "%lld descriptors exceed 2^23", (long long)M);
+    std::vector<uint8_t> train((size_t)M * 32);
+    std::vector<int32_t> tpage((size_t)M);
+    std::vector<float2> xy((size_t)M);
+    std::vector<PageInfo> info(P);
+    std::vector<uint8_t> smalls((size_t)small_bytes);
+    int64_t row = 0, sofs = 0;
+    for (int p = 0; p < P; ++p) {
+        const HostPage& pg = m->pages[p];
+        PageInfo& pi = info[p];
+        pi.w = pg.w; pi.h = pg.h; pi.area_idx = pg.area_idx; pi.sw = pg.sw; pi.sh = pg.sh;
+        pi.kp_ofs = (int32_t)row; pi.kp_cnt = (int32_t)pg.kp.size(); pi._pad = 0; pi.small_ofs = sofs;
+        std::memcpy(train.data() + (size_t)row * 32, pg.desc.data(), pg.desc.size());
+        for (size_t i = 0; i < pg.kp.size(); ++i) { tpage[row + i] = p; xy[row + i] = make_float2(pg.kp[i].x, pg.kp[i].y); }
+        std::memcpy(smalls.data() + sofs, pg.small_img.data(), pg.small_img.size());
+        row += (int64_t)pg.kp.size(); sofs += (int64_t)pg.small_img.size();
+    }
+    m->d_train.reserve(std::max<size_t>(train.size(), 64) + 64);   // + slack: the kNN loop reads whole rows only, no overrun
+    m->d_train_page.reserve(std::max<size_t>(tpage.size() * 4, 16));
+    m->d_page_xy.reserve(std::max<size_t>(xy.size() * sizeof(float2), 16));
+    m->d_pageinfo.reserve(std::max<size_t>(info.size() * sizeof(PageInfo), 16));
+    m->d_page_small.reserve(std::max<size_t>(smalls.size(), 16));
+    if (M > 0) {
+        HIP_CHECK(hipMemcpy(m->d_train.p, train.data(), train.size(), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    if (P > 0) {
+        HIP_CHECK(hipMemcpy(m->d_pageinfo.p, info.data(), info.size() * sizeof(PageInfo), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(m->d_page_small.p, smalls.data(), smalls.size(), hipMemcpyHostToDevice));
+    }
+    upload_area(m);
+    m->M = M;
+    m->finalized = true;
+    if (M == 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
+    API_CATCH(m)
+}
+
+int32_t slideo_matcher_page_count(const slideo_matcher* m) { return m ? (int32_t)m->pages.size() : -1; }
+int64_t slideo_matcher_descriptor_count(const slideo_matcher* m) { return m && m->finalized ? m->M : -1; }
+
+int32_t slideo_matcher_get_page_features(const slideo_matcher* cm, int32_t page_idx, slideo_keypoint* kp, uint8_t* desc32,
+                                         int32_t capacity, int32_t* n_out) {
+    slideo_matcher* m = const_cast<slideo_matcher*>(cm);
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (page_idx < 0 || page_idx >= (int)m->pages.size()) fail(SLIDEO_ERR_INVALID_ARG, "page %d out of range", page_idx);
+    const HostPage& pg = m->pages[page_idx];
+    if (n_out) *n_out = (int32_t)pg.kp.size();
+    if ((int)pg.kp.size() > capacity) fail(SLIDEO_ERR_CAPACITY, "page has %zu keypoints, capacity %d", pg.kp.size(), capacity);
+    if (kp) std::memcpy(kp, pg.kp.data(), pg.kp.size() * sizeof(slideo_keypoint));
+    if (desc32) std::memcpy(desc32, pg.desc.data(), pg.desc.size());
+    API_CATCH(m)
+}
+
+int32_t slideo_match_frames_bgr8(slideo_matcher* m, int32_t n_frames, const uint8_t* frames, int32_t width, int32_t height,
+                                 int32_t stride_bytes, int64_t frame_stride_bytes, slideo_verdict* verdicts_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    match_frames_impl(m, n_frames, frames, false, width, height, stride_bytes, frame_stride_bytes, verdicts_out, m->stream);
+    API_CATCH(m)
+}
+
+int32_t slideo_match_frames_bgr8_dev(slideo_matcher* m, int32_t n_frames, const uint8_t* frames_dev, int32_t width, int32_t height,
+                                     int32_t stride_bytes, int64_t frame_stride_bytes, slideo_verdict* verdicts_out, void* hip_stream) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->stream;
+    match_frames_impl(m, n_frames, frames_dev, true, width, height, stride_bytes, frame_stride_bytes, verdicts_out, st);
+    API_CATCH(m)
+}
+
+int32_t slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_batch, slideo_candidate* out, int32_t capacity,
+                                     int32_t* n_out) {
+    if (!m || !n_out) return SLIDEO_ERR_INVALID_ARG;
+    if (frame_in_batch < 0 || frame_in_batch >= (int)m->last_fcs.size()) return SLIDEO_ERR_INVALID_ARG;
+    const FrameCands& fc = m->last_fcs[frame_in_batch];
+    *n_out = fc.ncand;
+    if (fc.ncand > capacity) return SLIDEO_ERR_CAPACITY;
+    for (int i = 0; i < fc.ncand; ++i) {
+        slideo_candidate& c = out[i];
+        c.page_idx = fc.page[i]; c.n_votes = fc.count[i]; c.inliers = fc.inliers[i]; c.survived = 0; c.similarity = 0.f;
+        for (int j = 0; j < 6; ++j) c.transform[j] = fc.M[i][j];
+        for (int s = 0; s < fc.nsurv; ++s) if (fc.surv[s] == i) { c.survived = 1; c.similarity = fc.sim[s]; }
+    }
+    return SLIDEO_OK;
+}
+
+int32_t slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames, const uint8_t* frames, int32_t width, int32_t height,
+                                 int32_t stride_bytes, int64_t frame_stride_bytes, const uint8_t* prev_small,
+                                 uint8_t* last_small_out, uint8_t* changed_out, float* similarity_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (n_frames < 0 || (n_frames > 0 && (!frames || !changed_out))) fail(SLIDEO_ERR_INVALID_ARG, "null frames/changed");
+    validate_image(width, height, stride_bytes);
+    if (n_frames == 0) return SLIDEO_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int sw = 0, sh = 0;
+    // all small images of the run live in d_small with one leading slot for the previous frame
+    const size_t fb = (size_t)height * stride_bytes;
+    upload_frames(m, frames, n_frames, height, stride_bytes, frame_stride_bytes, st);
+    run_small(m, m->d_stage.as<uint8_t>(), n_frames, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
+    const size_t sb = (size_t)sw * sh * 3;
+    DevBuf& prev = m->d_prev_small;
+    prev.reserve(sb);
+    if (prev_small) HIP_CHECK(hipMemcpyAsync(prev.p, prev_small, sb, hipMemcpyHostToDevice, st));
+    m->d_ssd.reserve((size_t)n_frames * 8);
+    // pair i: (small[i-1], small[i]); pair 0 uses prev
+    if (prev_small) {
+        ssd_kernel<<<1, 256, 0, st>>>(prev.as<uint8_t>(), 0, m->d_small.as<uint8_t>(), 0, (int64_t)sb, m->d_ssd.as<unsigned long long>());
+        check_launch("ssd_kernel");
+    }
+    if (n_frames > 1) {
+        ssd_kernel<<<n_frames - 1, 256, 0, st>>>(m->d_small.as<uint8_t>(), (int64_t)sb, m->d_small.as<uint8_t>() + sb, (int64_t)sb, (int64_t)sb,
+                                                 m->d_ssd.as<unsigned long long>() + 1);
+        check_launch("ssd_kernel");
+    }
+    std::vector<unsigned long long> ssd(n_frames, 0);
+    HIP_CHECK(hipMemcpyAsync(ssd.data(), m->d_ssd.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, st));
+    if (last_small_out)
+        HIP_CHECK(hipMemcpyAsync(last_small_out, m->d_small.as<uint8_t>() + sb * (n_frames - 1), sb, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < n_frames; ++i) {
+        float sim = 0.0f;   // video_capture.rs:92: the first frame compares as 0.0
+        if (i > 0 || prev_small) {
+            double e = std::sqrt((double)ssd[i]);
+            float max_error = std::sqrt((255.0f * 255.0f * 3.0f) * (float)(sw * sh));
+            sim = 1.0f - (float)e / max_error;
+        }
+        changed_out[i] = sim < m->cfg.changed_similarity ? 1 : 0;
+        if (similarity_out) similarity_out[i] = sim;
+    }
+    API_CATCH(m)
+}
+
+// ---- debug taps ---------------------------------------------------------------------------
+
+int32_t slideo_orb_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride_bytes,
+                        slideo_keypoint* kp, uint8_t* desc32, int32_t capacity, int32_t* n_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!bgr || !n_out) fail(SLIDEO_ERR_INVALID_ARG, "null image/n_out");
+    validate_image(width, height, stride_bytes);
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const size_t fb = (size_t)height * stride_bytes;
+    m->d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    run_orb(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, st, false);
+    const uint32_t q = m->orb.qtot;
+    *n_out = (int32_t)q;
+    if ((int64_t)q > capacity) fail(SLIDEO_ERR_CAPACITY, "%u keypoints, capacity %d", q, capacity);
+    if (q) {
+        if (kp) HIP_CHECK(hipMemcpyAsync(kp, m->d_kp.p, (size_t)q * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
+        if (desc32) HIP_CHECK(hipMemcpyAsync(desc32, m->d_desc.p, (size_t)q * 32, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    API_CATCH(m)
+}
+
+int32_t slideo_pyramid_level_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride_bytes,
+                                  int32_t level, int32_t blurred, uint8_t* out, int64_t out_capacity, int32_t* lw, int32_t* lh) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!bgr || !out || !lw || !lh) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    validate_image(width, height, stride_bytes);
+    if (level < 0 || level >= m->cfg.nlevels) fail(SLIDEO_ERR_INVALID_ARG, "level out of range");
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const size_t fb = (size_t)height * stride_bytes;
+    m->d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    run_orb(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, st, false);
+    const LevelGeom& L = geom_for(m, width, height).g.lv[level];
+    *lw = L.w; *lh = L.h;
+    if ((int64_t)L.w * L.h > out_capacity) fail(SLIDEO_ERR_CAPACITY, "level needs %lld bytes", (long long)L.w * L.h);
+    if (L.w > 0 && L.h > 0) {
+        const uint8_t* src = (blurred ? m->d_blur.as<uint8_t>() : m->d_pyr.as<uint8_t>()) + L.ofs;
+        HIP_CHECK(hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    API_CATCH(m)
+}
+
+int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
+                           int32_t* idx_out, uint16_t* dist_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (nq < 0 || nt < 0 || k < 1 || k > KLIST) fail(SLIDEO_ERR_INVALID_ARG, "bad nq/nt/k (k must be 1..%d)", KLIST);
+    if ((nq && !q) || (nt && !t) || (nq && (!idx_out || !dist_out))) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    if (nq == 0) return SLIDEO_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64));
+    HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    run_knn(m, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), nt, st);
+    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
+    knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(m->d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
+    check_launch("knn_unpack_kernel");
+    HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 2, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    API_CATCH(m)
+}
+
+int32_t slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride_bytes,
+                                uint8_t* out, int64_t out_capacity, int32_t* sw_out, int32_t* sh_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!bgr || !out || !sw_out || !sh_out) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    validate_image(width, height, stride_bytes);
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const size_t fb = (size_t)height * stride_bytes;
+    m->d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    int sw = 0, sh = 0;
+    run_small(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
+    *sw_out = sw; *sh_out = sh;
+    if ((int64_t)sw * sh * 3 > out_capacity) fail(SLIDEO_ERR_CAPACITY, "small image needs %lld bytes", (long long)sw * sh * 3);
+    HIP_CHECK(hipMemcpyAsync(out, m->d_small.p, (size_t)sw * sh * 3, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    API_CATCH(m)
+}
+
+}  // extern "C"

@@ -1,0 +1,606 @@
+// verify.hip.h — per-frame decision kernels (everything after the kNN).
+//
+// Restates crates/matching-opencv/src/lib.rs:268-389 on the GPU:
+//   vote_kernel       5 % tolerance vote, bucket by page, top-40 pages, ordered
+//                     per-page match lists                       (lib.rs:268-295)
+//   ransac_kernel     estimateAffinePartial2D: 2-point RANSAC similarity with
+//                     OpenCV's adaptive iteration count + LM refine
+//                     (image_utils.rs:45-60, [OCV A.9])           (lib.rs:296-313)
+//   rate_kernel       sort by inliers, keep <= 10, rating filter  (lib.rs:329-333)
+//   reproject_kernel  warpAffine(nearest, inverse map) -> to_small_image ->
+//                     compute_similarity, fused: the full-resolution warp is
+//                     never materialised ([OCV A.10-A.12])        (lib.rs:335-351)
+//   verdict_kernel    sort by similarity, keep > 0.5, first       (lib.rs:370-389)
+//   small_image_kernel / ssd_kernel: to_small_image + compute_similarity for
+//                     page ingest (lib.rs:128) and the changed-frame mask
+//                     (video_capture.rs:86-98).
+// Orders the reference leaves to HashMap iteration are canonical:
+// pages tie-break by ascending index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geom.h"
+#include "knn.hip.h"
+
+namespace slideo {
+
+constexpr int MAXC = 64;       // >= max_candidate_pages
+constexpr int MAXR = 16;       // >= max_rated
+constexpr int RANSAC_LDS_PTS = 2048;
+
+struct FrameCands {            // one per frame of the batch, device resident
+    int32_t ncand, nsurv;
+    int32_t page[MAXC], count[MAXC], ofs[MAXC];
+    int32_t inliers[MAXC], found[MAXC];
+    double M[MAXC][6];         // slide -> frame
+    int32_t surv[MAXR];        // candidate slot of each survivor
+    float sim[MAXR];
+    unsigned long long ssd[MAXR];
+};
+
+struct PageInfo {              // per page, device resident
+    int32_t w, h;              // full size
+    int32_t area_idx;          // AreaGeom index (size class)
+    int32_t sw, sh;            // small size
+    int32_t kp_ofs, kp_cnt;    // rows of this page in the train matrix
+    int32_t _pad;
+    int64_t small_ofs;         // byte offset of the small image
+};
+
+struct VerifyParams {
+    int32_t k, klist, max_cand, max_rated;
+    float tol, min_similarity;
+    double thr, conf, min_rating, min_rating_ratio;
+    int32_t max_iters, refine_iters;
+};
+
+// ---------------------------------------------------------------------------
+// vote_kernel: grid B, block 256, dynamic LDS: counts[P] u32 | rank[P] u8 (padded) | runcnt[max_cand][256] u32
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32_t* __restrict__ keys,
+                                                   const uint32_t* __restrict__ qofs,
+                                                   const int32_t* __restrict__ train_page, int npages,
+                                                   FrameCands* __restrict__ fcs, uint2* __restrict__ votes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* counts = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* rank = smem + (size_t)npages * 4;
+    uint32_t* runcnt = reinterpret_cast<uint32_t*>(smem + (size_t)npages * 4 + (((size_t)npages + 15) & ~(size_t)15));
+    __shared__ unsigned long long red[4];
+    __shared__ int32_t s_page[MAXC], s_count[MAXC], s_ofs[MAXC];
+    __shared__ int32_t s_ncand;
+
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q0 = qofs[f], n = qofs[f + 1] - q0;
+    const int k = vp.k, KL = vp.klist;
+    FrameCands& fc = fcs[f];
+    for (int i = tid; i < npages; i += 256) { counts[i] = 0; rank[i] = 0xFF; }
+    __syncthreads();
+    const uint32_t total = n * (uint32_t)k;
+    // tolerance vote: d < best * tol (f32, strict)      lib.rs:275
+    auto passes = [&](uint32_t e, uint32_t& tidx) -> bool {
+        uint32_t q = e / (uint32_t)k, r = e - q * (uint32_t)k;
+        const uint32_t* kq = keys + (size_t)(q0 + q) * KL;
+        uint32_t key = kq[r];
+        if (key == KNN_EMPTY) return false;
+        float best = (float)(kq[0] >> KNN_KEY_SHIFT);
+        float lim = best * vp.tol;
+        tidx = key & KNN_IDX_MASK;
+        return (float)(key >> KNN_KEY_SHIFT) < lim;
+    };
+    for (uint32_t e = tid; e < total; e += 256) {
+        uint32_t t;
+        if (passes(e, t)) atomicAdd(&counts[train_page[t]], 1u);
+    }
+    __syncthreads();
+    // top max_cand pages by (count desc, page asc)       lib.rs:284-295
+    int nc = 0;
+    for (int round = 0; round < vp.max_cand; ++round) {
+        unsigned long long best = 0;
+        for (int p = tid; p < npages; p += 256) {
+            uint32_t c = counts[p];
+            if (c && rank[p] == 0xFF) {
+                unsigned long long comp = ((unsigned long long)c << 32) | (0xFFFFFFFFu - (uint32_t)p);
+                best = comp > best ? comp : best;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            unsigned long long o = __shfl_xor(best, d);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        best = red[0];
+        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+        __syncthreads();
+        if (best == 0) break;
+        int p = (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu));
+        if (tid == 0) { s_page[nc] = p; s_count[nc] = (int32_t)(best >> 32); rank[p] = (uint8_t)nc; }
+        ++nc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int o = 0;
+        for (int i = 0; i < nc; ++i) { s_ofs[i] = o; o += s_count[i]; }
+        s_ncand = nc;
+        fc.ncand = nc; fc.nsurv = 0;
+        for (int i = 0; i < nc; ++i) { fc.page[i] = s_page[i]; fc.count[i] = s_count[i]; fc.ofs[i] = s_ofs[i]; }
+    }
+    __syncthreads();
+    if (nc == 0) return;
+    // ordered placement: each thread owns a contiguous run of entries (q asc, r asc)
+    const uint32_t run = (total + 255) / 256;
+    const uint32_t e0 = min(total, tid * run), e1 = min(total, e0 + run);
+    for (int c = 0; c < nc; ++c) runcnt[c * 256 + tid] = 0;
+    for (uint32_t e = e0; e < e1; ++e) {
+        uint32_t t;
+        if (passes(e, t)) { uint8_t r = rank[train_page[t]]; if (r != 0xFF) runcnt[r * 256 + tid]++; }
+    }
+    __syncthreads();
+    // exclusive scan over the 256 threads, per candidate (wave w takes candidates w, w+4, ...)
+    for (int c = wave; c < nc; c += 4) {
+        uint32_t v[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = runcnt[c * 256 + lane * 4 + j]; s += v[j]; }
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        uint32_t ex = inc - s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { runcnt[c * 256 + lane * 4 + j] = ex; ex += v[j]; }
+    }
+    __syncthreads();
+    uint2* vout = votes + (size_t)q0 * k;
+    for (uint32_t e = e0; e < e1; ++e) {
+        uint32_t t;
+        if (passes(e, t)) {
+            uint8_t r = rank[train_page[t]];
+            if (r != 0xFF) {
+                uint32_t pos = (uint32_t)s_ofs[r] + runcnt[r * 256 + tid]++;
+                vout[pos] = make_uint2(e / (uint32_t)k, t);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ransac_kernel: one wave per (candidate, frame).  grid (max_cand, B), block 64.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void similarity_from_2(float4 p, float4 q, double M[6]) {
+    // p = (x1,y1,X1,Y1), q = (x2,y2,X2,Y2); from (x,y) -> to (X,Y)     [OCV A.9] runKernel
+    double x1 = p.x, y1 = p.y, X1 = p.z, Y1 = p.w, x2 = q.x, y2 = q.y, X2 = q.z, Y2 = q.w;
+    double d = 1. / ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+    double S0 = d * ((X1 - X2) * (x1 - x2) + (Y1 - Y2) * (y1 - y2));
+    double S1 = d * ((Y1 - Y2) * (x1 - x2) - (X1 - X2) * (y1 - y2));
+    double S2 = d * ((Y1 - Y2) * (x1 * y2 - x2 * y1) - (X1 * y2 - X2 * y1) * (y1 - y2) - (X1 * x2 - X2 * x1) * (x1 - x2));
+    double S3 = d * (-(X1 - X2) * (x1 * y2 - x2 * y1) - (Y1 * x2 - Y2 * x1) * (x1 - x2) - (Y1 * y2 - Y2 * y1) * (y1 - y2));
+    M[0] = S0; M[4] = S0; M[1] = -S1; M[2] = S2; M[3] = S1; M[5] = S3;
+}
+
+__device__ __forceinline__ int ransac_update_iters(double p, double ep, int max_iters) {
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, 2.0);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+    return v;
+}
+
+__device__ __forceinline__ bool solve4(const double Ain[16], const double bin[4], double x[4]) {
+    double A[4][5];
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) A[i][j] = Ain[i * 4 + j]; A[i][4] = bin[i]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (A[p][c] == 0.0) return false;
+        if (p != c) for (int j = 0; j < 5; ++j) { double t = A[p][j]; A[p][j] = A[c][j]; A[c][j] = t; }
+        for (int r = c + 1; r < 4; ++r) {
+            double fct = A[r][c] / A[c][c];
+            for (int j = c; j < 5; ++j) A[r][j] -= fct * A[c][j];
+        }
+    }
+    for (int i = 3; i >= 0; --i) {
+        double s = A[i][4];
+        for (int j = i + 1; j < 4; ++j) s -= A[i][j] * x[j];
+        x[i] = s / A[i][i];
+    }
+    return true;
+}
+
+// residual sums over the inliers for h = (a, b, tx, ty); wave-parallel
+__device__ __forceinline__ double lm_eval(const float4* pts, const uint8_t* mask, int n, int lane, const double h[4],
+                                          bool want_j, double A[16], double v[4], double* rinf) {
+    double S = 0, ri = 0, sq = 0, sx = 0, sy = 0, cnt = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    for (int i = lane; i < n; i += 64) {
+        if (!mask[i]) continue;
+        float4 p = pts[i];
+        double Mx = p.x, My = p.y;
+        double ex = (h[0] * Mx - h[1] * My + h[2]) - (double)p.z;
+        double ey = (h[1] * Mx + h[0] * My + h[3]) - (double)p.w;
+        S += ex * ex; S += ey * ey;
+        ri = fmax(ri, fmax(fabs(ex), fabs(ey)));
+        if (want_j) {
+            sq += Mx * Mx + My * My; sx += Mx; sy += My; cnt += 1.0;
+            v0 += Mx * ex + My * ey; v1 += -My * ex + Mx * ey; v2 += ex; v3 += ey;
+        }
+    }
+    S = wave_sum(S); ri = wave_max(ri);
+    if (want_j) {
+        sq = wave_sum(sq); sx = wave_sum(sx); sy = wave_sum(sy); cnt = wave_sum(cnt);
+        v[0] = wave_sum(v0); v[1] = wave_sum(v1); v[2] = wave_sum(v2); v[3] = wave_sum(v3);
+        // J^T J for rows {x,-y,1,0},{y,x,0,1}
+        A[0] = sq;  A[1] = 0;   A[2] = sx;  A[3] = sy;
+        A[4] = 0;   A[5] = sq;  A[6] = -sy; A[7] = sx;
+        A[8] = sx;  A[9] = -sy; A[10] = cnt; A[11] = 0;
+        A[12] = sy; A[13] = sx; A[14] = 0;  A[15] = cnt;
+    }
+    if (rinf) *rinf = ri;
+    return S;
+}
+
+__global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+                                                    const slideo_keypoint* __restrict__ frame_kp,
+                                                    const float2* __restrict__ page_xy,
+                                                    const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
+                                                    FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
+                                                    uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
+    __shared__ float4 lpts[RANSAC_LDS_PTS];
+    __shared__ uint8_t lmask[RANSAC_LDS_PTS];
+    const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    FrameCands& fc = fcs[f];
+    if (r >= fc.ncand) return;
+    const int count = fc.count[r];
+    const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
+    const uint2* vt = votes + vbase;
+    float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
+    uint8_t* mask = count <= RANSAC_LDS_PTS ? lmask : gmask + vbase;
+    for (int i = lane; i < count; i += 64) {
+        uint2 v = vt[i];
+        float2 s = page_xy[v.y];
+        const slideo_keypoint& kq = frame_kp[qofs[f] + v.x];
+        pts[i] = make_float4(s.x, s.y, kq.x, kq.y);     // from = slide pt, to = frame pt   lib.rs:299-302
+    }
+    __syncthreads();
+    double bestM[6] = {0, 0, 0, 0, 0, 0};
+    int found = 0, inl = 0;
+    const float thr2 = (float)(vp.thr * vp.thr);
+    if (count == 2) {
+        similarity_from_2(pts[0], pts[1], bestM);
+        found = 1; inl = 2;
+    } else if (count > 2) {
+        int niters = max(vp.max_iters, 1), max_good = 0;
+        uint32_t pos = 0;
+        for (int base = 0; base < niters; base += 64) {
+            // sample schedule: cv::RNG((uint64)-1) stream, idx = next() % count, second index redrawn while equal
+            if (pos + 4 * 64 + 64 > (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
+            uint32_t a = rng_tab[pos + 2 * lane] % (uint32_t)count;
+            uint32_t b = rng_tab[pos + 2 * lane + 1] % (uint32_t)count;
+            if (__builtin_amdgcn_ballot_w64(a == b) == 0ull) pos += 128;
+            else {
+                uint32_t p = pos;
+                for (int it = 0; it < 64; ++it) {
+                    uint32_t i0 = rng_tab[min(p, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count, i1;
+                    ++p;
+                    do { i1 = rng_tab[min(p, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count; ++p; } while (i1 == i0 && p < (uint32_t)RNG_TABLE);
+                    if (it == lane) { a = i0; b = i1; }
+                }
+                if (p >= (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
+                pos = p;
+            }
+            double M[6];
+            similarity_from_2(pts[a], pts[b], M);
+            const float F0 = (float)M[0], F1 = (float)M[1], F2 = (float)M[2], F3 = (float)M[3], F4 = (float)M[4], F5 = (float)M[5];
+            int good = 0;
+            for (int i = 0; i < count; ++i) {
+                float4 p = pts[i];
+                float ea = F0 * p.x + F1 * p.y + F2 - p.z;
+                float eb = F3 * p.x + F4 * p.y + F5 - p.w;
+                float e = ea * ea + eb * eb;
+                good += (e <= thr2) ? 1 : 0;
+            }
+            // sequential acceptance over the 64 iterations of this chunk
+            bool stop = false;
+            for (int i = 0; i < 64; ++i) {
+                if (base + i >= niters) { stop = true; break; }
+                int g = __shfl(good, i);
+                if (g > max(max_good, 1)) {
+                    max_good = g;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) bestM[j] = __shfl(M[j], i);
+                    niters = ransac_update_iters(vp.conf, (double)(count - g) / count, niters);
+                }
+            }
+            if (stop) break;
+        }
+        found = max_good > 0;
+        if (found) {
+            const float F0 = (float)bestM[0], F1 = (float)bestM[1], F2 = (float)bestM[2], F3 = (float)bestM[3], F4 = (float)bestM[4], F5 = (float)bestM[5];
+            int c = 0;
+            for (int i = lane; i < count; i += 64) {
+                float4 p = pts[i];
+                float ea = F0 * p.x + F1 * p.y + F2 - p.z;
+                float eb = F3 * p.x + F4 * p.y + F5 - p.w;
+                float e = ea * ea + eb * eb;
+                uint8_t m = e <= thr2;
+                mask[i] = m; c += m;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+            inl = c;
+            __syncthreads();
+            if (vp.refine_iters > 0 && inl > 0) {
+                // LMSolverImpl::run over the inliers ([OCV] calib3d/src/levmarq.cpp), 4 parameters
+                const double eps = (double)FLT_EPSILON;
+                double x[4] = {bestM[0], bestM[3], bestM[2], bestM[5]}, xd[4], A[16], v[4], D[4], d[4], Ap[16], rinf = 0;
+                double S = lm_eval(pts, mask, count, lane, x, true, A, v, &rinf);
+                for (int i = 0; i < 4; ++i) D[i] = A[i * 4 + i];
+                const double Rlo = 0.25, Rhi = 0.75;
+                double lambda = 1, lc = 0.75;
+                int iter = 0;
+                for (;;) {
+                    for (int i = 0; i < 16; ++i) Ap[i] = A[i];
+                    for (int i = 0; i < 4; ++i) Ap[i * 4 + i] += lambda * D[i];
+                    if (!solve4(Ap, v, d)) { d[0] = d[1] = d[2] = d[3] = 0; }
+                    for (int i = 0; i < 4; ++i) xd[i] = x[i] - d[i];
+                    double Sd = lm_eval(pts, mask, count, lane, xd, false, nullptr, nullptr, nullptr);
+                    double dS = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        double t = 2 * v[i];
+                        for (int j = 0; j < 4; ++j) t -= A[i * 4 + j] * d[j];
+                        dS += d[i] * t;
+                    }
+                    double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                    if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+                    else if (R < Rlo) {
+                        double t = 0;
+                        for (int i = 0; i < 4; ++i) t += d[i] * v[i];
+                        double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+                        nu = fmin(fmax(nu, 2.), 10.);
+                        if (lambda == 0) {
+                            double maxval = DBL_EPSILON;
+                            for (int i = 0; i < 4; ++i) {
+                                double e4[4] = {0, 0, 0, 0}, col[4];
+                                e4[i] = 1;
+                                if (solve4(A, e4, col)) maxval = fmax(maxval, fabs(col[i]));
+                            }
+                            lambda = lc = 1. / maxval;
+                            nu *= 0.5;
+                        }
+                        lambda *= nu;
+                    }
+                    if (Sd < S) {
+                        S = Sd;
+                        for (int i = 0; i < 4; ++i) x[i] = xd[i];
+                        lm_eval(pts, mask, count, lane, x, true, A, v, &rinf);
+                    }
+                    iter++;
+                    double dinf = fmax(fmax(fabs(d[0]), fabs(d[1])), fmax(fabs(d[2]), fabs(d[3])));
+                    if (!(iter < vp.refine_iters && dinf >= eps && rinf >= eps)) break;
+                }
+                bestM[0] = bestM[4] = x[0]; bestM[1] = -x[1]; bestM[2] = x[2]; bestM[3] = x[1]; bestM[5] = x[3];
+            }
+        } else {
+            for (int j = 0; j < 6; ++j) bestM[j] = 0;
+        }
+    }
+    if (lane == 0) {
+        fc.found[r] = found; fc.inliers[r] = inl;
+        for (int j = 0; j < 6; ++j) fc.M[r][j] = bestM[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// rate_kernel: one thread per frame.      lib.rs:329-333
+// ---------------------------------------------------------------------------
+__global__ void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict__ fcs) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    FrameCands& fc = fcs[f];
+    int order[MAXC];
+    const int nc = fc.ncand;
+    for (int i = 0; i < nc; ++i) order[i] = i;
+    for (int i = 1; i < nc; ++i) {          // stable insertion sort, rating desc
+        int o = order[i], j = i;
+        while (j > 0 && fc.inliers[order[j - 1]] < fc.inliers[o]) { order[j] = order[j - 1]; --j; }
+        order[j] = o;
+    }
+    const int top = min(nc, vp.max_rated);
+    const double best = top > 0 ? (double)fc.inliers[order[0]] : 0.0;
+    int ns = 0;
+    for (int i = 0; i < top; ++i) {
+        double rating = (double)fc.inliers[order[i]];
+        if (rating > vp.min_rating && rating / best > vp.min_rating_ratio) {
+            fc.surv[ns] = order[i]; fc.ssd[ns] = 0ull; fc.sim[ns] = 0.f; ++ns;
+        }
+    }
+    fc.nsurv = ns;
+}
+
+// ---------------------------------------------------------------------------
+// INTER_AREA of a virtual source image given by `fetch(sx, sy, bgr[3])`.
+// Same accumulation order as ResizeArea_Invoker ([OCV A.11]): per source row the
+// x taps accumulate into buf (f32, mul then add), rows accumulate sum (+)= beta*buf.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sat_int_d(double v) {
+    if (!(v > -2147483648.0)) return INT32_MIN;
+    if (v >= 2147483647.0) return INT32_MAX;
+    return (int)rint(v);
+}
+__device__ __forceinline__ uint8_t sat_u8_f(float v) {
+    int i = (int)rintf(v);
+    return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+template <class Fetch>
+__device__ __forceinline__ void area_pixel(const AreaGeom& ag, const AreaTap* __restrict__ taps, const int32_t* __restrict__ idx,
+                                           int dx, int dy, Fetch fetch, uint8_t out[3]) {
+    if (ag.fast) {
+        int sum0 = 0, sum1 = 0, sum2 = 0;
+        for (int yy = 0; yy < ag.iscale_y; ++yy)
+            for (int xx = 0; xx < ag.iscale_x; ++xx) {
+                uint8_t p[3];
+                fetch(min(dx * ag.iscale_x + xx, ag.sw - 1), min(dy * ag.iscale_y + yy, ag.sh - 1), p);
+                sum0 += p[0]; sum1 += p[1]; sum2 += p[2];
+            }
+        if (ag.iscale_x == 2 && ag.iscale_y == 2) {
+            out[0] = (uint8_t)((sum0 + 2) >> 2); out[1] = (uint8_t)((sum1 + 2) >> 2); out[2] = (uint8_t)((sum2 + 2) >> 2);
+        } else {
+            out[0] = sat_u8_f((float)sum0 * ag.fast_scale); out[1] = sat_u8_f((float)sum1 * ag.fast_scale);
+            out[2] = sat_u8_f((float)sum2 * ag.fast_scale);
+        }
+        return;
+    }
+    const int xb = idx[ag.xidx_ofs + dx], xe = idx[ag.xidx_ofs + dx + 1];
+    const int yb = idx[ag.yidx_ofs + dy], ye = idx[ag.yidx_ofs + dy + 1];
+    float s0 = 0, s1 = 0, s2 = 0;
+    for (int j = yb; j < ye; ++j) {
+        const AreaTap ty = taps[ag.ytap_ofs + j];
+        float b0 = 0, b1 = 0, b2 = 0;
+        for (int kx = xb; kx < xe; ++kx) {
+            const AreaTap tx = taps[ag.xtap_ofs + kx];
+            uint8_t p[3];
+            fetch(tx.si, ty.si, p);
+            b0 = b0 + (float)p[0] * tx.alpha; b1 = b1 + (float)p[1] * tx.alpha; b2 = b2 + (float)p[2] * tx.alpha;
+        }
+        if (j == yb) { s0 = ty.alpha * b0; s1 = ty.alpha * b1; s2 = ty.alpha * b2; }
+        else { s0 += ty.alpha * b0; s1 += ty.alpha * b1; s2 += ty.alpha * b2; }
+    }
+    out[0] = sat_u8_f(s0); out[1] = sat_u8_f(s1); out[2] = sat_u8_f(s2);
+}
+
+constexpr int SM_TW = 32, SM_TH = 8;   // small-image tile per 256-thread block
+
+// to_small_image of n equally sized images.  grid (tiles, n), block 256.
+__global__ __launch_bounds__(256) void small_image_kernel(AreaGeom ag, const AreaTap* __restrict__ taps,
+                                                          const int32_t* __restrict__ idx,
+                                                          const uint8_t* __restrict__ imgs, int64_t img_stride, int stride,
+                                                          uint8_t* __restrict__ out, int64_t out_stride) {
+    const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1)), dy = ty * SM_TH + (threadIdx.x / SM_TW);
+    if (dx >= ag.dw || dy >= ag.dh) return;
+    const uint8_t* img = imgs + (int64_t)blockIdx.y * img_stride;
+    uint8_t o[3];
+    area_pixel(ag, taps, idx, dx, dy, [&](int sx, int sy, uint8_t* p) {
+        const uint8_t* s = img + (int64_t)sy * stride + 3 * sx;
+        p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
+    }, o);
+    uint8_t* d = out + (int64_t)blockIdx.y * out_stride + ((int64_t)dy * ag.dw + dx) * 3;
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+}
+
+// sum of squared differences between consecutive small images: pair i = (a_i, b_i).  grid n, block 256.
+__global__ __launch_bounds__(256) void ssd_kernel(const uint8_t* __restrict__ a, int64_t a_stride,
+                                                  const uint8_t* __restrict__ b, int64_t b_stride, int64_t nbytes,
+                                                  unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long red[4];
+    const uint8_t* pa = a + (int64_t)blockIdx.x * a_stride;
+    const uint8_t* pb = b + (int64_t)blockIdx.x * b_stride;
+    unsigned long long s = 0;
+    for (int64_t i = threadIdx.x; i < nbytes; i += 256) { int d = (int)pa[i] - (int)pb[i]; s += (unsigned)(d * d); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// reproject_kernel: grid (tiles, max_rated, B), block 256.
+// For survivor s of frame f: warp the frame into the slide's space (nearest, inverse map,
+// 10-bit fixed point, [OCV A.10]), area-resize to the slide's small size, accumulate the
+// squared difference against the slide's small image.
+__global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
+                                                        const int32_t* __restrict__ idx, const PageInfo* __restrict__ pages,
+                                                        const uint8_t* __restrict__ page_small,
+                                                        const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
+                                                        int fw, int fh, FrameCands* __restrict__ fcs) {
+    __shared__ unsigned long long red[4];
+    const int s = blockIdx.y, f = blockIdx.z;
+    FrameCands& fc = fcs[f];
+    if (s >= fc.nsurv) return;
+    const int r = fc.surv[s];
+    const PageInfo pg = pages[fc.page[r]];
+    const AreaGeom ag = ags[pg.area_idx];
+    const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1)), dy = ty * SM_TH + (threadIdx.x / SM_TW);
+    double M[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) M[j] = fc.M[r][j];
+    const uint8_t* frame = frames + (int64_t)f * frame_stride;
+    unsigned long long acc = 0;
+    if (dx < ag.dw && dy < ag.dh) {
+        uint8_t o[3];
+        area_pixel(ag, taps, idx, dx, dy, [&](int x, int y, uint8_t* p) {
+            const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
+            int adelta = sat_int_d(M[0] * x * AB_SCALE), bdelta = sat_int_d(M[3] * x * AB_SCALE);
+            int X0 = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+            int Y0 = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+            int X = (int)((uint32_t)X0 + (uint32_t)adelta) >> AB_BITS;
+            int Y = (int)((uint32_t)Y0 + (uint32_t)bdelta) >> AB_BITS;
+            X = X < -32768 ? -32768 : (X > 32767 ? 32767 : X);
+            Y = Y < -32768 ? -32768 : (Y > 32767 ? 32767 : Y);
+            if ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) {
+                const uint8_t* sp = frame + (int64_t)Y * stride + 3 * X;
+                p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+            } else { p[0] = p[1] = p[2] = 0; }
+        }, o);
+        const uint8_t* ref = page_small + pg.small_ofs + ((int64_t)dy * ag.dw + dx) * 3;
+        int d0 = (int)o[0] - ref[0], d1 = (int)o[1] - ref[1], d2 = (int)o[2] - ref[2];
+        acc = (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&fc.ssd[s], red[0] + red[1] + red[2] + red[3]);
+}
+
+// compute_similarity (image_utils.rs:22-27): 1 - (f32)sqrt(ssd) / sqrt(255*255*3 * p) (f32)
+__device__ __forceinline__ float similarity_from_ssd(unsigned long long ssd, int sw, int sh) {
+    double err = sqrt((double)ssd);
+    float max_error = sqrtf((255.0f * 255.0f * 3.0f) * (float)(sw * sh));
+    return 1.0f - (float)err / max_error;
+}
+
+// verdict_kernel: one thread per frame.      lib.rs:370-389
+__global__ void verdict_kernel(VerifyParams vp, int nframes, const uint32_t* __restrict__ qofs,
+                               const PageInfo* __restrict__ pages, FrameCands* __restrict__ fcs,
+                               slideo_verdict* __restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    FrameCands& fc = fcs[f];
+    slideo_verdict v;
+    v.page_idx = -1; v.similarity = 0.f; v.inliers = 0; v.n_keypoints = (int32_t)(qofs[f + 1] - qofs[f]);
+    if (v.n_keypoints == 0) { fc.ncand = 0; fc.nsurv = 0; }
+    // stable: first maximal similarity among survivors in rating order
+    float best = 0.f; int bi = -1;
+    for (int s = 0; s < fc.nsurv; ++s) {
+        const PageInfo pg = pages[fc.page[fc.surv[s]]];
+        float sim = similarity_from_ssd(fc.ssd[s], pg.sw, pg.sh);
+        fc.sim[s] = sim;
+        if (bi < 0 || sim > best) { best = sim; bi = s; }
+    }
+    if (bi >= 0 && best > vp.min_similarity) {
+        v.page_idx = fc.page[fc.surv[bi]]; v.similarity = best; v.inliers = fc.inliers[fc.surv[bi]];
+    }
+    out[f] = v;
+}
+
+}  // namespace slideo

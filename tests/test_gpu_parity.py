@@ -1,0 +1,280 @@
+"""HIP path vs the CPU restatement, through the C ABI, on the same seeded inputs.
+
+Bar: integer stages bit-exact (pyramid, blur, keypoint sets,
+descriptor bits, kNN indices+distances, vote counts, inlier counts); float
+stages within stated tolerance (|d similarity| <= 1e-4, transform rel 1e-5).
+"""
+import numpy as np
+import pytest
+
+from conftest import small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m500(capi):
+    m = capi.Matcher(small_cfg(capi))
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def mdef(capi):
+    m = capi.Matcher(capi.default_config())
+    yield m
+    m.close()
+
+
+# ---- kNN ---------------------------------------------------------------------------------
+
+def test_knn_random_bit_exact(capi, oracle, mdef):
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    gi, gd = mdef.knn(q, t, 30)
+    oi, od = oracle.knn_hamming(q, t, 30)
+    assert np.array_equal(gd, od)
+    assert np.array_equal(gi, oi)
+
+
+def test_knn_heavy_ties_and_duplicates(capi, oracle, mdef):
+    # few distinct descriptors -> massive distance ties, zero distances; tie rule = lowest row
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, (7, 32), dtype=np.uint8)
+    t = base[rng.integers(0, 7, 3000)]
+    flip = rng.integers(0, 3000, 400)
+    t[flip, 0] ^= 1
+    q = base[rng.integers(0, 7, 130)]
+    gi, gd = mdef.knn(q, t, 30)
+    oi, od = oracle.knn_hamming(q, t, 30)
+    assert np.array_equal(gd, od) and np.array_equal(gi, oi)
+
+
+def test_knn_fewer_train_rows_than_k(capi, oracle, mdef):
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (65, 32), dtype=np.uint8)
+    for nt in (1, 7, 29):
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        gi, gd = mdef.knn(q, t, 30)
+        oi, od = oracle.knn_hamming(q, t, 30)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+        assert (gi[:, nt:] == -1).all() and (gd[:, nt:] == 65535).all()
+
+
+def test_knn_split_train_merge_path(capi, oracle, mdef):
+    # few queries, many train rows -> the train set is split over blocks and merged
+    rng = np.random.default_rng(4)
+    q = rng.integers(0, 256, (33, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (70001, 32), dtype=np.uint8)
+    t[rng.integers(0, 70001, 500)] = q[rng.integers(0, 33, 500)]       # exact duplicates across segments
+    gi, gd = mdef.knn(q, t, 30)
+    oi, od = oracle.knn_hamming(q, t, 30)
+    assert np.array_equal(gd, od) and np.array_equal(gi, oi)
+
+
+def test_knn_other_k(capi, oracle, mdef):
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    for k in (1, 2, 17, 32):
+        gi, gd = mdef.knn(q, t, k)
+        oi, od = oracle.knn_hamming(q, t, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_knn_property_full_size(capi, mdef):
+    # size-independent properties at a BASELINE-scale train set (the oracle would take minutes):
+    # distances ascending, ties by ascending row, distances recomputed on the host agree, and
+    # the k-th distance bounds every non-returned row for a sample of queries.
+    rng = np.random.default_rng(6)
+    q = rng.integers(0, 256, (2048, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (100000, 32), dtype=np.uint8)
+    gi, gd = mdef.knn(q, t, 30)
+    assert (np.diff(gd.astype(int), axis=1) >= 0).all()
+    same = np.diff(gd.astype(int), axis=1) == 0
+    assert (np.diff(gi, axis=1)[same] > 0).all()
+    d = np.unpackbits(q[:, None, :] ^ t[gi], axis=2).sum(2)
+    assert np.array_equal(d, gd)
+    for qi in range(0, 2048, 256):
+        dall = np.unpackbits(q[qi][None, :] ^ t, axis=1).sum(1)
+        order = np.lexsort((np.arange(len(t)), dall))[:30]
+        assert np.array_equal(order, gi[qi])
+
+
+# ---- ORB stages ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("which", ["frame", "page"])
+def test_pyramid_and_blur_bit_exact(capi, oracle, m500, cfg0_data, which):
+    pages, frames, _, _ = cfg0_data
+    img = frames[1] if which == "frame" else pages[0]
+    oc = small_cfg(oracle)
+    for level in range(8):
+        for blurred in (0, 1):
+            g = m500.pyramid_level(img, level, blurred)
+            o = oracle.pyramid_level(img, oc, level, blurred)
+            assert g.shape == o.shape
+            assert np.array_equal(g, o), "level %d blurred %d: %d px differ" % (level, blurred, (g != o).sum())
+
+
+def _cmp_orb(capi, oracle, matcher, ocfg, img):
+    gk, gd = matcher.orb(img)
+    ok, od = oracle.orb(img, ocfg)
+    assert len(gk) == len(ok), "keypoint count %d vs %d" % (len(gk), len(ok))
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(gk[f], ok[f]), f
+    assert np.array_equal(gk["angle"], ok["angle"]), "angle max diff %g" % np.abs(gk["angle"] - ok["angle"]).max()
+    assert np.array_equal(gd, od), "%d descriptor rows differ" % (gd != od).any(1).sum()
+    return len(gk)
+
+
+def test_orb_bit_exact_cfg0(capi, oracle, m500, cfg0_data):
+    pages, frames, _, _ = cfg0_data
+    oc = small_cfg(oracle)
+    n = 0
+    for img in list(frames[:4]) + list(pages[:2]):
+        n += _cmp_orb(capi, oracle, m500, oc, img)
+    assert n > 500
+
+
+def test_orb_bit_exact_1080p_defaults(capi, oracle, mdef, synth):
+    pages = synth.pages(2)
+    frames, _, _ = synth.frames(pages, 2, first=1)
+    oc = oracle.default_config()
+    assert _cmp_orb(capi, oracle, mdef, oc, frames[0]) > 1500
+    assert _cmp_orb(capi, oracle, mdef, oc, pages[1]) > 1500
+
+
+def test_orb_edge_cases(capi, oracle, m500):
+    oc = small_cfg(oracle)
+    flat = np.full((200, 300, 3), 128, np.uint8)                      # no corners at all
+    gk, gd = m500.orb(flat)
+    assert len(gk) == 0 and len(gd) == 0
+    tiny = np.random.default_rng(0).integers(0, 256, (130, 140, 3), dtype=np.uint8)   # only level 0 survives the 62 px border
+    _cmp_orb(capi, oracle, m500, oc, tiny)
+    odd = np.random.default_rng(1).integers(0, 256, (203, 317, 3), dtype=np.uint8)    # widths not multiples of 4
+    odd = (odd // 64 * 64).astype(np.uint8)
+    _cmp_orb(capi, oracle, m500, oc, odd)
+
+
+def test_orb_many_ties_kept(capi, oracle, m500):
+    # identical corners everywhere -> every score ties; retainBest keeps all of them (count > quota)
+    img = np.full((300, 400, 3), 255, np.uint8)
+    for y in range(70, 230, 16):
+        for x in range(70, 330, 16):
+            img[y:y + 6, x:x + 6] = 0
+    n = _cmp_orb(capi, oracle, m500, small_cfg(oracle), img)
+    assert n > 109
+
+
+# ---- small image / similarity --------------------------------------------------------------
+
+def test_small_image_bit_exact(capi, oracle, m500, cfg0_data):
+    pages, frames, _, _ = cfg0_data
+    for img in (pages[0], frames[0]):
+        assert np.array_equal(m500.small_image(img), oracle.small_image(img))
+    img = np.random.default_rng(2).integers(0, 256, (1200, 1600, 3), dtype=np.uint8)   # 4:3 -> integer scale 4 fast path
+    assert np.array_equal(m500.small_image(img), oracle.small_image(img))
+
+
+def test_changed_mask(capi, oracle, m500, cfg0_data):
+    pages, frames, _, _ = cfg0_data
+    seq = np.stack([frames[0], frames[0], frames[1], frames[1], frames[2]])
+    seq[1, 10:20, 10:20] ^= 3                                          # tiny change: still "unchanged"
+    gc, gs, glast = m500.changed_mask(seq)
+    oc_, os_, olast = oracle.changed_mask(seq, small_cfg(oracle))
+    assert list(gc) == list(oc_) == [True, False, True, False, True]
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(glast, olast)
+    gc2, gs2, _ = m500.changed_mask(seq[2:], prev_small=oracle.small_image(seq[1]))
+    assert list(gc2) == [True, False, True] and np.array_equal(gs2, os_[2:])
+
+
+# ---- end to end -------------------------------------------------------------------------------
+
+def _build_both(capi, oracle, gcfg, ocfg, pages):
+    m = capi.Matcher(gcfg)
+    m.add_pages(list(pages))
+    m.finalize()
+    db = oracle.PageDB(ocfg)
+    for p in pages:
+        db.add_page(p)
+    assert db.finalize() == 0
+    return m, db
+
+
+def _compare_traces(m, db, frames, verdicts):
+    for i, fr in enumerate(frames):
+        ov, oc = db.match_frame_trace(fr)
+        gv = verdicts[i]
+        gc = m.last_candidates(i)
+        assert gv["n_keypoints"] == ov["n_keypoints"]
+        assert len(gc) == len(oc)
+        assert list(gc["page_idx"]) == list(oc["page_idx"])
+        assert list(gc["n_votes"]) == list(oc["n_votes"])
+        assert list(gc["inliers"]) == list(oc["inliers"]), "inlier counts differ in frame %d" % i
+        assert list(gc["survived"]) == list(oc["survived"])
+        for a, b in zip(gc, oc):
+            if b["inliers"] > 0:
+                scale = np.array([1, 1, 1e3, 1, 1, 1e3])
+                assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale)
+            assert abs(a["similarity"] - b["similarity"]) <= 1e-4
+        assert gv["page_idx"] == ov["page_idx"]
+        assert gv["inliers"] == ov["inliers"]
+        assert abs(gv["similarity"] - ov["similarity"]) <= 1e-4
+
+
+def test_end_to_end_cfg0(capi, oracle, cfg0_data):
+    """BASELINE configs[0]: 8 synthetic 640x360 frames vs 4 pages, ORB-500."""
+    pages, frames, truth, _ = cfg0_data
+    m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
+    assert m.descriptor_count == db.descriptor_count
+    for p in range(4):
+        gk, gd = m.page_features(p)
+        ok, od = db.page_features(p)
+        assert np.array_equal(gd, od) and np.array_equal(gk["x"], ok["x"])
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    assert list(v["page_idx"]) == list(truth), "page assignment vs synthetic ground truth"
+    m.close()
+
+
+def test_end_to_end_1080p_reference_defaults(capi, oracle, synth):
+    """Reference literals (ORB-2000, rating > 50) on 1080p frames vs 2001x1125 pages."""
+    pages = synth.pages(5)
+    frames, truth, _ = synth.frames(pages, 6, first=3)
+    m, db = _build_both(capi, oracle, capi.default_config(), oracle.default_config(), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    assert list(v["page_idx"]) == list(truth)
+    m.close()
+
+
+def test_device_resident_frames_match_host_path(capi, cfg0_data):
+    import torch
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    v_host = m.match_frames(frames)
+    t = torch.from_numpy(frames).cuda()
+    v_dev = m.match_frames_dev(t.data_ptr(), len(frames), 640, 360)
+    assert np.array_equal(v_host, v_dev)
+    m.close()
+
+
+def test_state_and_error_behaviour(capi, cfg0_data):
+    pages, frames, _, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    with pytest.raises(capi.SlideoError) as e:
+        m.match_frames(frames[:1])
+    assert e.value.code == 4                                          # match before finalize
+    m.add_pages([np.full((450, 800, 3), 255, np.uint8)])              # blank deck: no descriptor at all
+    with pytest.raises(capi.SlideoError) as e:
+        m.finalize()
+    assert e.value.code == 6                                          # SLIDEO_ERR_EMPTY_INDEX
+    m.close()
+    m = capi.Matcher(small_cfg(capi))
+    with pytest.raises(capi.SlideoError) as e:
+        m.add_pages([np.zeros((100, 100, 3), np.uint8)])              # area < small_area: would upscale
+    assert e.value.code == 5
+    m.close()
