@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec matched, 1080p frames vs a 500-page ORB set (BASELINE.json metric).
+
+One "step" = one pass of the hot path (ORB detect+describe -> exact Hamming kNN
+k=30 -> 5 % vote -> RANSAC similarity -> re-projection verdict) over one batch of
+synthetic frames that is already resident in HBM when the timed region starts.
+One process per GPU; ranks shard frames (weak scaling: the per-GPU batch is
+fixed), the page DB is replicated, and each step ends with ONE RCCL all-gather of
+the per-frame verdict records.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints one JSON line.  `roofline` is the dominant kernel
+(knn_hamming_kernel), timed with HIP events on its launch stream inside the
+library; `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json metric: "frames/sec matched (1080p vs 500-page ORB set)"; SURVEY §8d "Headline"
+    "headline": dict(frame=(1920, 1080), page=(2001, 1125), pages=500, nfeatures=1000, batch=256,
+                     name="1080p frames vs 500-page deck, ORB-1000, exact Hamming kNN k=30 + 5% vote + RANSAC + reprojection verdict"),
+    # BASELINE.json configs[1]
+    "cfg1": dict(frame=(1920, 1080), page=(2001, 1125), pages=100, nfeatures=1000, batch=256,
+                 name="configs[1]: 1080p batch=256 vs 100 pages, ORB-1000"),
+    # small, for smoke runs
+    "tiny": dict(frame=(640, 360), page=(800, 450), pages=8, nfeatures=500, batch=16,
+                 name="tiny: 640x360 vs 8 pages, ORB-500"),
+}
+
+# MI355X ceilings (MI355X_MICROARCH.md): 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 32-bit VALU lane-ops/s
+# (= the 157.3 TFLOPS FP32 vector peak / 2); HBM3E 8 TB/s.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+HBM_PEAK_GBS = 8000.0
+LANEOPS_PER_PAIR = 16          # 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 per 256-bit pair
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
+    ap.add_argument("--pages", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from slideo_amd import _capi, synth
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch: wl["batch"] = args.batch
+    if args.pages: wl["pages"] = args.pages
+    fw, fh = wl["frame"]; pw, ph = wl["page"]
+    B, P = wl["batch"], wl["pages"]
+    ncpu = os.cpu_count() or 1
+    gen_threads = max(1, min(64, ncpu // max(world, 1)))
+
+    # ---- synthetic inputs (seeded; same pages on every rank, disjoint frame ranges per rank)
+    t0 = time.time()
+    pages = synth.pages(P, pw, ph, threads=gen_threads)
+    frames, truth, _ = synth.frames(pages, B, fw, fh, first=rank * B, threads=gen_threads)
+    t_gen = time.time() - t0
+
+    cfg = _capi.default_config(nfeatures=wl["nfeatures"])
+    m = _capi.Matcher(cfg, device=local_rank)
+    t0 = time.time()
+    CH = 50
+    for i in range(0, P, CH):
+        m.add_pages(list(pages[i:i + CH]))
+    m.finalize()
+    torch.cuda.synchronize()
+    t_db = time.time() - t0
+    M = m.descriptor_count
+
+    d_frames = torch.from_numpy(frames).cuda()          # inputs resident in HBM before timing
+    stream = torch.cuda.current_stream().cuda_stream
+    verdict_words = 4
+    d_verdicts = torch.zeros((B, verdict_words), dtype=torch.int32, device="cuda")
+    d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def step():
+        v = m.match_frames_dev(d_frames.data_ptr(), B, fw, fh, stream=stream)
+        if world > 1:
+            d_verdicts.copy_(torch.from_numpy(v.view(np.int32).reshape(B, verdict_words)), non_blocking=False)
+            dist.all_gather_into_tensor(d_all, d_verdicts)      # the one collective of the path (RCCL over xGMI)
+        return v
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        v = step()
+    m.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, knn_pairs = m.read_profile()
+    m.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    acc = float((v["page_idx"] == truth).mean())
+    total_frames = args.steps * B * world
+    fps = total_frames / dt
+
+    out = {
+        "metric": "frames/sec matched (1080p vs 500-page ORB set)" if args.workload == "headline" else "frames/sec matched",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
+                   "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30",
+                   "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step" % world,
+                   "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
+                   "accuracy_vs_synthetic_truth": round(acc, 4),
+                   "mean_keypoints_per_frame": round(float(v["n_keypoints"].mean()), 1)},
+    }
+    if rank == 0:
+        knn_ms, knn_n = prof["knn"]
+        if knn_n > 0:
+            avg_s = knn_ms / knn_n * 1e-3
+            pairs_per_launch = knn_pairs / knn_n
+            q_per_launch = pairs_per_launch / max(M, 1)
+            laneops = LANEOPS_PER_PAIR * pairs_per_launch
+            achieved = laneops / avg_s / 1e12
+            alg_bytes = 32.0 * (q_per_launch + M) + q_per_launch * 32 * 4      # operands once + key lists out
+            out["roofline"] = {
+                "kernel": "knn_hamming_kernel<32>", "bound": "valu",
+                "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
+                "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
+                "pairs_per_launch": int(pairs_per_launch), "laneops_per_pair": LANEOPS_PER_PAIR,
+                "pairs_per_s": round(pairs_per_launch / avg_s, 1),
+                "hbm_view": {"bound": "hbm", "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6),
+                             "algorithmic_bytes_per_launch": int(alg_bytes)},
+            }
+        out["stage_ms_per_step"] = {k: round(ms / max(args.steps, 1), 3) for k, (ms, n) in prof.items()}
+        # ORB stage: algorithmic bytes per frame = 3wh + 5*Pi + 3.6 kB * K
+        ws = [fw]; hs = [fh]
+        for l in range(1, cfg.nlevels):
+            s = np.float32(np.float64(np.float32(cfg.scale_factor)) ** l)
+            ws.append(int(np.rint(np.float32(fw) / s))); hs.append(int(np.rint(np.float32(fh) / s)))
+        Pi = int(sum(a * b for a, b in zip(ws, hs)))
+        orb_bytes = 3 * fw * fh + 5 * Pi + 3600 * float(v["n_keypoints"].mean())
+        orb_ms = prof["orb"][0] / max(prof["orb"][1], 1)
+        if orb_ms > 0:
+            out["orb_stage"] = {"bound": "hbm", "algorithmic_bytes_per_frame": int(orb_bytes),
+                                "achieved": round(orb_bytes * B / (orb_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(orb_bytes * B / (orb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the CPU restatement on the host cores, bounded sample (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"])
+        cores = ncpu
+        db = pyoracle.PageDB(ocfg)
+        t0 = time.time()
+        db.add_pages(pages, threads=cores)
+        rc = db.finalize()
+        t_cpu_db = time.time() - t0
+        assert rc == 0 and db.descriptor_count == M, "CPU restatement and GPU page DB disagree"
+        # ~3 core-seconds per frame at M=5e5: a sample of `cores//8` frames per core-group keeps this ~10-30 s of CPU work
+        ns = args.cpu_sample or max(8, min(B, cores))
+        t0 = time.time()
+        cv = db.match_frames(frames[:ns], threads=min(cores, ns))
+        t_cpu = time.time() - t0
+        agree = float((cv["page_idx"] == v["page_idx"][:ns]).mean())
+        out["cpu_baseline"] = {"value": round(ns / t_cpu, 3), "unit": "frames/s", "cores": int(min(cores, ns)),
+                               "kind": "port", "sample": "%d of the %d benchmark frames, one frame per thread, page DB prebuilt (%.1f s on %d threads)" % (ns, B, t_cpu_db, cores),
+                               "seconds": round(t_cpu, 2), "verdict_agreement_with_gpu": agree}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

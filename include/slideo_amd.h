@@ -166,6 +166,20 @@ int32_t     slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames,
 /* Optional progress sink for add_pages / match_frames. */
 int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user);
 
+/* ---- measurement ---------------------------------------------------------- */
+
+/* Stage timing with HIP events recorded on the stream the kernels are launched
+ * on (bench.py's roofline figures come from here).  enable != 0 starts
+ * accumulating; reading returns and clears the accumulators.  Stages:
+ *   0 orb (gray..describe)  1 knn (knn_hamming_kernel [+ merge])  2 verify
+ *   (vote, ransac, rate, reproject, verdict)  3 whole sub-batch incl. copies.
+ * launches_out[i] = number of timed intervals of stage i; for stage 1 each
+ * interval is exactly one knn_hamming_kernel launch (+ its merge when split). */
+#define SLIDEO_N_STAGES 4
+int32_t     slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable);
+int32_t     slideo_matcher_read_profile(slideo_matcher* m, double* ms_out /*[4]*/,
+                                        int64_t* launches_out /*[4]*/, int64_t* knn_pairs_out);
+
 /* ---- debug taps used by the parity tests ------------------------------ */
 
 /* FeatureExtractor::find_keypoints_and_descriptors (mo/feature_extractor.rs:29-46)

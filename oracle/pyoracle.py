@@ -262,6 +262,13 @@ class PageDB:
         rc = lib().so_pagedb_add_page(C.c_void_p(self._h), _p(bgr), w, h, w * 3)
         assert rc == 0, rc
 
+    def add_pages(self, pages, threads=1):
+        pages = np.ascontiguousarray(pages, np.uint8)
+        n, h, w, _ = pages.shape
+        rc = lib().so_pagedb_add_pages(C.c_void_p(self._h), _p(pages), n, w, h, w * 3,
+                                       C.c_int64(w * h * 3), threads)
+        assert rc == 0, rc
+
     def finalize(self):
         return lib().so_pagedb_finalize(C.c_void_p(self._h))
 

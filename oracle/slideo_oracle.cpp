@@ -1166,6 +1166,28 @@ int so_pagedb_add_page(so_pagedb* db, const uint8_t* bgr, int w, int h, int stri
     db->pages.push_back(std::move(p));
     return 0;
 }
+// n equally sized pages, `threads` workers (mirrors rayon par_iter over pages, mo/lib.rs:45-47)
+int so_pagedb_add_pages(so_pagedb* db, const uint8_t* pages, int n, int w, int h, int stride, int64_t page_stride, int threads) {
+    if (db->finalized) return 4;
+    size_t base = db->pages.size();
+    db->pages.resize(base + n);
+    threads = std::max(1, std::min(threads, n));
+    std::vector<int> rc(threads, 0);
+    auto work = [&](int t) {
+        for (int i = t; i < n; i += threads) {
+            Page& p = db->pages[base + i];
+            p.w = w; p.h = h;
+            const uint8_t* img = pages + (size_t)i * page_stride;
+            orb_detect_describe(img, w, h, stride, db->cfg, p.orb);
+            if (!small_image(img, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh)) rc[t] = 5;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+    for (int r : rc) if (r) return r;
+    return 0;
+}
 int so_pagedb_finalize(so_pagedb* db) {   // mo/flann.rs:65-71 (exact index = the concatenation)
     db->train.clear(); db->train_page.clear(); db->page_ofs.assign(1, 0);
     for (size_t p = 0; p < db->pages.size(); ++p) {

@@ -45,6 +45,7 @@ EXPORTS = [
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
+    "slideo_matcher_set_profiling", "slideo_matcher_read_profile",
 ]
 
 _lib = None
@@ -205,6 +206,17 @@ class Matcher:
         self._check(lib().slideo_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
                                                    _p(prev_small), _p(last), _p(changed), _p(sims)))
         return changed.astype(bool), sims, last
+
+    # ---- measurement ------------------------------------------------------------------
+    def set_profiling(self, enable=True):
+        self._check(lib().slideo_matcher_set_profiling(self._h, int(bool(enable))))
+
+    def read_profile(self):
+        """-> dict(stage -> (ms, intervals)), knn_pairs; clears the accumulators."""
+        ms = (C.c_double * 4)(); n = (C.c_int64 * 4)(); pairs = C.c_int64()
+        self._check(lib().slideo_matcher_read_profile(self._h, ms, n, C.byref(pairs)))
+        names = ["orb", "knn", "verify", "total"]
+        return {names[i]: (ms[i], n[i]) for i in range(4)}, pairs.value
 
     # ---- debug taps -----------------------------------------------------------------
     def orb(self, bgr, cap=None):

@@ -79,6 +79,13 @@ struct slideo_matcher {
     PinBuf h_info, h_verdicts;
     OrbOut orb;
 
+    // stage profiling (HIP events on the launch stream)
+    bool profiling = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double prof_ms[SLIDEO_N_STAGES] = {0, 0, 0, 0};
+    int64_t prof_n[SLIDEO_N_STAGES] = {0, 0, 0, 0};
+    int64_t prof_pairs = 0;
+
     // trace of the last match call
     std::vector<FrameCands> last_fcs;
     std::vector<slideo_verdict> last_verdicts;
@@ -287,7 +294,10 @@ void validate_image(int w, int h, int stride) {
 void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
                      slideo_verdict* out_host, hipStream_t st) {
     const slideo_config& c = m->cfg;
+    const bool prof = m->profiling;
+    if (prof) HIP_CHECK(hipEventRecord(m->ev[0], st));
     run_orb(m, frames_dev, n, w, h, stride, frame_stride, st, false);
+    if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));
     const uint32_t qtot = m->orb.qtot;
     const VerifyParams vp = make_vp(c);
     const int P = (int)m->pages.size();
@@ -296,7 +306,12 @@ void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w,
     HIP_CHECK(hipMemsetAsync(m->d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
     uint32_t* flags = m->d_flags.as<uint32_t>();   // zeroed by run_orb
     if (qtot > 0) {
+        // workspace first, so that no allocation sits inside the timed kNN interval
+        m->d_keys.reserve((size_t)qtot * KLIST * 4);
+        m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
+        if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));   // re-recorded after the (possible) allocations
         run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), (int)m->M, st);
+        if (prof) HIP_CHECK(hipEventRecord(m->ev[2], st));
         m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
         m->d_gpts.reserve((size_t)qtot * c.knn_k * sizeof(float4));
         m->d_gmask.reserve((size_t)qtot * c.knn_k);
@@ -322,13 +337,25 @@ void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w,
     verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), m->d_fcs.as<FrameCands>(),
                                                m->d_verdicts.as<slideo_verdict>());
     check_launch("verdict_kernel");
+    if (prof) HIP_CHECK(hipEventRecord(m->ev[3], st));
     m->h_verdicts.reserve((size_t)n * sizeof(slideo_verdict) + 16);
     HIP_CHECK(hipMemcpyAsync(m->h_verdicts.p, m->d_verdicts.p, (size_t)n * sizeof(slideo_verdict), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), flags, 4, hipMemcpyDeviceToHost, st));
     const size_t base = m->last_fcs.size();
     m->last_fcs.resize(base + n);
     HIP_CHECK(hipMemcpyAsync(m->last_fcs.data() + base, m->d_fcs.p, (size_t)n * sizeof(FrameCands), hipMemcpyDeviceToHost, st));
+    if (prof) HIP_CHECK(hipEventRecord(m->ev[4], st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (prof) {
+        float t;
+        HIP_CHECK(hipEventElapsedTime(&t, m->ev[0], qtot > 0 ? m->ev[1] : m->ev[3])); m->prof_ms[0] += t; m->prof_n[0]++;
+        if (qtot > 0) {
+            HIP_CHECK(hipEventElapsedTime(&t, m->ev[1], m->ev[2])); m->prof_ms[1] += t; m->prof_n[1]++;
+            m->prof_pairs += (int64_t)qtot * m->M;
+            HIP_CHECK(hipEventElapsedTime(&t, m->ev[2], m->ev[3])); m->prof_ms[2] += t; m->prof_n[2]++;
+        }
+        HIP_CHECK(hipEventElapsedTime(&t, m->ev[0], m->ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
+    }
     uint32_t fl;
     std::memcpy(&fl, m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), 4);
     if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
@@ -440,7 +467,27 @@ void slideo_matcher_destroy(slideo_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     delete m;
+}
+
+int32_t slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    HIP_CHECK(hipSetDevice(m->device));
+    if (enable && !m->ev[0]) for (auto& e : m->ev) HIP_CHECK(hipEventCreate(&e));
+    m->profiling = enable != 0;
+    for (int i = 0; i < SLIDEO_N_STAGES; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+    m->prof_pairs = 0;
+    API_CATCH(m)
+}
+
+int32_t slideo_matcher_read_profile(slideo_matcher* m, double* ms_out, int64_t* launches_out, int64_t* knn_pairs_out) {
+    if (!m || !ms_out || !launches_out) return SLIDEO_ERR_INVALID_ARG;
+    for (int i = 0; i < SLIDEO_N_STAGES; ++i) { ms_out[i] = m->prof_ms[i]; launches_out[i] = m->prof_n[i]; m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+    if (knn_pairs_out) *knn_pairs_out = m->prof_pairs;
+    m->prof_pairs = 0;
+    return SLIDEO_OK;
 }
 
 int32_t slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user) {

@@ -232,14 +232,16 @@ static void render_frame(uint64_t seed, int64_t frame_idx, const uint8_t* pages,
 extern "C" {
 
 // n pages of w x h (BGR, packed) into out[n][h][w][3]; sequential (template sharing).
-void slideo_synth_pages(uint64_t seed, int n, int w, int h, uint8_t* out) {
+void slideo_synth_pages(uint64_t seed, int n, int w, int h, uint8_t* out, int threads) {
     Rng rng(seed);
-    Layout prev, cur;
-    for (int i = 0; i < n; ++i) {
-        make_layout(cur, rng, w, h, i ? &prev : nullptr);
-        render_page(cur, i, w, h, out + (size_t)i * w * h * 3);
-        prev = cur;
-    }
+    std::vector<Layout> layouts(n);
+    for (int i = 0; i < n; ++i) make_layout(layouts[i], rng, w, h, i ? &layouts[i - 1] : nullptr);   // sequential: template sharing
+    threads = std::max(1, std::min(threads, n));
+    auto work = [&](int t) { for (int i = t; i < n; i += threads) render_page(layouts[i], i, w, h, out + (size_t)i * w * h * 3); };
+    if (threads == 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
 }
 
 // frames [first, first+n) of fw x fh; truth_page[n], truth_M[n][6] (slide -> frame).

@@ -22,10 +22,11 @@ def _L():
     return _lib
 
 
-def pages(n, w=2001, h=1125, seed=PAGE_SEED):
+def pages(n, w=2001, h=1125, seed=PAGE_SEED, threads=None):
     """n pages, uint8 [n, h, w, 3] BGR."""
     out = np.empty((n, h, w, 3), np.uint8)
-    _L().slideo_synth_pages(C.c_uint64(seed), n, w, h, out.ctypes.data_as(C.c_void_p))
+    threads = threads or min(os.cpu_count() or 1, 64)
+    _L().slideo_synth_pages(C.c_uint64(seed), n, w, h, out.ctypes.data_as(C.c_void_p), threads)
     return out
 
 
@@ -39,7 +40,7 @@ def frames(page_stack, n, w=1920, h=1080, first=0, seed=FRAME_SEED, threads=None
     out = np.empty((n, h, w, 3), np.uint8)
     tp = np.empty(n, np.int32)
     tm = np.empty((n, 6), np.float64)
-    threads = threads or min(os.cpu_count() or 1, 32)
+    threads = threads or min(os.cpu_count() or 1, 64)
     _L().slideo_synth_frames(C.c_uint64(seed), C.c_int64(first), n,
                              page_stack.ctypes.data_as(C.c_void_p), P, pw, ph, w, h,
                              out.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p),
