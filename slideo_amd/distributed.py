@@ -1,0 +1,54 @@
+"""Multi-GPU sharding of the frame path: one process per GPU.
+
+Frames are independent once the page DB exists (crates/matching-opencv/src/lib.rs:213-214), so
+rank r takes a contiguous block of the sampled frames, the page DB is replicated, and the only
+exchange is ONE all-gather of fixed-size verdict records; rank 0 then runs the reference's
+sort + consecutive-duplicate removal (lib.rs:229-244).  Backend "nccl" is RCCL on ROCm (GPU
+tensors); "gloo" works on CPU tensors and is what the CPU-only tests use.
+"""
+import numpy as np
+
+VERDICT_WORDS = 4   # page_idx i32, similarity f32 (bit pattern), inliers i32, n_keypoints i32
+
+
+def shard_range(n_frames, rank, world):
+    """Contiguous block [lo, hi) of rank `rank` (block sizes differ by at most one)."""
+    base, rem = divmod(n_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_verdicts(verdicts, n_total, rank, world, device=None):
+    """verdicts: structured array (_capi.VERDICT_DTYPE) of this rank's block.
+    Returns the concatenation over ranks in frame order (length n_total) on every rank."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return verdicts.copy()
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    buf = np.zeros((cap, VERDICT_WORDS), np.int32)
+    buf[: len(verdicts)] = verdicts.view(np.int32).reshape(-1, VERDICT_WORDS)
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world * cap, VERDICT_WORDS), dtype=torch.int32, device=t.device)
+    dist.all_gather_into_tensor(out, t)          # the single collective of the path
+    out = out.cpu().numpy().reshape(world, cap, VERDICT_WORDS)
+    parts = [out[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)]
+    return np.ascontiguousarray(np.concatenate(parts)).view(verdicts.dtype).reshape(-1)
+
+
+def timeline(verdicts, times_s, frame_idx, total_time_s, total_frames):
+    """lib.rs:185-189 + 229-244 on gathered verdicts: end-of-video sentinel, stable sort by time,
+    drop consecutive equal pages.  Returns a list of (time_s, frame_idx, page_idx or -1)."""
+    rows = [(float(total_time_s), int(total_frames), -1)]
+    rows += [(float(t), int(i), int(p)) for t, i, p in zip(times_s, frame_idx, verdicts["page_idx"])]
+    rows.sort(key=lambda r: r[0])
+    out, last = [], None
+    for r in rows:
+        if last is not None and last == r[2]:
+            continue
+        last = r[2]
+        out.append(r)
+    return out

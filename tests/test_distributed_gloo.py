@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: world-size-2 gloo run of the frame sharding + the single verdict all-gather."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_frames, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from slideo_amd import distributed as D, synth
+    import pyoracle as o
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pages = synth.pages(4, 800, 450, threads=1)
+    frames, truth, _ = synth.frames(pages, n_frames, 640, 360, threads=1)
+    lo, hi = D.shard_range(n_frames, rank, world)
+    db = o.PageDB(o.default_config(nfeatures=500, min_rating=12.0))     # page DB replicated on every rank
+    db.add_pages(pages, threads=1)
+    assert db.finalize() == 0
+    mine = db.match_frames(frames[lo:hi])                               # per-rank hot path (CPU stand-in for the GPU call)
+    allv = D.all_gather_verdicts(mine, n_frames, rank, world)
+    if rank == 0:
+        q.put((allv.tobytes(), truth.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from slideo_amd import distributed as D
+    for n in (0, 1, 7, 8, 9, 216000):
+        for w in (1, 2, 3, 8):
+            r = [D.shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_world2_gloo_gather_equals_single_process(oracle, synth):
+    import torch.multiprocessing as mp
+    from slideo_amd import distributed as D
+    n = 7                                                              # odd: ragged shards (4 + 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs: p.start()
+    raw, truth = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    got = np.frombuffer(raw, dtype=oracle.VERDICT_DTYPE)
+    pages = synth.pages(4, 800, 450, threads=1)
+    frames, truth2, _ = synth.frames(pages, n, 640, 360, threads=1)
+    db = oracle.PageDB(oracle.default_config(nfeatures=500, min_rating=12.0))
+    db.add_pages(pages, threads=2)
+    assert db.finalize() == 0
+    single = db.match_frames(frames, threads=2)
+    assert np.array_equal(got, single)
+    assert got["page_idx"].tolist() == truth == truth2.tolist()
+    # rank-0 post-processing: sentinel + dedup (lib.rs:185-189, 229-244)
+    tl = D.timeline(got, [5.0 * i for i in range(n)], [150 * i for i in range(n)], 5.0 * n, 150 * n)
+    assert tl[-1][2] == -1 or tl[-1][0] < 5.0 * n
+    assert all(a[2] != b[2] for a, b in zip(tl, tl[1:]))
