@@ -11,8 +11,8 @@ the per-frame verdict records.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints one JSON line.  `roofline` is the dominant kernel
-(knn_hamming_kernel), timed with HIP events on its launch stream inside the
+Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the exact
+Hamming kNN: knn_mfma_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
 library; `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
 bounded sample of the same workload on the host cores.
 """
@@ -43,6 +43,7 @@ WORKLOADS = {
 # (= the 157.3 TFLOPS FP32 vector peak / 2); HBM3E 8 TB/s.
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
+MFMA_FP4_PEAK_TFLOPS = 10000.0   # dense FP4/FP6 MFMA peak (MI355X_MICROARCH.md; AMD's 20 PF figure is 2:1 sparse)
 LANEOPS_PER_PAIR = 16          # 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 per 256-bit pair
 
 
@@ -54,6 +55,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
+    ap.add_argument("--knn", default="mfma", choices=["mfma", "valu"], help="kNN engine (identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
@@ -93,6 +95,7 @@ def main():
 
     cfg = _capi.default_config(nfeatures=wl["nfeatures"])
     m = _capi.Matcher(cfg, device=local_rank)
+    m.set_knn_engine(args.knn)
     t0 = time.time()
     CH = 50
     for i in range(0, P, CH):
@@ -146,7 +149,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
-                   "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30",
+                   "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step" % world,
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
                    "accuracy_vs_synthetic_truth": round(acc, 4),
@@ -158,20 +161,26 @@ def main():
             avg_s = knn_ms / knn_n * 1e-3
             pairs_per_launch = knn_pairs / knn_n
             q_per_launch = pairs_per_launch / max(M, 1)
-            laneops = LANEOPS_PER_PAIR * pairs_per_launch
-            achieved = laneops / avg_s / 1e12
-            alg_bytes = 32.0 * (q_per_launch + M) + q_per_launch * 32 * 4      # operands once + key lists out
-            out["roofline"] = {
-                "kernel": "knn_hamming_kernel<32>", "bound": "valu",
-                "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
-                "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": None,
-                "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
-                "pairs_per_launch": int(pairs_per_launch), "laneops_per_pair": LANEOPS_PER_PAIR,
-                "pairs_per_s": round(pairs_per_launch / avg_s, 1),
-                "hbm_view": {"bound": "hbm", "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6),
-                             "algorithmic_bytes_per_launch": int(alg_bytes)},
-            }
+            # minimal operand traffic: packed queries + packed train once, 32 keys per query out
+            alg_bytes = 32.0 * (q_per_launch + M) + q_per_launch * 32 * 4
+            hbm_view = {"bound": "hbm", "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(alg_bytes)}
+            common = {"traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
+                      "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
+                      "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream", "hbm_view": hbm_view}
+            if args.knn == "mfma":
+                # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
+                flops = 2.0 * 256 * pairs_per_launch
+                achieved = flops / avg_s / 1e12
+                out["roofline"] = dict({"kernel": "knn_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4)", "bound": "mfma",
+                                        "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512}, **common)
+            else:
+                laneops = LANEOPS_PER_PAIR * pairs_per_launch
+                achieved = laneops / avg_s / 1e12
+                out["roofline"] = dict({"kernel": "knn_hamming_kernel<32> (v_xor_b32 + v_bcnt_u32_b32)", "bound": "valu",
+                                        "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
+                                        "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR}, **common)
         out["stage_ms_per_step"] = {k: round(ms / max(args.steps, 1), 3) for k, (ms, n) in prof.items()}
         # ORB stage: algorithmic bytes per frame = 3wh + 5*Pi + 3.6 kB * K
         ws = [fw]; hs = [fh]

@@ -175,6 +175,10 @@ int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn
  *   (vote, ransac, rate, reproject, verdict)  3 whole sub-batch incl. copies.
  * launches_out[i] = number of timed intervals of stage i; for stage 1 each
  * interval is exactly one knn_hamming_kernel launch (+ its merge when split). */
+/* kNN engine: 0 = FP4 matrix-core kernel (default), 1 = integer-VALU popcount kernel.
+ * Both are exact and return identical results; the switch exists for A/B measurement. */
+int32_t     slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine);
+
 #define SLIDEO_N_STAGES 4
 int32_t     slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable);
 int32_t     slideo_matcher_read_profile(slideo_matcher* m, double* ms_out /*[4]*/,

@@ -45,7 +45,7 @@ EXPORTS = [
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
-    "slideo_matcher_set_profiling", "slideo_matcher_read_profile",
+    "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine",
 ]
 
 _lib = None
@@ -206,6 +206,10 @@ class Matcher:
         self._check(lib().slideo_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
                                                    _p(prev_small), _p(last), _p(changed), _p(sims)))
         return changed.astype(bool), sims, last
+
+    def set_knn_engine(self, engine):
+        """'mfma' (default, FP4 matrix cores) or 'valu' (integer popcount); identical results."""
+        self._check(lib().slideo_matcher_set_knn_engine(self._h, {"mfma": 0, "valu": 1}[engine]))
 
     # ---- measurement ------------------------------------------------------------------
     def set_profiling(self, enable=True):

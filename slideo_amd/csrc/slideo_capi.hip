@@ -16,6 +16,7 @@
 #include "common.h"
 #include "geom.h"
 #include "knn.hip.h"
+#include "knn_mfma.hip.h"
 #include "orb.hip.h"
 #include "slideo_amd.h"
 #include "verify.hip.h"
@@ -70,7 +71,8 @@ struct slideo_matcher {
     std::vector<HostPage> pages;
     bool finalized = false;
     int64_t M = -1;
-    DevBuf d_train, d_train_page, d_page_xy, d_pageinfo, d_page_small;
+    DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
+    int knn_engine = 0;     // 0 = FP4 MFMA (default), 1 = integer VALU popcount
 
     // workspace
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_prev_small, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
@@ -243,9 +245,33 @@ void run_orb(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, 
 }
 
 // ---- exact Hamming kNN: keys into d_keys[0 .. nq*KLIST) -------------------------------
-void run_knn(slideo_matcher* m, const uint32_t* q_dev, int nq, const uint32_t* t_dev, int nt, hipStream_t st) {
+int knn_pad_rows(int nt) { return cdiv(std::max(nt, 1), KM_ST_ROWS) * KM_ST_ROWS; }
+
+// FP4 tile-major expansion of a packed train matrix (knn_mfma.hip.h)
+void expand_train(const uint32_t* t_dev, int nt, DevBuf& out, hipStream_t st) {
+    const int nt_pad = knn_pad_rows(nt);
+    out.reserve((size_t)nt_pad * 128);
+    knn_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(t_dev, nt, nt_pad, out.as<uint4>());
+    check_launch("knn_expand_train_kernel");
+}
+
+// t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
+void run_knn(slideo_matcher* m, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt, hipStream_t st) {
     if (nq <= 0) return;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    if (m->knn_engine == 0 && nt > 0) {
+        const int qblocks = cdiv(nq, KM_QPB);
+        const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
+        int nseg = qblocks >= 512 ? 1 : std::min(cdiv(512, qblocks), n_st);
+        const int st_per_seg = cdiv(n_st, std::max(nseg, 1));
+        nseg = cdiv(n_st, st_per_seg);
+        m->d_keys.reserve((size_t)nseg * 2 * nq * KLIST * 4);
+        knn_mfma_kernel<<<dim3(qblocks, nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), st_per_seg, m->d_keys.as<uint32_t>());
+        check_launch("knn_mfma_kernel");
+        knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg * 2);
+        check_launch("knn_merge_kernel");
+        return;
+    }
     const int qblocks = cdiv(nq, KNN_BLOCK);
     int nseg = 1;
     if (qblocks < 1024) nseg = std::min(cdiv(1024, qblocks), std::max(1, nt / 4096));
@@ -307,10 +333,10 @@ void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w,
     uint32_t* flags = m->d_flags.as<uint32_t>();   // zeroed by run_orb
     if (qtot > 0) {
         // workspace first, so that no allocation sits inside the timed kNN interval
-        m->d_keys.reserve((size_t)qtot * KLIST * 4);
+        m->d_keys.reserve((size_t)qtot * KLIST * 4 * 2);
         m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
         if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));   // re-recorded after the (possible) allocations
-        run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), (int)m->M, st);
+        run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, st);
         if (prof) HIP_CHECK(hipEventRecord(m->ev[2], st));
         m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
         m->d_gpts.reserve((size_t)qtot * c.knn_k * sizeof(float4));
@@ -471,6 +497,12 @@ void slideo_matcher_destroy(slideo_matcher* m) {
     delete m;
 }
 
+int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
+    if (!m || engine < 0 || engine > 1) return SLIDEO_ERR_INVALID_ARG;
+    m->knn_engine = engine;
+    return SLIDEO_OK;
+}
+
 int32_t slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
@@ -584,6 +616,8 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         HIP_CHECK(hipMemcpy(m->d_train.p, train.data(), train.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
+        expand_train(m->d_train.as<uint32_t>(), (int)M, m->d_trainx, m->stream);
+        HIP_CHECK(hipStreamSynchronize(m->stream));
     }
     if (P > 0) {
         HIP_CHECK(hipMemcpy(m->d_pageinfo.p, info.data(), info.size() * sizeof(PageInfo), hipMemcpyHostToDevice));
@@ -755,7 +789,9 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64));
     HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    run_knn(m, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), nt, st);
+    DevBuf tapx;
+    if (m->knn_engine == 0 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
+    run_knn(m, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt, st);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(m->d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");

@@ -27,8 +27,16 @@ def mdef(capi):
 
 
 # ---- kNN ---------------------------------------------------------------------------------
+# every kNN test runs on both engines: "mfma" (FP4 matrix cores, default) and "valu" (popcount)
 
-def test_knn_random_bit_exact(capi, oracle, mdef):
+@pytest.fixture(params=["mfma", "valu"])
+def knn_engine(request, mdef):
+    mdef.set_knn_engine(request.param)
+    yield request.param
+    mdef.set_knn_engine("mfma")
+
+
+def test_knn_random_bit_exact(capi, oracle, mdef, knn_engine):
     rng = np.random.default_rng(1)
     q = rng.integers(0, 256, (700, 32), dtype=np.uint8)
     t = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
@@ -38,7 +46,7 @@ def test_knn_random_bit_exact(capi, oracle, mdef):
     assert np.array_equal(gi, oi)
 
 
-def test_knn_heavy_ties_and_duplicates(capi, oracle, mdef):
+def test_knn_heavy_ties_and_duplicates(capi, oracle, mdef, knn_engine):
     # few distinct descriptors -> massive distance ties, zero distances; tie rule = lowest row
     rng = np.random.default_rng(2)
     base = rng.integers(0, 256, (7, 32), dtype=np.uint8)
@@ -51,7 +59,7 @@ def test_knn_heavy_ties_and_duplicates(capi, oracle, mdef):
     assert np.array_equal(gd, od) and np.array_equal(gi, oi)
 
 
-def test_knn_fewer_train_rows_than_k(capi, oracle, mdef):
+def test_knn_fewer_train_rows_than_k(capi, oracle, mdef, knn_engine):
     rng = np.random.default_rng(3)
     q = rng.integers(0, 256, (65, 32), dtype=np.uint8)
     for nt in (1, 7, 29):
@@ -62,7 +70,7 @@ def test_knn_fewer_train_rows_than_k(capi, oracle, mdef):
         assert (gi[:, nt:] == -1).all() and (gd[:, nt:] == 65535).all()
 
 
-def test_knn_split_train_merge_path(capi, oracle, mdef):
+def test_knn_split_train_merge_path(capi, oracle, mdef, knn_engine):
     # few queries, many train rows -> the train set is split over blocks and merged
     rng = np.random.default_rng(4)
     q = rng.integers(0, 256, (33, 32), dtype=np.uint8)
@@ -73,7 +81,22 @@ def test_knn_split_train_merge_path(capi, oracle, mdef):
     assert np.array_equal(gd, od) and np.array_equal(gi, oi)
 
 
-def test_knn_other_k(capi, oracle, mdef):
+def test_knn_unaligned_sizes_and_complement(capi, oracle, mdef, knn_engine):
+    # sizes around the 32-row tile / 128-row super-tile / 256-query block edges; all-zero, all-one and
+    # complementary descriptors exercise distance 0 and 256 (the extremes of the +-1 dot product)
+    rng = np.random.default_rng(8)
+    for nq, nt in [(1, 31), (31, 32), (33, 127), (255, 128), (257, 129), (300, 4097)]:
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        q[0] = 0; t[0] = 255; t[-1] = 0
+        if nt > 3: t[2] = ~q[min(nq - 1, 1)]
+        gi, gd = mdef.knn(q, t, 30)
+        oi, od = oracle.knn_hamming(q, t, 30)
+        assert np.array_equal(gd, od) and np.array_equal(gi, oi), (nq, nt)
+    assert gd.max() <= 256 or (gd == 65535).any()
+
+
+def test_knn_other_k(capi, oracle, mdef, knn_engine):
     rng = np.random.default_rng(5)
     q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
     t = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
@@ -83,7 +106,7 @@ def test_knn_other_k(capi, oracle, mdef):
         assert np.array_equal(gi, oi) and np.array_equal(gd, od)
 
 
-def test_knn_property_full_size(capi, mdef):
+def test_knn_property_full_size(capi, mdef, knn_engine):
     # size-independent properties at a BASELINE-scale train set (the oracle would take minutes):
     # distances ascending, ties by ascending row, distances recomputed on the host agree, and
     # the k-th distance bounds every non-returned row for a sample of queries.
@@ -247,6 +270,21 @@ def test_end_to_end_1080p_reference_defaults(capi, oracle, synth):
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v)
     assert list(v["page_idx"]) == list(truth)
+    m.close()
+
+
+def test_knn_engines_give_identical_verdicts(capi, cfg0_data):
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    a = m.match_frames(frames)
+    ca = [m.last_candidates(i) for i in range(len(frames))]
+    m.set_knn_engine("valu")
+    b = m.match_frames(frames)
+    cb = [m.last_candidates(i) for i in range(len(frames))]
+    assert np.array_equal(a, b)
+    for x, y in zip(ca, cb):
+        assert np.array_equal(x["n_votes"], y["n_votes"]) and np.array_equal(x["inliers"], y["inliers"])
     m.close()
 
 
