@@ -70,6 +70,14 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ f
 // [OCV A.2] INTER_LINEAR_EXACT: out = (cy0*(cx0*p00+cx1*p01) + cy1*(cx0*p10+cx1*p11) + 2^15) >> 16
 // grid (ceil(dw/4/256), dh, B)
 // ---------------------------------------------------------------------------
+// Each thread makes 4 adjacent outputs.  Their source span is <= 4*scale + 2 bytes, fetched as
+// (up to 4) aligned dwords per source row instead of 16 single-byte loads.
+__device__ __forceinline__ uint32_t byte_of(const uint32_t (&d)[4], int i) {   // byte i (0..15) of 4 dwords
+    uint32_t lo = (i & 8) ? d[2] : d[0], hi = (i & 8) ? d[3] : d[1];
+    uint32_t w = (i & 4) ? hi : lo;
+    return (w >> ((i & 3) * 8)) & 0xffu;
+}
+
 __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
                                                      LevelGeom src, LevelGeom dst,
                                                      const uint32_t* __restrict__ lin_tab) {
@@ -81,16 +89,41 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
     const uint8_t* r0 = base + src.ofs + (int64_t)yo * src.pitch;
     const uint8_t* r1 = base + src.ofs + (int64_t)min(yo + 1, src.h - 1) * src.pitch;
-    uint32_t outv = 0;
     const int nx = min(4, dst.w - x0);
-    for (int i = 0; i < nx; ++i) {
-        const uint32_t xe = lin_tab[dst.xtab_ofs + x0 + i];
-        const int xo = xe & 0xffff, cx1 = xe >> 16, cx0 = 256 - cx1;
-        const int xo1 = min(xo + 1, src.w - 1);
-        uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
-        uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
-        uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
-        outv |= v << (8 * i);
+    uint32_t xe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xe[i] = lin_tab[dst.xtab_ofs + min(x0 + i, dst.w - 1)];
+    const int xfirst = xe[0] & 0xffff;
+    const int xlast = min((int)(xe[nx - 1] & 0xffff) + 1, src.w - 1);
+    const int xa = xfirst & ~3;                       // aligned start; rows are 16-byte aligned with pitch % 16 == 0
+    uint32_t outv = 0;
+    if (xlast - xa < 16) {
+        uint32_t a[4], b[4];
+        const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int di = min(d0 + i, maxd);
+            a[i] = reinterpret_cast<const uint32_t*>(r0)[di];
+            b[i] = reinterpret_cast<const uint32_t*>(r1)[di];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
+            const int xo1 = min(xo + 1, src.w - 1);
+            uint32_t h0 = (uint32_t)cx0 * byte_of(a, xo - xa) + (uint32_t)cx1 * byte_of(a, xo1 - xa);
+            uint32_t h1 = (uint32_t)cx0 * byte_of(b, xo - xa) + (uint32_t)cx1 * byte_of(b, xo1 - xa);
+            uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
+            outv |= v << (8 * i);
+        }
+    } else {      // (not reached for shrink factors < 3; kept for generality)
+        for (int i = 0; i < nx; ++i) {
+            const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
+            const int xo1 = min(xo + 1, src.w - 1);
+            uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
+            uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
+            uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
+            outv |= v << (8 * i);
+        }
     }
     uint8_t* d = base + dst.ofs + (int64_t)y * dst.pitch + x0;
     if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
@@ -117,13 +150,13 @@ __device__ __forceinline__ int level_of_tile(const PyrGeom& g, int tile, bool bl
     return l;
 }
 
-constexpr int FAST_RW = FAST_TW + 8, FAST_RH = FAST_TH + 8;   // raw tile (halo 4)
+constexpr int FAST_RW = FAST_TW + 16, FAST_RH = FAST_TH + 8;  // raw tile (halo 4, + up to 3 bytes of dword alignment slack)
 constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (halo 1)
 
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist) {
-    __shared__ uint8_t raw[FAST_RH][FAST_RW];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ uint8_t sc[FAST_SH][FAST_SW + 2];
     const int f = blockIdx.y;
     const int l = level_of_tile(g, blockIdx.x, false);
@@ -134,10 +167,16 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
     const int t = g.fast_thr;
 
-    for (int i = threadIdx.x; i < FAST_RW * FAST_RH; i += 256) {
-        int ry = i / FAST_RW, rx = i - ry * FAST_RW;
-        int gx = min(max(x0 - 4 + rx, 0), L.w - 1), gy = min(max(y0 - 4 + ry, 0), L.h - 1);
-        raw[ry][rx] = img[(int64_t)gy * L.pitch + gx];
+    // raw tile: rows y0-4 .. y0+TH+3, columns from the dword-aligned xa <= x0-4; aligned dword loads
+    const int xa = (x0 - 4) & ~3, xoff = (x0 - 4) - xa;          // xoff in 0..3
+    {
+        const int ndw = FAST_RW / 4, maxd = (L.pitch >> 2) - 1;
+        for (int i = threadIdx.x; i < ndw * FAST_RH; i += 256) {
+            int ry = i / ndw, rd = i - ry * ndw;
+            int gy = min(max(y0 - 4 + ry, 0), L.h - 1);
+            int gd = min((xa >> 2) + rd, maxd);
+            reinterpret_cast<uint32_t*>(&raw[ry][0])[rd] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
+        }
     }
     __syncthreads();
     // scores for positions (x0-1+sx, y0-1+sy); positions past the keep-region's
@@ -147,8 +186,15 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
         int score = 0;
         if (gx <= L.rx1 && gy <= L.ry1) {
-            const int cx = sx + 3, cy = sy + 3;   // raw coords
+            const int cx = sx + 3 + xoff, cy = sy + 3;   // raw coords
             const int v = raw[cy][cx];
+            // quick reject: every arc of 9 contains one pixel of each antipodal pair, so a pair whose two
+            // pixels are both within t of the centre rules the pixel out.  Flat regions leave whole waves here.
+            {
+                const int a0 = raw[cy + 3][cx], a8 = raw[cy - 3][cx], a4 = raw[cy][cx + 3], a12 = raw[cy][cx - 3];
+                const bool maybe = (abs(a0 - v) > t || abs(a8 - v) > t) && (abs(a4 - v) > t || abs(a12 - v) > t);
+                if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) { sc[sy][sx] = 0; continue; }
+            }
             int p[16];
             p[0] = raw[cy + 3][cx];     p[1] = raw[cy + 3][cx + 1]; p[2] = raw[cy + 2][cx + 2];
             p[3] = raw[cy + 1][cx + 3]; p[4] = raw[cy][cx + 3];     p[5] = raw[cy - 1][cx + 3];
@@ -225,43 +271,86 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
+// Register sliding-window form: a wave owns a strip of 64 dwords (256 columns, of which the inner
+// BLUR_TW = 248 are outputs) and BLUR_RH output rows; each lane streams one aligned dword per source row,
+// runs the vertical 7-tap pass on packed u16 pairs (v_pk_mad_u16) over a 7-row register ring, fetches
+// its neighbours' vertical sums with wave shuffles for the horizontal pass, and stores one dword.
+// No LDS, no barriers.  The sum is exact integer arithmetic, so vertical-then-horizontal equals
+// OpenCV's horizontal-then-vertical order bit for bit.
+typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t blur_load_dword(const uint8_t* __restrict__ img, int pitch, int w, int gy, int xs) {
+    const uint8_t* row = img + (int64_t)gy * pitch;
+    if (xs >= 0 && xs + 3 < w) return *reinterpret_cast<const uint32_t*>(row + xs);
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d |= (uint32_t)row[reflect101(xs + i, w)] << (8 * i);
+    return d;
+}
+
 __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab) {
-    __shared__ uint8_t raw[BLUR_TH + 6][BLUR_TW + 8];
-    __shared__ uint16_t hp[BLUR_TH + 6][BLUR_TW];
     const int f = blockIdx.y;
     const int l = level_of_tile(g, blockIdx.x, true);
     const LevelGeom L = g.lv[l];
     const int tile = blockIdx.x - L.btile0;
     const int ty = tile / L.btx, tx = tile - ty * L.btx;
-    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tx * BLUR_TW;                                   // first output column of the strip
+    const int y0 = ty * BLUR_TH + wave * BLUR_RH;                  // first output row of this wave
+    if (y0 >= L.h) return;
+    const int xs = x0 - 4 + 4 * lane;                              // this lane's 4 columns (lane 0 / 63 = halo)
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
     uint8_t* out = blur + (int64_t)f * g.frame_bytes + L.ofs;
-    int k[7];
+    uint32_t k[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) k[i] = tab->gk[i];
-    for (int i = threadIdx.x; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-        int ry = i / (BLUR_TW + 6), rx = i - ry * (BLUR_TW + 6);
-        int gx = reflect101(x0 - 3 + rx, L.w), gy = reflect101(y0 - 3 + ry, L.h);
-        raw[ry][rx] = img[(int64_t)gy * L.pitch + gx];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-        int ry = i / BLUR_TW, rx = i - ry * BLUR_TW;
-        uint32_t a = 0;
+    for (int i = 0; i < 7; ++i) k[i] = (uint32_t)tab->gk[i];
+    uint32_t kk[7];                                                // tap replicated in both halves for packed math
 #pragma unroll
-        for (int j = 0; j < 7; ++j) a += (uint32_t)k[j] * raw[ry][rx + j];
-        hp[ry][rx] = (uint16_t)a;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < BLUR_TH * BLUR_TW; i += 256) {
-        int py = i / BLUR_TW, px = i - py * BLUR_TW;
-        int gx = x0 + px, gy = y0 + py;
-        if (gx < L.w && gy < L.h) {
-            uint32_t a = 0;
+    for (int i = 0; i < 7; ++i) kk[i] = k[i] | (k[i] << 16);
+    // ring of the last 7 source rows, each as two packed-u16 dwords: A = (p0,p1), B = (p2,p3)
+    uint32_t ra[7], rb[7];
+    auto fetch = [&](int y, uint32_t& A, uint32_t& B) {
+        uint32_t d = blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs);
+        A = __builtin_amdgcn_perm(0u, d, 0x0C010C00u);             // bytes: [p0, 0, p1, 0]
+        B = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);             // bytes: [p2, 0, p3, 0]
+    };
 #pragma unroll
-            for (int j = 0; j < 7; ++j) a += (uint32_t)k[j] * hp[py + j][px];
-            out[(int64_t)gy * L.pitch + gx] = (uint8_t)((a + (1u << 15)) >> 16);
+    for (int j = 0; j < 6; ++j) fetch(y0 - 3 + j, ra[j], rb[j]);
+    const bool inner = lane >= 1 && lane <= 62;
+    for (int gI = 0; gI < BLUR_RH / 7; ++gI) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) {
+            const int i = gI * 7 + ph;                              // output row y0 + i; taps are rows y0+i-3+j in ring[(ph+j)%7]
+            fetch(y0 + i + 3, ra[(ph + 6) % 7], rb[(ph + 6) % 7]);
+            uint32_t va = 0, vb = 0;                                // packed vertical sums (<= 65280 each)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                blur_us2 ka = __builtin_bit_cast(blur_us2, kk[j]);
+                va = __builtin_bit_cast(uint32_t, (blur_us2)(__builtin_bit_cast(blur_us2, ra[(ph + j) % 7]) * ka + __builtin_bit_cast(blur_us2, va)));
+                vb = __builtin_bit_cast(uint32_t, (blur_us2)(__builtin_bit_cast(blur_us2, rb[(ph + j) % 7]) * ka + __builtin_bit_cast(blur_us2, vb)));
+            }
+            // neighbours: left lane's (v1 | v2,v3), right lane's (v0,v1 | v2)
+            const uint32_t la = __shfl_up(va, 1), lb = __shfl_up(vb, 1);
+            const uint32_t rA = __shfl_down(va, 1), rB = __shfl_down(vb, 1);
+            uint32_t x[10];                                         // vertical sums of columns xs-3 .. xs+6
+            x[0] = la >> 16; x[1] = lb & 0xffff; x[2] = lb >> 16;
+            x[3] = va & 0xffff; x[4] = va >> 16; x[5] = vb & 0xffff; x[6] = vb >> 16;
+            x[7] = rA & 0xffff; x[8] = rA >> 16; x[9] = rB & 0xffff;
+            uint32_t o = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a += k[j] * x[c + j];
+                o |= ((a + (1u << 15)) >> 16) << (8 * c);
+            }
+            const int gy = y0 + i;
+            if (inner && gy < L.h && xs < L.w) {
+                uint8_t* d = out + (int64_t)gy * L.pitch + xs;
+                if (xs + 3 < L.w) *reinterpret_cast<uint32_t*>(d) = o;
+                else for (int c = 0; c < 4 && xs + c < L.w; ++c) d[c] = (uint8_t)(o >> (8 * c));
+            }
         }
     }
 }
