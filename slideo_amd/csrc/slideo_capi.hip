@@ -77,7 +77,7 @@ struct slideo_matcher {
     // workspace
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_prev_small, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_small, d_ssd;
-    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist;
+    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist, d_knn_pend;
     PinBuf h_info, h_verdicts;
     OrbOut orb;
 
@@ -262,14 +262,18 @@ void run_knn(slideo_matcher* m, const uint32_t* q_dev, int nq, const uint32_t* t
     if (m->knn_engine == 0 && nt > 0) {
         const int qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
-        int nseg = qblocks >= 512 ? 1 : std::min(cdiv(512, qblocks), n_st);
+        int nseg = qblocks >= 384 ? 1 : std::min(cdiv(512, qblocks), n_st);
         const int st_per_seg = cdiv(n_st, std::max(nseg, 1));
         nseg = cdiv(n_st, st_per_seg);
-        m->d_keys.reserve((size_t)nseg * 2 * nq * KLIST * 4);
-        knn_mfma_kernel<<<dim3(qblocks, nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), st_per_seg, m->d_keys.as<uint32_t>());
+        m->d_keys.reserve((size_t)nseg * nq * KLIST * 4);
+        m->d_knn_pend.reserve((size_t)qblocks * nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
+        knn_mfma_kernel<<<dim3(qblocks, nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), st_per_seg, m->d_keys.as<uint32_t>(),
+                                                                    m->d_knn_pend.as<uint32_t>());
         check_launch("knn_mfma_kernel");
-        knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg * 2);
-        check_launch("knn_merge_kernel");
+        if (nseg > 1) {
+            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg);
+            check_launch("knn_merge_kernel");
+        }
         return;
     }
     const int qblocks = cdiv(nq, KNN_BLOCK);
@@ -334,6 +338,7 @@ void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w,
     if (qtot > 0) {
         // workspace first, so that no allocation sits inside the timed kNN interval
         m->d_keys.reserve((size_t)qtot * KLIST * 4 * 2);
+        m->d_knn_pend.reserve((size_t)cdiv((int)qtot, KM_QPB) * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
         m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
         if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));   // re-recorded after the (possible) allocations
         run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, st);
