@@ -43,6 +43,7 @@ constexpr int KM_THREADS = KM_WAVES * 64;
 constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-query B tiles per wave)
 constexpr int KM_ST_ROWS = 128;                // rows per super-tile
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
+constexpr int KM_STAGE = KM_ST_U4 / KM_THREADS;  // uint4 staged per thread and super-tile
 
 // 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if 0, 0xA (-1.0) if 1; bit i -> nibble i.
 __host__ __device__ __forceinline__ uint32_t fp4_expand8(uint32_t byte) {
@@ -155,17 +156,17 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     };
 
     if (st0 < st1) {
-        lds[0][tid] = tx[(size_t)st0 * KM_ST_U4 + tid];
-        lds[0][tid + KM_THREADS] = tx[(size_t)st0 * KM_ST_U4 + tid + KM_THREADS];
+#pragma unroll
+        for (int i = 0; i < KM_STAGE; ++i) lds[0][tid + i * KM_THREADS] = tx[(size_t)st0 * KM_ST_U4 + tid + i * KM_THREADS];
     }
     __syncthreads();
     int cur = 0;
     for (int st = st0; st < st1; ++st) {
-        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        uint4 nx[KM_STAGE];
         const bool more = st + 1 < st1;
         if (more) {
-            n0 = tx[(size_t)(st + 1) * KM_ST_U4 + tid];
-            n1 = tx[(size_t)(st + 1) * KM_ST_U4 + tid + KM_THREADS];
+#pragma unroll
+            for (int i = 0; i < KM_STAGE; ++i) nx[i] = tx[(size_t)(st + 1) * KM_ST_U4 + tid + i * KM_THREADS];
         }
         const uint4* L = lds[cur];
 #pragma unroll 1
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             }
         }
         if (more) {
-            lds[cur ^ 1][tid] = n0;
-            lds[cur ^ 1][tid + KM_THREADS] = n1;
+#pragma unroll
+            for (int i = 0; i < KM_STAGE; ++i) lds[cur ^ 1][tid + i * KM_THREADS] = nx[i];
         }
         __syncthreads();
         cur ^= 1;
