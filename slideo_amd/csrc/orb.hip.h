@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ f
 // ---------------------------------------------------------------------------
 // Each thread makes 4 adjacent outputs.  Their source span is <= 4*scale + 2 bytes, fetched as
 // (up to 4) aligned dwords per source row instead of 16 single-byte loads.
-__device__ __forceinline__ uint32_t byte_of(const uint32_t (&d)[4], int i) {   // byte i (0..15) of 4 dwords
-    uint32_t lo = (i & 8) ? d[2] : d[0], hi = (i & 8) ? d[3] : d[1];
-    uint32_t w = (i & 4) ? hi : lo;
-    return (w >> ((i & 3) * 8)) & 0xffu;
+__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, int i) {   // byte i (0..15) of 16 bytes
+    // (a dynamically indexed register array would be demoted to LDS by the compiler)
+    const uint64_t w = (i & 8) ? hi : lo;
+    return (uint32_t)(w >> ((i & 7) * 8)) & 0xffu;
 }
 
 __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
@@ -98,20 +98,18 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     const int xa = xfirst & ~3;                       // aligned start; rows are 16-byte aligned with pitch % 16 == 0
     uint32_t outv = 0;
     if (xlast - xa < 16) {
-        uint32_t a[4], b[4];
         const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int di = min(d0 + i, maxd);
-            a[i] = reinterpret_cast<const uint32_t*>(r0)[di];
-            b[i] = reinterpret_cast<const uint32_t*>(r1)[di];
-        }
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0);
+        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1);
+        const int i0 = min(d0, maxd), i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd), i3 = min(d0 + 3, maxd);
+        const uint64_t alo = (uint64_t)p0[i0] | ((uint64_t)p0[i1] << 32), ahi = (uint64_t)p0[i2] | ((uint64_t)p0[i3] << 32);
+        const uint64_t blo = (uint64_t)p1[i0] | ((uint64_t)p1[i1] << 32), bhi = (uint64_t)p1[i2] | ((uint64_t)p1[i3] << 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
             const int xo1 = min(xo + 1, src.w - 1);
-            uint32_t h0 = (uint32_t)cx0 * byte_of(a, xo - xa) + (uint32_t)cx1 * byte_of(a, xo1 - xa);
-            uint32_t h1 = (uint32_t)cx0 * byte_of(b, xo - xa) + (uint32_t)cx1 * byte_of(b, xo1 - xa);
+            uint32_t h0 = (uint32_t)cx0 * byte_of(alo, ahi, xo - xa) + (uint32_t)cx1 * byte_of(alo, ahi, xo1 - xa);
+            uint32_t h1 = (uint32_t)cx0 * byte_of(blo, bhi, xo - xa) + (uint32_t)cx1 * byte_of(blo, bhi, xo1 - xa);
             uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
             outv |= v << (8 * i);
         }
@@ -158,6 +156,8 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
                                                    uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ uint8_t sc[FAST_SH][FAST_SW + 2];
+    __shared__ uint16_t queue[FAST_SW * FAST_SH];
+    __shared__ uint32_t qn;
     const int f = blockIdx.y;
     const int l = level_of_tile(g, blockIdx.x, false);
     const LevelGeom L = g.lv[l];
@@ -179,22 +179,39 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         }
     }
     __syncthreads();
-    // scores for positions (x0-1+sx, y0-1+sy); positions past the keep-region's
-    // 1-px halo are not needed (score 0).  All needed positions are >= 3 px inside the level.
+    // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy).  Every arc of 9 contains one pixel of
+    // each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out; the
+    // four pairs tested here (axes + diagonals) leave only corner-like pixels.  Survivors are queued so that the
+    // full segment test and the score run densely on them instead of dragging whole waves along.
+    // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < FAST_SW * FAST_SH; i += 256) {
         int sy = i / FAST_SW, sx = i - sy * FAST_SW;
         int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        int score = 0;
+        sc[sy][sx] = 0;
         if (gx <= L.rx1 && gy <= L.ry1) {
             const int cx = sx + 3 + xoff, cy = sy + 3;   // raw coords
             const int v = raw[cy][cx];
-            // quick reject: every arc of 9 contains one pixel of each antipodal pair, so a pair whose two
-            // pixels are both within t of the centre rules the pixel out.  Flat regions leave whole waves here.
-            {
-                const int a0 = raw[cy + 3][cx], a8 = raw[cy - 3][cx], a4 = raw[cy][cx + 3], a12 = raw[cy][cx - 3];
-                const bool maybe = (abs(a0 - v) > t || abs(a8 - v) > t) && (abs(a4 - v) > t || abs(a12 - v) > t);
-                if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) { sc[sy][sx] = 0; continue; }
+            const int a0 = raw[cy + 3][cx], a8 = raw[cy - 3][cx], a4 = raw[cy][cx + 3], a12 = raw[cy][cx - 3];
+            bool maybe = (abs(a0 - v) > t || abs(a8 - v) > t) && (abs(a4 - v) > t || abs(a12 - v) > t);
+            if (maybe) {
+                const int a2 = raw[cy + 2][cx + 2], a10 = raw[cy - 2][cx - 2], a6 = raw[cy - 2][cx + 2], a14 = raw[cy + 2][cx - 2];
+                maybe = (abs(a2 - v) > t || abs(a10 - v) > t) && (abs(a6 - v) > t || abs(a14 - v) > t);
             }
+            if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    // Phase B — segment test + cornerScore<16> on the queued positions only
+    const uint32_t nqueued = qn;
+    for (uint32_t kq = threadIdx.x; kq < nqueued; kq += 256) {
+        const int i = queue[kq];
+        const int sy = i / FAST_SW, sx = i - sy * FAST_SW;
+        int score = 0;
+        {
+            const int cx = sx + 3 + xoff, cy = sy + 3;   // raw coords
+            const int v = raw[cy][cx];
             int p[16];
             p[0] = raw[cy + 3][cx];     p[1] = raw[cy + 3][cx + 1]; p[2] = raw[cy + 2][cx + 2];
             p[3] = raw[cy + 1][cx + 3]; p[4] = raw[cy][cx + 3];     p[5] = raw[cy - 1][cx + 3];

@@ -77,7 +77,7 @@ struct slideo_matcher {
     // workspace
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_prev_small, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_small, d_ssd;
-    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist, d_knn_pend;
+    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist, d_knn_pend, d_pairs;
     PinBuf h_info, h_verdicts;
     OrbOut orb;
 
@@ -355,14 +355,18 @@ void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w,
                                                                      m->d_rng.as<uint32_t>(), m->d_fcs.as<FrameCands>(),
                                                                      m->d_gpts.as<float4>(), m->d_gmask.as<uint8_t>(), flags);
         check_launch("ransac_kernel");
-        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_fcs.as<FrameCands>());
+        m->d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
+        uint32_t* pair_count = m->d_pairs.as<uint32_t>();
+        PairDesc* pair_list = reinterpret_cast<PairDesc*>(m->d_pairs.as<uint8_t>() + 64);
+        HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));
+        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
         check_launch("rate_kernel");
-        int max_tiles = 0;
-        for (const AreaGeom& ag : m->area_geoms) max_tiles = std::max(max_tiles, cdiv(ag.dw, SM_TW) * cdiv(ag.dh, SM_TH));
-        reproject_kernel<<<dim3(max_tiles, c.max_rated, n), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
-                                                                          m->d_area_idx.as<int32_t>(), m->d_pageinfo.as<PageInfo>(),
-                                                                          m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
-                                                                          stride, w, h, m->d_fcs.as<FrameCands>());
+        int max_tile_rows = 0;
+        for (const AreaGeom& ag : m->area_geoms) max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));
+        reproject_kernel<<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
+                                                                                  m->d_area_idx.as<int32_t>(),
+                                                                                  m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
+                                                                                  stride, w, h, m->d_fcs.as<FrameCands>(), pair_list, pair_count);
         check_launch("reproject_kernel");
     }
     verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), m->d_fcs.as<FrameCands>(),

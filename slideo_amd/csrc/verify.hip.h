@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "geom.h"
 #include "knn.hip.h"
 
@@ -46,6 +48,12 @@ struct PageInfo {              // per page, device resident
     int32_t kp_ofs, kp_cnt;    // rows of this page in the train matrix
     int32_t _pad;
     int64_t small_ofs;         // byte offset of the small image
+};
+
+struct PairDesc {              // one (frame, survivor) unit of re-projection work, written by rate_kernel
+    int32_t f, s, area_idx, _pad;
+    int64_t small_ofs;
+    double M[6];
 };
 
 struct VerifyParams {
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
 // ---------------------------------------------------------------------------
 // rate_kernel: one thread per frame.      lib.rs:329-333
 // ---------------------------------------------------------------------------
-__global__ void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict__ fcs) {
+__global__ void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict__ fcs, const PageInfo* __restrict__ pages,
+                            PairDesc* __restrict__ pair_list, uint32_t* __restrict__ pair_count) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;
     FrameCands& fc = fcs[f];
@@ -429,6 +438,17 @@ __global__ void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict
         }
     }
     fc.nsurv = ns;
+    if (ns > 0) {     // compact (frame, survivor) work list for reproject_kernel; order is irrelevant (sums are per pair)
+        const uint32_t base = atomicAdd(pair_count, (uint32_t)ns);
+        for (int i = 0; i < ns; ++i) {
+            const int r = fc.surv[i];
+            const PageInfo pg = pages[fc.page[r]];
+            PairDesc d;
+            d.f = f; d.s = i; d.area_idx = pg.area_idx; d._pad = 0; d.small_ofs = pg.small_ofs;
+            for (int j = 0; j < 6; ++j) d.M[j] = fc.M[r][j];
+            pair_list[base + i] = d;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -449,6 +469,73 @@ __device__ __forceinline__ uint8_t sat_u8_f(float v) {
 template <class Fetch>
 __device__ __forceinline__ void area_pixel(const AreaGeom& ag, const AreaTap* __restrict__ taps, const int32_t* __restrict__ idx,
                                            int dx, int dy, Fetch fetch, uint8_t out[3]) {
+    if (ag.fast) {
+        int sum0 = 0, sum1 = 0, sum2 = 0;
+        for (int yy = 0; yy < ag.iscale_y; ++yy)
+            for (int xx = 0; xx < ag.iscale_x; ++xx) {
+                uint8_t p[3];
+                fetch(min(dx * ag.iscale_x + xx, ag.sw - 1), min(dy * ag.iscale_y + yy, ag.sh - 1), p);
+                sum0 += p[0]; sum1 += p[1]; sum2 += p[2];
+            }
+        if (ag.iscale_x == 2 && ag.iscale_y == 2) {
+            out[0] = (uint8_t)((sum0 + 2) >> 2); out[1] = (uint8_t)((sum1 + 2) >> 2); out[2] = (uint8_t)((sum2 + 2) >> 2);
+        } else {
+            out[0] = sat_u8_f((float)sum0 * ag.fast_scale); out[1] = sat_u8_f((float)sum1 * ag.fast_scale);
+            out[2] = sat_u8_f((float)sum2 * ag.fast_scale);
+        }
+        return;
+    }
+    const int xb = idx[ag.xidx_ofs + dx], xe = idx[ag.xidx_ofs + dx + 1];
+    const int yb = idx[ag.yidx_ofs + dy], ye = idx[ag.yidx_ofs + dy + 1];
+    float s0 = 0, s1 = 0, s2 = 0;
+    constexpr int XB = 8;                       // x taps fetched per batch (a shrink by s needs <= ceil(s) + 2 taps)
+    if (xe - xb <= XB) {
+        // common case: all x taps of a source row in ONE batch -> their gathers are in flight together.
+        // Taps beyond xe get alpha 0 and a clamped (valid) source index; adding 0.f * p leaves the sum unchanged
+        // bit for bit (the partial sums are non-negative, so no -0 can arise).
+        AreaTap tx[XB];
+#pragma unroll
+        for (int k = 0; k < XB; ++k) {
+            const bool in = xb + k < xe;
+            tx[k] = taps[ag.xtap_ofs + (in ? xb + k : xe - 1)];
+            if (!in) tx[k].alpha = 0.f;
+        }
+        for (int j = yb; j < ye; ++j) {
+            const AreaTap ty = taps[ag.ytap_ofs + j];
+            uint8_t p[XB][3];
+#pragma unroll
+            for (int k = 0; k < XB; ++k) fetch(tx[k].si, ty.si, p[k]);
+            float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+            for (int k = 0; k < XB; ++k) {
+                if (xb + k < xe) {
+                    b0 = b0 + (float)p[k][0] * tx[k].alpha; b1 = b1 + (float)p[k][1] * tx[k].alpha; b2 = b2 + (float)p[k][2] * tx[k].alpha;
+                }
+            }
+            if (j == yb) { s0 = ty.alpha * b0; s1 = ty.alpha * b1; s2 = ty.alpha * b2; }
+            else { s0 += ty.alpha * b0; s1 += ty.alpha * b1; s2 += ty.alpha * b2; }
+        }
+    } else {
+        for (int j = yb; j < ye; ++j) {
+            const AreaTap ty = taps[ag.ytap_ofs + j];
+            float b0 = 0, b1 = 0, b2 = 0;
+            for (int kx = xb; kx < xe; ++kx) {
+                const AreaTap tx = taps[ag.xtap_ofs + kx];
+                uint8_t p[3];
+                fetch(tx.si, ty.si, p);
+                b0 = b0 + (float)p[0] * tx.alpha; b1 = b1 + (float)p[1] * tx.alpha; b2 = b2 + (float)p[2] * tx.alpha;
+            }
+            if (j == yb) { s0 = ty.alpha * b0; s1 = ty.alpha * b1; s2 = ty.alpha * b2; }
+            else { s0 += ty.alpha * b0; s1 += ty.alpha * b1; s2 += ty.alpha * b2; }
+        }
+    }
+    out[0] = sat_u8_f(s0); out[1] = sat_u8_f(s1); out[2] = sat_u8_f(s2);
+}
+
+// Same arithmetic, no batching (compact code) — used by reproject's rare fallback paths.
+template <class Fetch>
+__device__ __noinline__ void area_pixel_simple(const AreaGeom& ag, const AreaTap* __restrict__ taps, const int32_t* __restrict__ idx,
+                                               int dx, int dy, Fetch fetch, uint8_t out[3]) {
     if (ag.fast) {
         int sum0 = 0, sum1 = 0, sum2 = 0;
         for (int yy = 0; yy < ag.iscale_y; ++yy)
@@ -524,52 +611,170 @@ __global__ __launch_bounds__(256) void ssd_kernel(const uint8_t* __restrict__ a,
 // For survivor s of frame f: warp the frame into the slide's space (nearest, inverse map,
 // 10-bit fixed point, [OCV A.10]), area-resize to the slide's small size, accumulate the
 // squared difference against the slide's small image.
+// The fixed-point warp terms of imgwarp.cpp — adelta[x], bdelta[x] per source column and X0[y], Y0[y] per
+// source row — are computed once per block into LDS for the source window of the block's 32x8 small pixels,
+// so the per-tap work is two LDS reads, two adds/shifts and one 3-byte gather.
+constexpr int RP_SPAN_X = 512, RP_SPAN_Y = 160;
+constexpr int RP_WIN_BYTES = 32 * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
+
+// grid (max tile rows, min(B, 65535)), block 256.  Block (ty, y) walks the pairs y, y + gridDim.y, ... of the compact
+// list built by rate_kernel and, for each, the whole row `ty` of 32x8 output tiles: the per-pair constants are
+// fetched once (one flat descriptor instead of a chain of dependent loads) and amortised over the strip.
 __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
-                                                        const int32_t* __restrict__ idx, const PageInfo* __restrict__ pages,
+                                                        const int32_t* __restrict__ idx,
                                                         const uint8_t* __restrict__ page_small,
                                                         const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
-                                                        int fw, int fh, FrameCands* __restrict__ fcs) {
+                                                        int fw, int fh, FrameCands* __restrict__ fcs,
+                                                        const PairDesc* __restrict__ pair_list, const uint32_t* __restrict__ pair_count) {
     __shared__ unsigned long long red[4];
-    const int s = blockIdx.y, f = blockIdx.z;
-    FrameCands& fc = fcs[f];
-    if (s >= fc.nsurv) return;
-    const int r = fc.surv[s];
-    const PageInfo pg = pages[fc.page[r]];
-    const AreaGeom ag = ags[pg.area_idx];
-    const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1)), dy = ty * SM_TH + (threadIdx.x / SM_TW);
-    double M[6];
+    __shared__ int s_ad[RP_SPAN_X], s_bd[RP_SPAN_X], s_x0[RP_SPAN_Y], s_y0[RP_SPAN_Y];
+    __shared__ __attribute__((aligned(16))) uint8_t win[RP_WIN_BYTES + 16];   // + a zero pixel at RP_WIN_BYTES
+    const uint32_t npairs = *pair_count;
+    if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(win + RP_WIN_BYTES)[threadIdx.x] = 0;
+    const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
+    for (uint32_t pi = blockIdx.y; pi < npairs; pi += gridDim.y) {
+        const PairDesc pd = pair_list[pi];
+        const int f = pd.f;
+        const AreaGeom ag = ags[pd.area_idx];
+        const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
+        const int ty = blockIdx.x;
+        if (ty >= tiles_y) continue;                                  // uniform per block
+        double M[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) M[j] = fc.M[r][j];
-    const uint8_t* frame = frames + (int64_t)f * frame_stride;
-    unsigned long long acc = 0;
-    if (dx < ag.dw && dy < ag.dh) {
-        uint8_t o[3];
-        area_pixel(ag, taps, idx, dx, dy, [&](int x, int y, uint8_t* p) {
-            const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
-            int adelta = sat_int_d(M[0] * x * AB_SCALE), bdelta = sat_int_d(M[3] * x * AB_SCALE);
-            int X0 = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
-            int Y0 = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
-            int X = (int)((uint32_t)X0 + (uint32_t)adelta) >> AB_BITS;
-            int Y = (int)((uint32_t)Y0 + (uint32_t)bdelta) >> AB_BITS;
-            X = X < -32768 ? -32768 : (X > 32767 ? 32767 : X);
-            Y = Y < -32768 ? -32768 : (Y > 32767 ? 32767 : Y);
-            if ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) {
-                const uint8_t* sp = frame + (int64_t)Y * stride + 3 * X;
-                p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
-            } else { p[0] = p[1] = p[2] = 0; }
-        }, o);
-        const uint8_t* ref = page_small + pg.small_ofs + ((int64_t)dy * ag.dw + dx) * 3;
-        int d0 = (int)o[0] - ref[0], d1 = (int)o[1] - ref[1], d2 = (int)o[2] - ref[2];
-        acc = (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+        for (int j = 0; j < 6; ++j) M[j] = pd.M[j];
+        const uint8_t* frame = frames + (int64_t)f * frame_stride;
+        const int dy = ty * SM_TH + (threadIdx.x / SM_TW);
+        const int dya = ty * SM_TH, dyb = min(ag.dh, dya + SM_TH) - 1;
+        int sy_lo, sy_hi;
+        if (ag.fast) { sy_lo = dya * ag.iscale_y; sy_hi = min((dyb + 1) * ag.iscale_y - 1, ag.sh - 1); }
+        else { sy_lo = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dya]].si; sy_hi = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dyb + 1] - 1].si; }
+        const bool tabled_y = (sy_hi - sy_lo) < RP_SPAN_Y;
+        __syncthreads();                                              // previous pair's readers of the LDS tables are done
+        if (tabled_y)
+            for (int i = threadIdx.x; i <= sy_hi - sy_lo; i += 256) {
+                const int y = sy_lo + i;
+                s_x0[i] = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+                s_y0[i] = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+            }
+        unsigned long long acc = 0;
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1));
+            const int dxa = tx * SM_TW, dxb = min(ag.dw, dxa + SM_TW) - 1;
+            int sx_lo, sx_hi;
+            if (ag.fast) { sx_lo = dxa * ag.iscale_x; sx_hi = min((dxb + 1) * ag.iscale_x - 1, ag.sw - 1); }
+            else { sx_lo = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxa]].si; sx_hi = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxb + 1] - 1].si; }
+            const bool tabled = tabled_y && (sx_hi - sx_lo) < RP_SPAN_X;
+            __syncthreads();                                          // previous tile's readers of s_ad / win are done
+            if (tabled)
+                for (int i = threadIdx.x; i <= sx_hi - sx_lo; i += 256) {
+                    const int x = sx_lo + i;
+                    s_ad[i] = sat_int_d(M[0] * x * AB_SCALE); s_bd[i] = sat_int_d(M[3] * x * AB_SCALE);
+                }
+            __syncthreads();
+            // frame-space bounding box of the window: X, Y are monotone in x and in y, so the corners bound them
+            bool windowed = false;
+            int wx0 = 0, wy0 = 0, wpitch = 0;
+            if (tabled) {
+                const int nx = sx_hi - sx_lo, ny = sy_hi - sy_lo;
+                auto XY = [&](int ix, int iy, int& X, int& Y) {
+                    X = (int)((uint32_t)s_x0[iy] + (uint32_t)s_ad[ix]) >> AB_BITS;
+                    Y = (int)((uint32_t)s_y0[iy] + (uint32_t)s_bd[ix]) >> AB_BITS;
+                };
+                int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
+                XY(0, 0, X00, Y00); XY(nx, 0, X10, Y10); XY(0, ny, X01, Y01); XY(nx, ny, X11, Y11);
+                int bx0 = max(min(min(X00, X10), min(X01, X11)), 0), bx1 = min(max(max(X00, X10), max(X01, X11)), fw - 1);
+                int by0 = max(min(min(Y00, Y10), min(Y01, Y11)), 0), by1 = min(max(max(Y00, Y10), max(Y01, Y11)), fh - 1);
+                if (bx1 >= bx0 && by1 >= by0) {
+                    // window columns start at a multiple of 4 pixels so that 4 pixels = 3 aligned source dwords;
+                    // stored as 4 bytes per pixel (B,G,R,0): one aligned ds_read_b32 per tap later
+                    const int px0 = bx0 & ~3, npx4 = (bx1 - px0 + 4) >> 2;        // groups of 4 pixels per row
+                    wpitch = npx4 * 16;
+                    if ((int64_t)wpitch * (by1 - by0 + 1) <= RP_WIN_BYTES && (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)stride) & 3) == 0) {
+                        windowed = true; wx0 = px0; wy0 = by0;
+                        const int nrows = by1 - by0 + 1;
+                        const int last_dw = (stride >> 2) - 1;                    // stay inside the row allocation
+                        for (int i = threadIdx.x; i < npx4 * nrows; i += 256) {
+                            const int ry = i / npx4, g = i - ry * npx4;
+                            const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(by0 + ry) * stride);
+                            const int d0 = ((px0 >> 2) + g) * 3;
+                            const uint32_t a = row[min(d0, last_dw)], b = row[min(d0 + 1, last_dw)], c = row[min(d0 + 2, last_dw)];
+                            uint4 o4;                                             // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                            o4.x = a & 0x00FFFFFFu;
+                            o4.y = (a >> 24) | ((b & 0xFFFFu) << 8);
+                            o4.z = (b >> 16) | ((c & 0xFFu) << 16);
+                            o4.w = c >> 8;
+                            reinterpret_cast<uint4*>(win)[i] = o4;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (dx < ag.dw && dy < ag.dh) {
+                uint8_t o[3];
+                const int xb = ag.fast ? 0 : idx[ag.xidx_ofs + dx], xe = ag.fast ? 0 : idx[ag.xidx_ofs + dx + 1];
+                if (windowed && !ag.fast && ag.max_xtaps <= 8) {
+                    // common case: LDS tables + LDS window.  Per output pixel: x-tap terms once, then per source row
+                    // 2 LDS reads and per tap 2 add/shift pairs, a bounds test and ONE aligned 4-byte LDS read.
+                    // Out-of-frame taps and the padding taps (alpha 0) read the zero pixel kept at the end of `win`.
+                    const int yb = idx[ag.yidx_ofs + dy], ye = idx[ag.yidx_ofs + dy + 1];
+                    auto run = [&](auto xb_tag) {
+                        constexpr int XB = decltype(xb_tag)::value;
+                        float al[XB]; int adk[XB], bdk[XB];
+#pragma unroll
+                        for (int k = 0; k < XB; ++k) {
+                            const bool in = xb + k < xe;
+                            const AreaTap t = taps[ag.xtap_ofs + (in ? xb + k : xe - 1)];
+                            al[k] = in ? t.alpha : 0.f;
+                            adk[k] = s_ad[t.si - sx_lo]; bdk[k] = in ? s_bd[t.si - sx_lo] : (int)0x40000000;   // padding taps land far outside the frame
+                        }
+                        float s0 = 0, s1 = 0, s2 = 0;
+                        const int wbase = -wy0 * wpitch - 4 * wx0;
+                        for (int j = yb; j < ye; ++j) {
+                            const AreaTap tyv = taps[ag.ytap_ofs + j];
+                            const int X0 = s_x0[tyv.si - sy_lo], Y0 = s_y0[tyv.si - sy_lo];
+                            float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+                            for (int k = 0; k < XB; ++k) {
+                                const int X = (int)((uint32_t)X0 + (uint32_t)adk[k]) >> AB_BITS;
+                                const int Y = (int)((uint32_t)Y0 + (uint32_t)bdk[k]) >> AB_BITS;
+                                // (saturate_cast<short> of imgwarp.cpp cannot change the in-frame test for frames < 32768 px)
+                                const bool inb = (unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh;
+                                const int ofs = inb ? (int)__mul24(Y, wpitch) + 4 * X + wbase : RP_WIN_BYTES;
+                                const uint32_t px = *reinterpret_cast<const uint32_t*>(win + ofs);
+                                b0 = b0 + (float)(px & 255u) * al[k]; b1 = b1 + (float)((px >> 8) & 255u) * al[k]; b2 = b2 + (float)((px >> 16) & 255u) * al[k];
+                            }
+                            if (j == yb) { s0 = tyv.alpha * b0; s1 = tyv.alpha * b1; s2 = tyv.alpha * b2; }
+                            else { s0 += tyv.alpha * b0; s1 += tyv.alpha * b1; s2 += tyv.alpha * b2; }
+                        }
+                        o[0] = sat_u8_f(s0); o[1] = sat_u8_f(s1); o[2] = sat_u8_f(s2);
+                    };
+                    if (ag.max_xtaps <= 6) run(std::integral_constant<int, 6>{}); else run(std::integral_constant<int, 8>{});
+                } else {
+                    area_pixel_simple(ag, taps, idx, dx, dy, [&](int x, int y, uint8_t* p) {
+                        const int adelta = sat_int_d(M[0] * x * AB_SCALE), bdelta = sat_int_d(M[3] * x * AB_SCALE);
+                        const int X0 = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+                        const int Y0 = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+                        int X = (int)((uint32_t)X0 + (uint32_t)adelta) >> AB_BITS;
+                        int Y = (int)((uint32_t)Y0 + (uint32_t)bdelta) >> AB_BITS;
+                        X = X < -32768 ? -32768 : (X > 32767 ? 32767 : X);
+                        Y = Y < -32768 ? -32768 : (Y > 32767 ? 32767 : Y);
+                        if ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) {
+                            const uint8_t* sp = frame + (int64_t)Y * stride + 3 * X;
+                            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+                        } else { p[0] = p[1] = p[2] = 0; }
+                    }, o);
+                }
+                const uint8_t* ref = page_small + pd.small_ofs + ((int64_t)dy * ag.dw + dx) * 3;
+                int d0 = (int)o[0] - ref[0], d1 = (int)o[1] - ref[1], d2 = (int)o[2] - ref[2];
+                acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&fcs[f].ssd[pd.s], red[0] + red[1] + red[2] + red[3]);
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&fc.ssd[s], red[0] + red[1] + red[2] + red[3]);
 }
 
 // compute_similarity (image_utils.rs:22-27): 1 - (f32)sqrt(ssd) / sqrt(255*255*3 * p) (f32)
