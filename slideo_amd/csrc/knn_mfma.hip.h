@@ -41,7 +41,7 @@ typedef float knn_v16f __attribute__((ext_vector_type(16)));
 constexpr int KM_WAVES = 8;                    // waves per block
 constexpr int KM_THREADS = KM_WAVES * 64;
 constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-query B tiles per wave)
-constexpr int KM_ST_ROWS = 128;                // rows per super-tile
+constexpr int KM_ST_ROWS = 128;                // rows per super-tile (one block barrier per super-tile)
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
 constexpr int KM_STAGE = KM_ST_U4 / KM_THREADS;  // uint4 staged per thread and super-tile
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
         }
         const uint4* L = lds[cur];
 #pragma unroll 1
-        for (int tile = 0; tile < 4; ++tile) {
+        for (int tile = 0; tile < KM_ST_ROWS / 32; ++tile) {
             knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
