@@ -152,6 +152,18 @@ int32_t     slideo_match_frames_bgr8_dev(slideo_matcher* m, int32_t n_frames,
                                          int32_t stride_bytes, int64_t frame_stride_bytes,
                                          slideo_verdict* verdicts_out, void* hip_stream);
 
+/* Streaming form of the same call for callers that keep the GPU fed: submit a unit of frames (device
+ * memory, must stay valid until collected), later collect its verdicts.  At most two units are in
+ * flight; they run on two internal streams so that the ORB stage of one unit overlaps the matrix-core
+ * bound kNN of the previous one (the reference gets the same effect from rayon's work stealing,
+ * mo/lib.rs:174,213).  Tickets must be collected in submission order.  The synchronous entry points
+ * above use the same machinery on two halves of their batch. */
+int32_t     slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames,
+                                           const uint8_t* frames_dev, int32_t width, int32_t height,
+                                           int32_t stride_bytes, int64_t frame_stride_bytes,
+                                           void* hip_stream, int64_t* ticket_out);
+int32_t     slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out);
+
 /* Replaces MarkSimilarIter (mo/video_capture.rs:86-98) for a run of sampled
  * frames in host memory: changed[i] = 1 iff similarity(small(frame i-1),
  * small(frame i)) < cfg.changed_similarity; the first frame compares against

@@ -46,6 +46,7 @@ EXPORTS = [
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine",
+    "slideo_match_frames_submit_dev", "slideo_match_frames_collect",
 ]
 
 _lib = None
@@ -186,6 +187,21 @@ class Matcher:
         self._check(lib().slideo_match_frames_bgr8_dev(self._h, n, C.c_void_p(dev_ptr), w, h, stride,
                                                        C.c_int64(frame_stride), _p(out),
                                                        C.c_void_p(stream)))
+        return out
+
+    def submit_dev(self, dev_ptr, n, w, h, stride=None, frame_stride=None, stream=0):
+        """Streaming form: returns a ticket; at most two units in flight; collect in order."""
+        stride = stride or w * 3
+        frame_stride = frame_stride or stride * h
+        t = C.c_int64()
+        self._check(lib().slideo_match_frames_submit_dev(self._h, n, C.c_void_p(dev_ptr), w, h, stride,
+                                                         C.c_int64(frame_stride), C.c_void_p(stream), C.byref(t)))
+        return (t.value, n)
+
+    def collect(self, ticket):
+        t, n = ticket
+        out = np.zeros(n, VERDICT_DTYPE)
+        self._check(lib().slideo_match_frames_collect(self._h, C.c_int64(t), _p(out)))
         return out
 
     def last_candidates(self, frame_in_batch):

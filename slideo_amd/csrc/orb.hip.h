@@ -148,14 +148,19 @@ __device__ __forceinline__ int level_of_tile(const PyrGeom& g, int tile, bool bl
     return l;
 }
 
-constexpr int FAST_RW = FAST_TW + 16, FAST_RH = FAST_TH + 8;  // raw tile (halo 4, + up to 3 bytes of dword alignment slack)
+// Tile = FAST_TW x FAST_TH outputs; scores are needed on a 1-px halo (FAST_SW x FAST_SH, FAST_SW = 128 so that a
+// score row is exactly two wave-widths) and raw pixels on a 4-px halo, fetched as aligned dwords.
 constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (halo 1)
+constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;  // raw tile: halo 4 + up to 3 bytes alignment slack, rounded to a multiple of 4
+static_assert(FAST_SW == 128 && FAST_RW % 4 == 0, "fast_kernel maps one score row onto two wave-widths");
+
+__device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsigned)(a - v + t) > (unsigned)(2 * t); }   // |a - v| > t
 
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
-    __shared__ uint8_t sc[FAST_SH][FAST_SW + 2];
+    __shared__ uint8_t sc[FAST_SH][FAST_SW];
     __shared__ uint16_t queue[FAST_SW * FAST_SH];
     __shared__ uint32_t qn;
     const int f = blockIdx.y;
@@ -166,11 +171,13 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH;
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
     const int t = g.fast_thr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // raw tile: rows y0-4 .. y0+TH+3, columns from the dword-aligned xa <= x0-4; aligned dword loads
     const int xa = (x0 - 4) & ~3, xoff = (x0 - 4) - xa;          // xoff in 0..3
     {
-        const int ndw = FAST_RW / 4, maxd = (L.pitch >> 2) - 1;
+        constexpr int ndw = FAST_RW / 4;
+        const int maxd = (L.pitch >> 2) - 1;
         for (int i = threadIdx.x; i < ndw * FAST_RH; i += 256) {
             int ry = i / ndw, rd = i - ry * ndw;
             int gy = min(max(y0 - 4 + ry, 0), L.h - 1);
@@ -178,28 +185,30 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
             reinterpret_cast<uint32_t*>(&raw[ry][0])[rd] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
         }
     }
-    __syncthreads();
-    // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy).  Every arc of 9 contains one pixel of
-    // each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out; the
-    // four pairs tested here (axes + diagonals) leave only corner-like pixels.  Survivors are queued so that the
-    // full segment test and the score run densely on them instead of dragging whole waves along.
-    // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < FAST_SW * FAST_SH; i += 256) {
-        int sy = i / FAST_SW, sx = i - sy * FAST_SW;
-        int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        sc[sy][sx] = 0;
-        if (gx <= L.rx1 && gy <= L.ry1) {
-            const int cx = sx + 3 + xoff, cy = sy + 3;   // raw coords
-            const int v = raw[cy][cx];
-            const int a0 = raw[cy + 3][cx], a8 = raw[cy - 3][cx], a4 = raw[cy][cx + 3], a12 = raw[cy][cx - 3];
-            bool maybe = (abs(a0 - v) > t || abs(a8 - v) > t) && (abs(a4 - v) > t || abs(a12 - v) > t);
-            if (maybe) {
-                const int a2 = raw[cy + 2][cx + 2], a10 = raw[cy - 2][cx - 2], a6 = raw[cy - 2][cx + 2], a14 = raw[cy + 2][cx - 2];
-                maybe = (abs(a2 - v) > t || abs(a10 - v) > t) && (abs(a6 - v) > t || abs(a14 - v) > t);
+    // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...,
+    // lane covers sx = lane and lane + 64 (no divisions, constant LDS offsets).  Every arc of 9 contains one pixel of
+    // each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out; the four
+    // pairs tested (axes, then diagonals) leave only corner-like pixels, which are queued for the full test.
+    // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
+    for (int sy = wave; sy < FAST_SH; sy += 4) {
+        const int gy = y0 - 1 + sy;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const int sx = lane + 64 * hx;
+            const int gx = x0 - 1 + sx;
+            sc[sy][sx] = 0;
+            if (gx <= L.rx1 && gy <= L.ry1) {
+                const uint8_t* c = &raw[sy + 3][sx + 3 + xoff];
+                const int v = c[0];
+                bool maybe = (fast_differs(c[3 * FAST_RW], v, t) || fast_differs(c[-3 * FAST_RW], v, t)) &&
+                             (fast_differs(c[3], v, t) || fast_differs(c[-3], v, t));
+                if (maybe)
+                    maybe = (fast_differs(c[2 * FAST_RW + 2], v, t) || fast_differs(c[-2 * FAST_RW - 2], v, t)) &&
+                            (fast_differs(c[-2 * FAST_RW + 2], v, t) || fast_differs(c[2 * FAST_RW - 2], v, t));
+                if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + sx);
             }
-            if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)i;
         }
     }
     __syncthreads();
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const uint32_t nqueued = qn;
     for (uint32_t kq = threadIdx.x; kq < nqueued; kq += 256) {
         const int i = queue[kq];
-        const int sy = i / FAST_SW, sx = i - sy * FAST_SW;
+        const int sy = i >> 7, sx = i & 127;
         int score = 0;
         {
             const int cx = sx + 3 + xoff, cy = sy + 3;   // raw coords
@@ -250,29 +259,33 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         sc[sy][sx] = (uint8_t)score;
     }
     __syncthreads();
-    // NMS (strictly greater than all 8 neighbours) + emit
-    const int lane = threadIdx.x & 63;
+    // NMS (strictly greater than all 8 neighbours) + emit; wave w takes output rows w, w+4, ...
     uint32_t* ccount = cand_count + (size_t)f * g.nlevels + l;
     uint32_t* clist = cand + (size_t)f * g.cand_per_frame + L.cand_ofs;
     uint32_t* h = hist + ((size_t)f * g.nlevels + l) * 256;
-    for (int i = threadIdx.x; i < FAST_TW * FAST_TH; i += 256) {
-        int py = i / FAST_TW, px = i - py * FAST_TW;
-        int gx = x0 + px, gy = y0 + py;
-        int s = sc[py + 1][px + 1];
-        bool keep = s > 0 && gx < L.rx1 && gy < L.ry1 &&
-                    s > sc[py][px] && s > sc[py][px + 1] && s > sc[py][px + 2] &&
-                    s > sc[py + 1][px] && s > sc[py + 1][px + 2] &&
-                    s > sc[py + 2][px] && s > sc[py + 2][px + 1] && s > sc[py + 2][px + 2];
-        uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(m));
-            base = __shfl(base, 0);
-            if (keep) {
-                uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < (uint32_t)L.cand_cap)
-                    clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-                atomicAdd(h + s, 1u);
+    for (int py = wave; py < FAST_TH; py += 4) {
+        const int gy = y0 + py;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const int px = lane + 64 * hx;
+            const int gx = x0 + px;
+            const uint8_t* c = &sc[py + 1][min(px, FAST_TW - 1) + 1];
+            const int s = c[0];
+            int m = max(max((int)c[-FAST_SW - 1], (int)c[-FAST_SW]), (int)c[-FAST_SW + 1]);
+            m = max(max(m, (int)c[-1]), (int)c[1]);
+            m = max(max(m, (int)c[FAST_SW - 1]), max((int)c[FAST_SW], (int)c[FAST_SW + 1]));
+            const bool keep = px < FAST_TW && s > m && gx < L.rx1 && gy < L.ry1;     // s > m >= 0 implies s > 0
+            const uint64_t msk = __builtin_amdgcn_ballot_w64(keep);
+            if (msk) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(msk));
+                base = __shfl(base, 0);
+                if (keep) {
+                    uint32_t pos = base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull));
+                    if (pos < (uint32_t)L.cand_cap)
+                        clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+                    atomicAdd(h + s, 1u);
+                }
             }
         }
     }

@@ -40,10 +40,27 @@ struct HostPage {
     std::vector<uint8_t> small_img;
 };
 
-struct OrbOut {            // where the last run_orb left its results (device)
+struct OrbOut {            // where the last ORB run of a slot left its results (device)
     uint32_t qtot = 0, max_count = 0;
     int nframes = 0;
     std::vector<uint32_t> qofs;   // host copy, nframes+1
+};
+
+// One workspace + stream.  Two slots let the ORB stage of one unit of frames run concurrently with the
+// kNN / verification stages of the previous unit (matrix-core bound vs VALU/LDS/HBM bound work).
+struct Slot {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr;
+    DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs;
+    PinBuf h_info, h_out;
+    OrbOut orb;
+    // unit in flight
+    bool busy = false;
+    int64_t ticket = 0;
+    int n = 0;
+    bool timed = false;
 };
 
 }  // namespace
@@ -51,7 +68,7 @@ struct OrbOut {            // where the last run_orb left its results (device)
 struct slideo_matcher {
     slideo_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // = slots[0].st (setup, page ingest, taps)
     std::string err;
     slideo_progress_fn progress = nullptr;
     void* progress_user = nullptr;
@@ -74,23 +91,20 @@ struct slideo_matcher {
     DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
     int knn_engine = 0;     // 0 = FP4 MFMA (default), 1 = integer VALU popcount
 
-    // workspace
-    DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_prev_small, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
-    DevBuf d_items, d_kp, d_desc, d_keys, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_small, d_ssd;
-    DevBuf d_tapq, d_tapt, d_tapidx, d_tapdist, d_knn_pend, d_pairs;
-    PinBuf h_info, h_verdicts;
-    OrbOut orb;
+    // workspaces
+    Slot slots[2];
+    int next_slot = 0;
+    int64_t next_ticket = 1;
+    DevBuf d_small, d_ssd, d_prev_small, d_tapq, d_tapt, d_tapidx, d_tapdist;
 
-    // stage profiling (HIP events on the launch stream)
+    // stage profiling (HIP events on the launch streams)
     bool profiling = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[SLIDEO_N_STAGES] = {0, 0, 0, 0};
     int64_t prof_n[SLIDEO_N_STAGES] = {0, 0, 0, 0};
     int64_t prof_pairs = 0;
 
     // trace of the last match call
     std::vector<FrameCands> last_fcs;
-    std::vector<slideo_verdict> last_verdicts;
 };
 
 namespace {
@@ -152,99 +166,122 @@ void upload_area(slideo_matcher* m) {
     m->area_dirty = false;
 }
 
-// max frames of size (w,h) per sub-batch under the workspace budget
+// max frames of size (w,h) per unit under the workspace budget (two slots share it)
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
     size_t per = (size_t)g.frame_bytes * 2 + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
-    size_t fit = std::max<size_t>(1, m->ws_budget / std::max<size_t>(per, 1));
-    return (int)std::min<size_t>({(size_t)n, fit, (size_t)4096});
+    size_t fit = std::max<size_t>(1, (m->ws_budget / 2) / std::max<size_t>(per, 1));
+    return (int)std::min<size_t>({(size_t)std::max(n, 1), fit, (size_t)4096});
 }
 
-// ---- ORB over `n` equally sized frames already on the device -------------------
-// Leaves: d_qofs[n+1], d_kp[qtot], d_desc[qtot*32]; m->orb filled.  `blurred_needed` always true.
-void run_orb(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
-             hipStream_t st, bool keep_host_qofs) {
+void require_idle(slideo_matcher* m) {
+    if (m->slots[0].busy || m->slots[1].busy) fail(SLIDEO_ERR_STATE, "a submitted unit has not been collected yet");
+}
+
+// ---- ORB over `n` equally sized frames already on the device, in three steps -------------
+// stage 1: gray, pyramid, FAST+NMS, blur, retainBest thresholds, per-frame offsets; copies {Qtot, max, flags} to pinned memory
+void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
+    hipStream_t st = S.st;
     GeomEntry& ge = geom_for(m, w, h);
     const PyrGeom& g = ge.g;
     const int L = g.nlevels;
-    m->d_pyr.reserve((size_t)g.frame_bytes * n);
-    m->d_blur.reserve((size_t)g.frame_bytes * n);
-    m->d_cand.reserve(std::max<size_t>((size_t)g.cand_per_frame * n * 4, 16));
+    S.d_pyr.reserve((size_t)g.frame_bytes * n);
+    S.d_blur.reserve((size_t)g.frame_bytes * n);
+    S.d_cand.reserve(std::max<size_t>((size_t)g.cand_per_frame * n * 4, 16));
     const size_t n_cc = (size_t)n * L;
-    m->d_hist.reserve(n_cc * 256 * 4);
-    m->d_candcount.reserve(n_cc * 2 * 4);
-    m->d_flags.reserve(16);
-    uint32_t* hist = m->d_hist.as<uint32_t>();
-    uint32_t* cand_count = m->d_candcount.as<uint32_t>();
-    uint32_t* cursor = cand_count + n_cc;
-    uint32_t* flags = m->d_flags.as<uint32_t>();
+    S.d_hist.reserve(n_cc * 256 * 4);
+    S.d_candcount.reserve(n_cc * 2 * 4);
+    S.d_flags.reserve(16);
+    uint32_t* hist = S.d_hist.as<uint32_t>();
+    uint32_t* cand_count = S.d_candcount.as<uint32_t>();
+    uint32_t* flags = S.d_flags.as<uint32_t>();
     HIP_CHECK(hipMemsetAsync(hist, 0, n_cc * 256 * 4, st));
     HIP_CHECK(hipMemsetAsync(cand_count, 0, n_cc * 2 * 4, st));
     HIP_CHECK(hipMemsetAsync(flags, 0, 16, st));
-    m->d_thr.reserve(n_cc * 4); m->d_lvlofs.reserve(n_cc * 4); m->d_kpcount.reserve((size_t)n * 4);
-    m->d_qofs.reserve((size_t)(n + 1) * 4); m->d_info.reserve(64);
-    m->h_info.reserve(64);
+    S.d_thr.reserve(n_cc * 4); S.d_lvlofs.reserve(n_cc * 4); S.d_kpcount.reserve((size_t)n * 4);
+    S.d_qofs.reserve((size_t)(n + 1) * 4); S.d_info.reserve(64);
+    S.h_info.reserve(64);
 
     const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
     {
         dim3 grid(cdiv(cdiv(w, 4), 256), h, n);
-        gray_kernel<<<grid, 256, 0, st>>>(frames_dev, frame_stride, stride, m->d_pyr.as<uint8_t>(), g.frame_bytes, w, h,
+        gray_kernel<<<grid, 256, 0, st>>>(frames_dev, frame_stride, stride, S.d_pyr.as<uint8_t>(), g.frame_bytes, w, h,
                                           g.lv[0].pitch, aligned4);
         check_launch("gray_kernel");
     }
     for (int l = 1; l < L; ++l) {
         if (g.lv[l].w <= 0 || g.lv[l].h <= 0) continue;
         dim3 grid(cdiv(cdiv(g.lv[l].w, 4), 256), g.lv[l].h, n);
-        resize_kernel<<<grid, 256, 0, st>>>(m->d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>());
+        resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>());
         check_launch("resize_kernel");
     }
     if (g.fast_tiles > 0) {
-        fast_kernel<<<dim3(g.fast_tiles, n), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_cand.as<uint32_t>(), cand_count, hist);
+        fast_kernel<<<dim3(g.fast_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
         check_launch("fast_kernel");
     }
     if (g.blur_tiles > 0) {
-        blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+        blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
         check_launch("blur_kernel");
     }
-    threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, m->d_thr.as<uint32_t>(), m->d_lvlofs.as<uint32_t>(),
-                                           m->d_kpcount.as<uint32_t>(), flags);
+    threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, S.d_thr.as<uint32_t>(), S.d_lvlofs.as<uint32_t>(),
+                                           S.d_kpcount.as<uint32_t>(), flags);
     check_launch("threshold_kernel");
-    scan_kernel<<<1, 1024, 0, st>>>(m->d_kpcount.as<uint32_t>(), n, m->d_qofs.as<uint32_t>(), m->d_info.as<uint32_t>());
+    scan_kernel<<<1, 1024, 0, st>>>(S.d_kpcount.as<uint32_t>(), n, S.d_qofs.as<uint32_t>(), S.d_info.as<uint32_t>());
     check_launch("scan_kernel");
-    HIP_CHECK(hipMemcpyAsync(m->h_info.p, m->d_info.p, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(m->h_info.as<uint32_t>() + 2, flags, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    const uint32_t qtot = m->h_info.as<uint32_t>()[0], maxc = m->h_info.as<uint32_t>()[1], fl = m->h_info.as<uint32_t>()[2];
+    HIP_CHECK(hipMemcpyAsync(S.h_info.p, S.d_info.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(S.h_info.as<uint32_t>() + 2, flags, 4, hipMemcpyDeviceToHost, st));
+    S.orb.nframes = n;
+}
+
+// the one mid-pipeline host sync: 12 bytes that size everything downstream
+void orb_wait_info(slideo_matcher* m, Slot& S) {
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    const uint32_t qtot = S.h_info.as<uint32_t>()[0], maxc = S.h_info.as<uint32_t>()[1], fl = S.h_info.as<uint32_t>()[2];
     if (fl & 1u) fail(SLIDEO_ERR_HIP, "internal: FAST candidate list overflow");
     if (fl & 2u)
         fail(SLIDEO_ERR_CAPACITY, "a frame produced %u keypoints (ties at the retainBest threshold are kept, as in OpenCV); the in-LDS canonical sort holds %d",
              maxc, KP_CAP_PER_FRAME);
-    m->orb.qtot = qtot; m->orb.max_count = maxc; m->orb.nframes = n;
-    m->d_items.reserve(std::max<size_t>((size_t)qtot * 8, 16));
-    m->d_kp.reserve(std::max<size_t>((size_t)qtot * sizeof(slideo_keypoint), 16));
-    m->d_desc.reserve(std::max<size_t>((size_t)qtot * 32, 32));
-    if (qtot > 0) {
-        compact_kernel<<<dim3(L, n), 256, 0, st>>>(g, m->d_cand.as<uint32_t>(), cand_count, m->d_thr.as<uint32_t>(),
-                                                   m->d_lvlofs.as<uint32_t>(), m->d_qofs.as<uint32_t>(), cursor,
-                                                   m->d_items.as<uint64_t>());
-        check_launch("compact_kernel");
-        int np2 = 2;
-        while ((uint32_t)np2 < maxc) np2 <<= 1;
-        sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(m->d_qofs.as<uint32_t>(), m->d_items.as<uint64_t>(), np2);
-        check_launch("sort_kernel");
-        describe_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, m->d_pyr.as<uint8_t>(), m->d_blur.as<uint8_t>(),
-                                                            m->d_tables.as<OrbTables>(), m->d_qofs.as<uint32_t>(), n,
-                                                            m->d_items.as<uint64_t>(), qtot, m->d_kp.as<slideo_keypoint>(),
-                                                            m->d_desc.as<uint8_t>());
-        check_launch("describe_kernel");
-    }
+    S.orb.qtot = qtot; S.orb.max_count = maxc;
+}
+
+// stage 2: compact the kept candidates, canonical sort, IC angle + rotated BRIEF
+void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
+    hipStream_t st = S.st;
+    const PyrGeom& g = geom_for(m, w, h).g;
+    const int L = g.nlevels, n = S.orb.nframes;
+    const uint32_t qtot = S.orb.qtot, maxc = S.orb.max_count;
+    S.d_items.reserve(std::max<size_t>((size_t)qtot * 8, 16));
+    S.d_kp.reserve(std::max<size_t>((size_t)qtot * sizeof(slideo_keypoint), 16));
+    S.d_desc.reserve(std::max<size_t>((size_t)qtot * 32, 32));
+    if (qtot == 0) return;
+    uint32_t* cand_count = S.d_candcount.as<uint32_t>();
+    uint32_t* cursor = cand_count + (size_t)n * L;
+    compact_kernel<<<dim3(L, n), 256, 0, st>>>(g, S.d_cand.as<uint32_t>(), cand_count, S.d_thr.as<uint32_t>(),
+                                               S.d_lvlofs.as<uint32_t>(), S.d_qofs.as<uint32_t>(), cursor, S.d_items.as<uint64_t>());
+    check_launch("compact_kernel");
+    int np2 = 2;
+    while ((uint32_t)np2 < maxc) np2 <<= 1;
+    sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(S.d_qofs.as<uint32_t>(), S.d_items.as<uint64_t>(), np2);
+    check_launch("sort_kernel");
+    describe_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
+                                                        S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot,
+                                                        S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>());
+    check_launch("describe_kernel");
+}
+
+// synchronous ORB (page ingest, taps).  Leaves: d_qofs[n+1], d_kp[qtot], d_desc[qtot*32]; S.orb filled.
+void run_orb(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+             bool keep_host_qofs) {
+    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride);
+    orb_wait_info(m, S);
+    orb_stage2(m, S, w, h);
     if (keep_host_qofs) {
-        m->orb.qofs.resize(n + 1);
-        HIP_CHECK(hipMemcpyAsync(m->orb.qofs.data(), m->d_qofs.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        S.orb.qofs.resize(n + 1);
+        HIP_CHECK(hipMemcpyAsync(S.orb.qofs.data(), S.d_qofs.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, S.st));
+        HIP_CHECK(hipStreamSynchronize(S.st));
     }
 }
 
-// ---- exact Hamming kNN: keys into d_keys[0 .. nq*KLIST) -------------------------------
+// ---- exact Hamming kNN: keys into S.d_keys[0 .. nq*KLIST) ------------------------------
 int knn_pad_rows(int nt) { return cdiv(std::max(nt, 1), KM_ST_ROWS) * KM_ST_ROWS; }
 
 // FP4 tile-major expansion of a packed train matrix (knn_mfma.hip.h)
@@ -255,42 +292,60 @@ void expand_train(const uint32_t* t_dev, int nt, DevBuf& out, hipStream_t st) {
     check_launch("knn_expand_train_kernel");
 }
 
-// t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
-void run_knn(slideo_matcher* m, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt, hipStream_t st) {
-    if (nq <= 0) return;
-    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+struct KnnPlan { int qblocks, nseg, per_seg; };
+KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
+    KnnPlan p{};
+    nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
     if (m->knn_engine == 0 && nt > 0) {
-        const int qblocks = cdiv(nq, KM_QPB);
+        p.qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
-        int nseg = qblocks >= 384 ? 1 : std::min(cdiv(512, qblocks), n_st);
-        const int st_per_seg = cdiv(n_st, std::max(nseg, 1));
-        nseg = cdiv(n_st, st_per_seg);
-        m->d_keys.reserve((size_t)nseg * nq * KLIST * 4);
-        m->d_knn_pend.reserve((size_t)qblocks * nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
-        knn_mfma_kernel<<<dim3(qblocks, nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), st_per_seg, m->d_keys.as<uint32_t>(),
-                                                                    m->d_knn_pend.as<uint32_t>());
+        // >= 1 block per 2 CUs already fills half of the matrix pipes and keeps the insert warm-up to one pass;
+        // fewer query blocks split the train set (each segment pays its own warm-up) to fill the chip
+        int nseg = p.qblocks >= 128 ? 1 : std::min(cdiv(512, p.qblocks), n_st);
+        p.per_seg = cdiv(n_st, std::max(nseg, 1));
+        p.nseg = cdiv(n_st, p.per_seg);
+    } else {
+        p.qblocks = cdiv(nq, KNN_BLOCK);
+        int nseg = 1;
+        if (p.qblocks < 1024) nseg = std::min(cdiv(1024, p.qblocks), std::max(1, nt / 4096));
+        p.nseg = std::max(1, std::min(nseg, 256));
+        p.per_seg = cdiv(std::max(nt, 1), p.nseg);
+    }
+    return p;
+}
+
+void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt) {
+    const KnnPlan p = knn_plan(m, nq, nt);
+    S.d_keys.reserve((size_t)p.nseg * std::max(nq, 1) * KLIST * 4);
+    if (m->knn_engine == 0) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
+}
+
+// t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
+void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt) {
+    if (nq <= 0) return;
+    hipStream_t st = S.st;
+    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    const KnnPlan p = knn_plan(m, nq, nt);
+    knn_reserve(m, S, nq, nt);
+    if (m->knn_engine == 0 && nt > 0) {
+        knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
+                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>());
         check_launch("knn_mfma_kernel");
-        if (nseg > 1) {
-            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg);
+        if (p.nseg > 1) {
+            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
             check_launch("knn_merge_kernel");
         }
         return;
     }
-    const int qblocks = cdiv(nq, KNN_BLOCK);
-    int nseg = 1;
-    if (qblocks < 1024) nseg = std::min(cdiv(1024, qblocks), std::max(1, nt / 4096));
-    nseg = std::max(1, std::min(nseg, 256));
-    const int seg_len = cdiv(std::max(nt, 1), nseg);
-    m->d_keys.reserve((size_t)nseg * nq * KLIST * 4);
-    knn_hamming_kernel<KLIST><<<dim3(qblocks, nseg), KNN_BLOCK, 0, st>>>(q_dev, nq, t_dev, nt, seg_len, m->d_keys.as<uint32_t>());
+    knn_hamming_kernel<KLIST><<<dim3(p.qblocks, p.nseg), KNN_BLOCK, 0, st>>>(q_dev, nq, t_dev, nt, p.per_seg, S.d_keys.as<uint32_t>());
     check_launch("knn_hamming_kernel");
-    if (nseg > 1) {
-        knn_merge_kernel<KLIST><<<qblocks, KNN_BLOCK, 0, st>>>(m->d_keys.as<uint32_t>(), nq, nseg);
+    if (p.nseg > 1) {
+        knn_merge_kernel<KLIST><<<p.qblocks, KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
         check_launch("knn_merge_kernel");
     }
 }
 
-// ---- to_small_image of n equally sized device images into d_small ----------------------
+// ---- to_small_image of n equally sized device images into m->d_small --------------------
 void run_small(slideo_matcher* m, const uint8_t* imgs_dev, int n, int w, int h, int stride, int64_t img_stride,
                int& sw, int& sh, hipStream_t st) {
     int ac = area_class_for(m, w, h);
@@ -304,15 +359,15 @@ void run_small(slideo_matcher* m, const uint8_t* imgs_dev, int n, int w, int h, 
     check_launch("small_image_kernel");
 }
 
-void upload_frames(slideo_matcher* m, const uint8_t* host, int n, int h, int stride, int64_t frame_stride, hipStream_t st) {
-    // copies n frames so that the device layout keeps (stride, frame_stride') with frame_stride' = h*stride
+// copies n host frames into S.d_stage with frame stride h*stride
+void upload_frames(Slot& S, const uint8_t* host, int n, int h, int stride, int64_t frame_stride) {
     const size_t fb = (size_t)h * stride;
-    m->d_stage.reserve(fb * n + 16);
+    S.d_stage.reserve(fb * n + 16);
     if ((size_t)frame_stride == fb) {
-        HIP_CHECK(hipMemcpyAsync(m->d_stage.p, host, fb * n, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(S.d_stage.p, host, fb * n, hipMemcpyHostToDevice, S.st));
     } else {
         for (int i = 0; i < n; ++i)
-            HIP_CHECK(hipMemcpyAsync(m->d_stage.as<uint8_t>() + fb * i, host + (size_t)frame_stride * i, fb, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(S.d_stage.as<uint8_t>() + fb * i, host + (size_t)frame_stride * i, fb, hipMemcpyHostToDevice, S.st));
     }
 }
 
@@ -320,109 +375,153 @@ void validate_image(int w, int h, int stride) {
     if (w < 1 || h < 1 || stride < w * 3) fail(SLIDEO_ERR_INVALID_ARG, "bad image geometry w=%d h=%d stride=%d", w, h, stride);
 }
 
-// ---- the per-frame hot path over one sub-batch of device frames ------------------------
-void match_sub_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
-                     slideo_verdict* out_host, hipStream_t st) {
+// ---- one unit of the per-frame hot path: enqueue everything, then collect ---------------
+// `frames_dev` must stay valid until the unit is collected (reproject reads the frames).
+void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
     const slideo_config& c = m->cfg;
+    hipStream_t st = S.st;
     const bool prof = m->profiling;
-    if (prof) HIP_CHECK(hipEventRecord(m->ev[0], st));
-    run_orb(m, frames_dev, n, w, h, stride, frame_stride, st, false);
-    if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));
-    const uint32_t qtot = m->orb.qtot;
+    S.timed = prof;
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
+    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride);
+    orb_wait_info(m, S);                  // the other slot's kNN / verify keep the GPU busy meanwhile
+    const uint32_t qtot = S.orb.qtot;
+    // all workspace before the timed kNN interval
+    knn_reserve(m, S, (int)qtot, (int)m->M);
+    S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
+    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
+    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * c.knn_k, 16));
+    S.d_fcs.reserve((size_t)n * sizeof(FrameCands));
+    S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
+    S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
+    S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
+    orb_stage2(m, S, w, h);
     const VerifyParams vp = make_vp(c);
     const int P = (int)m->pages.size();
-    m->d_fcs.reserve((size_t)n * sizeof(FrameCands));
-    m->d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
-    HIP_CHECK(hipMemsetAsync(m->d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
-    uint32_t* flags = m->d_flags.as<uint32_t>();   // zeroed by run_orb
+    HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
+    uint32_t* flags = S.d_flags.as<uint32_t>();   // zeroed by orb_stage1
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
-        // workspace first, so that no allocation sits inside the timed kNN interval
-        m->d_keys.reserve((size_t)qtot * KLIST * 4 * 2);
-        m->d_knn_pend.reserve((size_t)cdiv((int)qtot, KM_QPB) * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
-        m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
-        if (prof) HIP_CHECK(hipEventRecord(m->ev[1], st));   // re-recorded after the (possible) allocations
-        run_knn(m, m->d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, st);
-        if (prof) HIP_CHECK(hipEventRecord(m->ev[2], st));
-        m->d_votes.reserve((size_t)qtot * c.knn_k * sizeof(uint2));
-        m->d_gpts.reserve((size_t)qtot * c.knn_k * sizeof(float4));
-        m->d_gmask.reserve((size_t)qtot * c.knn_k);
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M);
+        if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
-        vote_kernel<<<n, 256, lds, st>>>(vp, m->d_keys.as<uint32_t>(), m->d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
-                                         m->d_fcs.as<FrameCands>(), m->d_votes.as<uint2>());
+        vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
+                                         S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
         check_launch("vote_kernel");
-        ransac_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(vp, m->d_qofs.as<uint32_t>(), m->d_kp.as<slideo_keypoint>(),
-                                                                     m->d_page_xy.as<float2>(), m->d_votes.as<uint2>(),
-                                                                     m->d_rng.as<uint32_t>(), m->d_fcs.as<FrameCands>(),
-                                                                     m->d_gpts.as<float4>(), m->d_gmask.as<uint8_t>(), flags);
+        ransac_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(),
+                                                                     m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                                                                     m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(),
+                                                                     S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
         check_launch("ransac_kernel");
-        m->d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
-        uint32_t* pair_count = m->d_pairs.as<uint32_t>();
-        PairDesc* pair_list = reinterpret_cast<PairDesc*>(m->d_pairs.as<uint8_t>() + 64);
+        uint32_t* pair_count = S.d_pairs.as<uint32_t>();
+        PairDesc* pair_list = reinterpret_cast<PairDesc*>(S.d_pairs.as<uint8_t>() + 64);
         HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));
-        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
+        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
         check_launch("rate_kernel");
         int max_tile_rows = 0;
         for (const AreaGeom& ag : m->area_geoms) max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));
         reproject_kernel<<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
                                                                                   m->d_area_idx.as<int32_t>(),
                                                                                   m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
-                                                                                  stride, w, h, m->d_fcs.as<FrameCands>(), pair_list, pair_count);
+                                                                                  stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
         check_launch("reproject_kernel");
     }
-    verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, m->d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), m->d_fcs.as<FrameCands>(),
-                                               m->d_verdicts.as<slideo_verdict>());
+    verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), S.d_fcs.as<FrameCands>(),
+                                               S.d_verdicts.as<slideo_verdict>());
     check_launch("verdict_kernel");
-    if (prof) HIP_CHECK(hipEventRecord(m->ev[3], st));
-    m->h_verdicts.reserve((size_t)n * sizeof(slideo_verdict) + 16);
-    HIP_CHECK(hipMemcpyAsync(m->h_verdicts.p, m->d_verdicts.p, (size_t)n * sizeof(slideo_verdict), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), flags, 4, hipMemcpyDeviceToHost, st));
-    const size_t base = m->last_fcs.size();
-    m->last_fcs.resize(base + n);
-    HIP_CHECK(hipMemcpyAsync(m->last_fcs.data() + base, m->d_fcs.p, (size_t)n * sizeof(FrameCands), hipMemcpyDeviceToHost, st));
-    if (prof) HIP_CHECK(hipEventRecord(m->ev[4], st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (prof) {
-        float t;
-        HIP_CHECK(hipEventElapsedTime(&t, m->ev[0], qtot > 0 ? m->ev[1] : m->ev[3])); m->prof_ms[0] += t; m->prof_n[0]++;
-        if (qtot > 0) {
-            HIP_CHECK(hipEventElapsedTime(&t, m->ev[1], m->ev[2])); m->prof_ms[1] += t; m->prof_n[1]++;
-            m->prof_pairs += (int64_t)qtot * m->M;
-            HIP_CHECK(hipEventElapsedTime(&t, m->ev[2], m->ev[3])); m->prof_ms[2] += t; m->prof_n[2]++;
-        }
-        HIP_CHECK(hipEventElapsedTime(&t, m->ev[0], m->ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
-    }
-    uint32_t fl;
-    std::memcpy(&fl, m->h_verdicts.as<uint8_t>() + (size_t)n * sizeof(slideo_verdict), 4);
-    if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
-    std::memcpy(out_host, m->h_verdicts.p, (size_t)n * sizeof(slideo_verdict));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[3], st));
+    uint8_t* ho = S.h_out.as<uint8_t>();
+    HIP_CHECK(hipMemcpyAsync(ho, S.d_verdicts.p, (size_t)n * sizeof(slideo_verdict), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(ho + (size_t)n * sizeof(slideo_verdict), S.d_fcs.p, (size_t)n * sizeof(FrameCands), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(ho + (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)), flags, 4, hipMemcpyDeviceToHost, st));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[4], st));
+    S.busy = true; S.n = n;
 }
 
-void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_device, int w, int h, int stride,
-                       int64_t frame_stride, slideo_verdict* out, hipStream_t st) {
+void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
+    const int n = S.n;
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    S.busy = false;
+    const uint32_t qtot = S.orb.qtot;
+    if (S.timed) {
+        float t;
+        HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[1])); m->prof_ms[0] += t; m->prof_n[0]++;
+        if (qtot > 0) {
+            HIP_CHECK(hipEventElapsedTime(&t, S.ev[1], S.ev[2])); m->prof_ms[1] += t; m->prof_n[1]++;
+            m->prof_pairs += (int64_t)qtot * m->M;
+            HIP_CHECK(hipEventElapsedTime(&t, S.ev[2], S.ev[3])); m->prof_ms[2] += t; m->prof_n[2]++;
+        }
+        HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
+    }
+    const uint8_t* ho = S.h_out.as<uint8_t>();
+    uint32_t fl;
+    std::memcpy(&fl, ho + (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)), 4);
+    if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
+    std::memcpy(out_host, ho, (size_t)n * sizeof(slideo_verdict));
+    const size_t base = m->last_fcs.size();
+    m->last_fcs.resize(base + n);
+    std::memcpy(m->last_fcs.data() + base, ho + (size_t)n * sizeof(slideo_verdict), (size_t)n * sizeof(FrameCands));
+}
+
+void check_match_args(slideo_matcher* m, int n, const void* frames, const void* out, int w, int h, int stride, int64_t frame_stride) {
     if (!m->finalized) fail(SLIDEO_ERR_STATE, "slideo_matcher_finalize_pages must be called before matching");
     if (m->M <= 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
     if (n < 0 || (n > 0 && (!frames || !out))) fail(SLIDEO_ERR_INVALID_ARG, "null frames/verdicts");
     validate_image(w, h, stride);
     if (frame_stride < (int64_t)h * stride) fail(SLIDEO_ERR_INVALID_ARG, "frame_stride smaller than one frame");
+}
+
+// Synchronous matching of n frames: cut into units and run them through the two slots as a pipeline.
+void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_device, int w, int h, int stride,
+                       int64_t frame_stride, slideo_verdict* out, hipStream_t user_stream) {
+    check_match_args(m, n, frames, out, w, h, stride, frame_stride);
     HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
     m->last_fcs.clear();
+    if (n == 0) return;
     GeomEntry& ge = geom_for(m, w, h);
-    area_class_for(m, w, h);   // frames never need a small image here, but keep classes warm for the changed mask
+    area_class_for(m, w, h);
     upload_area(m);
-    const int sub = sub_batch_for(m, ge.g, n);
-    for (int i = 0; i < n; i += sub) {
-        const int cnt = std::min(sub, n - i);
-        const uint8_t* dev;
-        int64_t fs = frame_stride;
-        if (on_device) dev = frames + (int64_t)i * frame_stride;
-        else {
-            upload_frames(m, frames + (int64_t)i * frame_stride, cnt, h, stride, frame_stride, st);
-            dev = m->d_stage.as<uint8_t>(); fs = (int64_t)h * stride;
+    int unit = sub_batch_for(m, ge.g, n);
+    if (n >= 128 && unit >= (n + 1) / 2) unit = (n + 1) / 2;      // two halves overlap ORB with kNN / verify
+    struct Pending { Slot* S; int ofs; };
+    std::vector<Pending> pend;
+    if (on_device && user_stream)
+        for (Slot& S : m->slots) {      // inputs produced on the caller's stream: order our streams behind it
+            HIP_CHECK(hipEventRecord(S.ev_in, user_stream));
+            HIP_CHECK(hipStreamWaitEvent(S.st, S.ev_in, 0));
         }
-        match_sub_batch(m, dev, cnt, w, h, stride, fs, out + i, st);
-        if (m->progress) m->progress(m->progress_user, (uint64_t)(i + cnt), (uint64_t)n, "Processing frames...");
+    int done = 0;
+    try {
+        for (int i = 0; i < n; i += unit) {
+            const int cnt = std::min(unit, n - i);
+            if (pend.size() == 2) {
+                unit_collect(m, *pend[0].S, out + pend[0].ofs);
+                done += pend[0].S->n;
+                pend.erase(pend.begin());
+                if (m->progress) m->progress(m->progress_user, (uint64_t)done, (uint64_t)n, "Processing frames...");
+            }
+            Slot& S = m->slots[m->next_slot];
+            m->next_slot ^= 1;
+            const uint8_t* dev;
+            int64_t fs = frame_stride;
+            if (on_device) dev = frames + (int64_t)i * frame_stride;
+            else {
+                upload_frames(S, frames + (int64_t)i * frame_stride, cnt, h, stride, frame_stride);
+                dev = S.d_stage.as<uint8_t>(); fs = (int64_t)h * stride;
+            }
+            unit_submit(m, S, dev, cnt, w, h, stride, fs);
+            pend.push_back({&S, i});
+        }
+        for (Pending& p : pend) {
+            unit_collect(m, *p.S, out + p.ofs);
+            done += p.S->n;
+            if (m->progress) m->progress(m->progress_user, (uint64_t)done, (uint64_t)n, "Processing frames...");
+        }
+    } catch (...) {
+        for (Slot& S : m->slots) { (void)hipStreamSynchronize(S.st); S.busy = false; }
+        throw;
     }
-    m->last_verdicts.assign(out, out + n);
 }
 
 void set_err(slideo_matcher* m, const char* what) {
@@ -480,7 +579,12 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     std::unique_ptr<slideo_matcher> mm(new slideo_matcher());
     mm->cfg = *cfg; mm->device = device;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
-    HIP_CHECK(hipStreamCreateWithFlags(&mm->stream, hipStreamNonBlocking));
+    for (Slot& S : mm->slots) {
+        HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        for (auto& e : S.ev) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+    }
+    mm->stream = mm->slots[0].st;
     OrbTables t{};
     umax_table(cfg->patch_size / 2, t.umax);
     gauss7_fixed(t.gk);
@@ -501,8 +605,11 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
 void slideo_matcher_destroy(slideo_matcher* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+    for (Slot& S : m->slots) {
+        if (S.st) { (void)hipStreamSynchronize(S.st); (void)hipStreamDestroy(S.st); }
+        for (auto& e : S.ev) if (e) (void)hipEventDestroy(e);
+        if (S.ev_in) (void)hipEventDestroy(S.ev_in);
+    }
     delete m;
 }
 
@@ -516,7 +623,6 @@ int32_t slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
     HIP_CHECK(hipSetDevice(m->device));
-    if (enable && !m->ev[0]) for (auto& e : m->ev) HIP_CHECK(hipEventCreate(&e));
     m->profiling = enable != 0;
     for (int i = 0; i < SLIDEO_N_STAGES; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
     m->prof_pairs = 0;
@@ -544,7 +650,9 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
     if (m->finalized) fail(SLIDEO_ERR_STATE, "pages cannot be added after finalize");
     if (n_pages < 0 || (n_pages > 0 && (!data || !width || !height || !stride_bytes))) fail(SLIDEO_ERR_INVALID_ARG, "null page arrays");
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     const uint64_t total = (uint64_t)n_pages;
     if (m->progress) m->progress(m->progress_user, 0, total, "Analyzing PDF pages...");     // lib.rs:43
     int i = 0;
@@ -557,19 +665,19 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
         int cap = std::min(sub_batch_for(m, ge.g, n_pages - i), 64), cnt = 1;
         while (cnt < cap && width[i + cnt] == w && height[i + cnt] == h && stride_bytes[i + cnt] == stride && data[i + cnt]) ++cnt;
         const size_t fb = (size_t)h * stride;
-        m->d_stage.reserve(fb * cnt + 16);
+        S.d_stage.reserve(fb * cnt + 16);
         for (int j = 0; j < cnt; ++j)
-            HIP_CHECK(hipMemcpyAsync(m->d_stage.as<uint8_t>() + fb * j, data[i + j], fb, hipMemcpyHostToDevice, st));
-        run_orb(m, m->d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, st, true);
-        const uint32_t qtot = m->orb.qtot;
+            HIP_CHECK(hipMemcpyAsync(S.d_stage.as<uint8_t>() + fb * j, data[i + j], fb, hipMemcpyHostToDevice, st));
+        run_orb(m, S, S.d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, true);
+        const uint32_t qtot = S.orb.qtot;
         std::vector<slideo_keypoint> kp(qtot);
         std::vector<uint8_t> desc((size_t)qtot * 32);
         if (qtot) {
-            HIP_CHECK(hipMemcpyAsync(kp.data(), m->d_kp.p, (size_t)qtot * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipMemcpyAsync(desc.data(), m->d_desc.p, (size_t)qtot * 32, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(kp.data(), S.d_kp.p, (size_t)qtot * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(desc.data(), S.d_desc.p, (size_t)qtot * 32, hipMemcpyDeviceToHost, st));
         }
         int sw = 0, sh = 0;
-        run_small(m, m->d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, sw, sh, st);
+        run_small(m, S.d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, sw, sh, st);
         std::vector<uint8_t> smalls((size_t)cnt * sw * sh * 3);
         HIP_CHECK(hipMemcpyAsync(smalls.data(), m->d_small.p, smalls.size(), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -577,7 +685,7 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
         for (int j = 0; j < cnt; ++j) {
             HostPage pg;
             pg.w = w; pg.h = h; pg.sw = sw; pg.sh = sh; pg.area_idx = ac;
-            const uint32_t a = m->orb.qofs[j], b = m->orb.qofs[j + 1];
+            const uint32_t a = S.orb.qofs[j], b = S.orb.qofs[j + 1];
             pg.kp.assign(kp.begin() + a, kp.begin() + b);
             pg.desc.assign(desc.begin() + (size_t)a * 32, desc.begin() + (size_t)b * 32);
             pg.small_img.assign(smalls.begin() + (size_t)j * sw * sh * 3, smalls.begin() + (size_t)(j + 1) * sw * sh * 3);
@@ -660,7 +768,7 @@ int32_t slideo_match_frames_bgr8(slideo_matcher* m, int32_t n_frames, const uint
                                  int32_t stride_bytes, int64_t frame_stride_bytes, slideo_verdict* verdicts_out) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
-    match_frames_impl(m, n_frames, frames, false, width, height, stride_bytes, frame_stride_bytes, verdicts_out, m->stream);
+    match_frames_impl(m, n_frames, frames, false, width, height, stride_bytes, frame_stride_bytes, verdicts_out, nullptr);
     API_CATCH(m)
 }
 
@@ -668,8 +776,49 @@ int32_t slideo_match_frames_bgr8_dev(slideo_matcher* m, int32_t n_frames, const 
                                      int32_t stride_bytes, int64_t frame_stride_bytes, slideo_verdict* verdicts_out, void* hip_stream) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
-    hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->stream;
-    match_frames_impl(m, n_frames, frames_dev, true, width, height, stride_bytes, frame_stride_bytes, verdicts_out, st);
+    match_frames_impl(m, n_frames, frames_dev, true, width, height, stride_bytes, frame_stride_bytes, verdicts_out,
+                      reinterpret_cast<hipStream_t>(hip_stream));
+    API_CATCH(m)
+}
+
+int32_t slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames, const uint8_t* frames_dev, int32_t width, int32_t height,
+                                       int32_t stride_bytes, int64_t frame_stride_bytes, void* hip_stream, int64_t* ticket_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!ticket_out) fail(SLIDEO_ERR_INVALID_ARG, "null ticket_out");
+    check_match_args(m, n_frames, frames_dev, ticket_out, width, height, stride_bytes, frame_stride_bytes);
+    if (n_frames < 1) fail(SLIDEO_ERR_INVALID_ARG, "submit needs at least one frame");
+    HIP_CHECK(hipSetDevice(m->device));
+    Slot& S = m->slots[m->next_slot];
+    if (S.busy) fail(SLIDEO_ERR_STATE, "both slots are in flight: collect ticket %lld first", (long long)S.ticket);
+    GeomEntry& ge = geom_for(m, width, height);
+    if (n_frames > sub_batch_for(m, ge.g, n_frames))
+        fail(SLIDEO_ERR_CAPACITY, "%d frames exceed the per-slot workspace budget (%d); submit smaller units or raise SLIDEO_WS_GB",
+             n_frames, sub_batch_for(m, ge.g, n_frames));
+    area_class_for(m, width, height);
+    upload_area(m);
+    if (!m->slots[0].busy && !m->slots[1].busy) m->last_fcs.clear();
+    if (hip_stream) {
+        HIP_CHECK(hipEventRecord(S.ev_in, reinterpret_cast<hipStream_t>(hip_stream)));
+        HIP_CHECK(hipStreamWaitEvent(S.st, S.ev_in, 0));
+    }
+    unit_submit(m, S, frames_dev, n_frames, width, height, stride_bytes, frame_stride_bytes);
+    S.ticket = m->next_ticket++;
+    *ticket_out = S.ticket;
+    m->next_slot ^= 1;
+    API_CATCH(m)
+}
+
+int32_t slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!verdicts_out) fail(SLIDEO_ERR_INVALID_ARG, "null verdicts_out");
+    HIP_CHECK(hipSetDevice(m->device));
+    Slot* S = nullptr;
+    for (Slot& c : m->slots) if (c.busy && c.ticket == ticket) S = &c;
+    if (!S) fail(SLIDEO_ERR_STATE, "ticket %lld is not in flight", (long long)ticket);
+    for (Slot& c : m->slots) if (c.busy && c.ticket < ticket) fail(SLIDEO_ERR_STATE, "collect ticket %lld first (in order)", (long long)c.ticket);
+    unit_collect(m, *S, verdicts_out);
     API_CATCH(m)
 }
 
@@ -698,12 +847,13 @@ int32_t slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames, const uint
     validate_image(width, height, stride_bytes);
     if (n_frames == 0) return SLIDEO_OK;
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     int sw = 0, sh = 0;
-    // all small images of the run live in d_small with one leading slot for the previous frame
     const size_t fb = (size_t)height * stride_bytes;
-    upload_frames(m, frames, n_frames, height, stride_bytes, frame_stride_bytes, st);
-    run_small(m, m->d_stage.as<uint8_t>(), n_frames, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
+    upload_frames(S, frames, n_frames, height, stride_bytes, frame_stride_bytes);
+    run_small(m, S.d_stage.as<uint8_t>(), n_frames, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
     const size_t sb = (size_t)sw * sh * 3;
     DevBuf& prev = m->d_prev_small;
     prev.reserve(sb);
@@ -746,17 +896,19 @@ int32_t slideo_orb_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width, in
     if (!bgr || !n_out) fail(SLIDEO_ERR_INVALID_ARG, "null image/n_out");
     validate_image(width, height, stride_bytes);
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     const size_t fb = (size_t)height * stride_bytes;
-    m->d_stage.reserve(fb + 16);
-    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
-    run_orb(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, st, false);
-    const uint32_t q = m->orb.qtot;
+    S.d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    run_orb(m, S, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, false);
+    const uint32_t q = S.orb.qtot;
     *n_out = (int32_t)q;
     if ((int64_t)q > capacity) fail(SLIDEO_ERR_CAPACITY, "%u keypoints, capacity %d", q, capacity);
     if (q) {
-        if (kp) HIP_CHECK(hipMemcpyAsync(kp, m->d_kp.p, (size_t)q * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
-        if (desc32) HIP_CHECK(hipMemcpyAsync(desc32, m->d_desc.p, (size_t)q * 32, hipMemcpyDeviceToHost, st));
+        if (kp) HIP_CHECK(hipMemcpyAsync(kp, S.d_kp.p, (size_t)q * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
+        if (desc32) HIP_CHECK(hipMemcpyAsync(desc32, S.d_desc.p, (size_t)q * 32, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     }
     API_CATCH(m)
@@ -770,16 +922,18 @@ int32_t slideo_pyramid_level_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t
     validate_image(width, height, stride_bytes);
     if (level < 0 || level >= m->cfg.nlevels) fail(SLIDEO_ERR_INVALID_ARG, "level out of range");
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     const size_t fb = (size_t)height * stride_bytes;
-    m->d_stage.reserve(fb + 16);
-    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
-    run_orb(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, st, false);
+    S.d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    run_orb(m, S, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, false);
     const LevelGeom& L = geom_for(m, width, height).g.lv[level];
     *lw = L.w; *lh = L.h;
     if ((int64_t)L.w * L.h > out_capacity) fail(SLIDEO_ERR_CAPACITY, "level needs %lld bytes", (long long)L.w * L.h);
     if (L.w > 0 && L.h > 0) {
-        const uint8_t* src = (blurred ? m->d_blur.as<uint8_t>() : m->d_pyr.as<uint8_t>()) + L.ofs;
+        const uint8_t* src = (blurred ? S.d_blur.as<uint8_t>() : S.d_pyr.as<uint8_t>()) + L.ofs;
         HIP_CHECK(hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -794,15 +948,17 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     if ((nq && !q) || (nt && !t) || (nq && (!idx_out || !dist_out))) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
     if (nq == 0) return SLIDEO_OK;
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64));
     HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
     DevBuf tapx;
     if (m->knn_engine == 0 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
-    run_knn(m, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt, st);
+    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
-    knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(m->d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
+    knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");
     HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 2, hipMemcpyDeviceToHost, st));
@@ -817,12 +973,14 @@ int32_t slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t w
     if (!bgr || !out || !sw_out || !sh_out) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
     validate_image(width, height, stride_bytes);
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
     const size_t fb = (size_t)height * stride_bytes;
-    m->d_stage.reserve(fb + 16);
-    HIP_CHECK(hipMemcpyAsync(m->d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
+    S.d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
     int sw = 0, sh = 0;
-    run_small(m, m->d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
+    run_small(m, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
     *sw_out = sw; *sh_out = sh;
     if ((int64_t)sw * sh * 3 > out_capacity) fail(SLIDEO_ERR_CAPACITY, "small image needs %lld bytes", (long long)sw * sh * 3);
     HIP_CHECK(hipMemcpyAsync(out, m->d_small.p, (size_t)sw * sh * 3, hipMemcpyDeviceToHost, st));

