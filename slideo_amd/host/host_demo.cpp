@@ -1,0 +1,40 @@
+// host_demo — drives the C++ trait-surface mirror the way crates/app/src/main.rs:69-93 drives the reference:
+//   host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating]
+// pages.txt: one PPM path per line (page order).  Prints "time_ms page_nr" per timeline entry (page_nr 0 = None).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "matching.hpp"
+
+struct PdfPage {                     // crates/app/src/pdf_to_images.rs:19-31
+    std::string path; int page_nr;
+    std::string get_path() const { return path; }
+    bool operator==(const PdfPage& o) const { return page_nr == o.page_nr; }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating]\n"); return 2; }
+    try {
+        std::vector<PdfPage> pages;
+        std::ifstream lst(argv[1]);
+        std::string line;
+        while (std::getline(lst, line)) if (!line.empty()) pages.push_back({line, (int)pages.size() + 1});
+        slideo_config cfg; slideo_config_default(&cfg);
+        if (argc > 3) cfg.nfeatures = std::atoi(argv[3]);
+        if (argc > 4) cfg.min_rating = std::atof(argv[4]);
+        uint64_t last = 0;
+        slideo_host::ProgressReporter rep([&](uint64_t d, uint64_t t, const std::string& msg) { last = d; (void)t; (void)msg; });
+        slideo_host::HipImageVideoMatcher matcher(0, &cfg);
+        auto vm = matcher.create_video_matcher(pages, rep);
+        auto task = vm->match_images_with_video(argv[2], rep);
+        auto out = task->process();
+        for (auto& m : out) std::printf("%lld %d\n", (long long)std::llround(m.video_time_s * 1000.0), m.image ? m.image->page_nr : 0);
+        std::fprintf(stderr, "progress callbacks ended at %llu\n", (unsigned long long)last);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "host_demo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

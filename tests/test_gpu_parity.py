@@ -366,3 +366,61 @@ def test_state_and_error_behaviour(capi, cfg0_data):
         m.add_pages([np.zeros((100, 100, 3), np.uint8)])              # area < small_area: would upscale
     assert e.value.code == 5
     m.close()
+
+
+# ---- more shapes and edge cases ---------------------------------------------------------------
+
+def test_orb_bit_exact_4k_orb2000(capi, oracle, mdef, synth):
+    """BASELINE configs[4] shape: one 3840x2160 frame, ORB-2000 (reference literals)."""
+    pages = synth.pages(1)
+    frames, _, _ = synth.frames(pages, 1, 3840, 2160, first=5)
+    n = _cmp_orb(capi, oracle, mdef, oracle.default_config(), frames[0])
+    assert n >= 2000
+
+
+def test_strided_host_frames_and_empty_batch(capi, cfg0_data):
+    import ctypes as C
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    ref = m.match_frames(frames)
+    # rows padded to a stride that is not a multiple of 4, frames padded as well
+    n, h, w, _ = frames.shape
+    stride, fstride = w * 3 + 5, (w * 3 + 5) * h + 77
+    buf = np.zeros(n * fstride, np.uint8)
+    for i in range(n):
+        rows = buf[i * fstride: i * fstride + stride * h].reshape(h, stride)
+        rows[:, : w * 3] = frames[i].reshape(h, w * 3)
+    out = np.zeros(n, capi.VERDICT_DTYPE)
+    rc = capi.lib().slideo_match_frames_bgr8(m._h, n, buf.ctypes.data_as(C.c_void_p), w, h, stride, C.c_int64(fstride),
+                                             out.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and np.array_equal(out, ref)
+    assert len(m.match_frames(frames[:0])) == 0                       # empty batch is a no-op
+    m.close()
+
+
+def test_oversize_image_is_rejected_loudly(capi):
+    m = capi.Matcher(small_cfg(capi))
+    with pytest.raises(capi.SlideoError) as e:
+        m.orb(np.zeros((100, 4200, 3), np.uint8))
+    assert e.value.code == 5
+    m.close()
+
+
+def test_mixed_page_sizes(capi, oracle, synth):
+    """Pages of different sizes (two INTER_AREA size classes incl. the integer-scale fast path) in one deck."""
+    a = synth.pages(2, 800, 450)
+    b = synth.pages(2, 1600, 1200, seed=7)                  # 4:3 -> small image 400x300, integer scale 4
+    cfg_g, cfg_o = small_cfg(capi), small_cfg(oracle)
+    m = capi.Matcher(cfg_g)
+    m.add_pages([a[0], b[0], a[1], b[1]]); m.finalize()
+    db = oracle.PageDB(cfg_o)
+    for p in (a[0], b[0], a[1], b[1]):
+        db.add_page(p)
+    assert db.finalize() == 0 and db.descriptor_count == m.descriptor_count
+    fa, ta, _ = synth.frames(a, 3, 640, 360, first=11)
+    fb_, tb, _ = synth.frames(b, 3, 640, 480, first=12)
+    for frames in (fa, fb_):
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)
+    m.close()

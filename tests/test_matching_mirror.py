@@ -85,3 +85,34 @@ def test_trait_surface_end_to_end(tmp_path, capi, synth):
         exp.append((60.0, None))
     assert [(m.video_time, m.image) for m in out] == exp
     assert all(isinstance(m, mt.Matching) for m in out)
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_matches_python_mirror(tmp_path, capi, synth):
+    """slideo_amd/host/matching.hpp (compiled, g++) drives the same C ABI and yields the same timeline."""
+    import subprocess
+    from slideo_amd import build
+    exe = build.build_host_demo()
+    pages = synth.pages(4, 800, 450)
+    paths = []
+    for i, p in enumerate(pages):
+        path = os.path.join(tmp_path, "p-%d.ppm" % (i + 1))
+        with open(path, "wb") as f:
+            f.write(b"P6\n800 450\n255\n" + p[:, :, ::-1].tobytes())
+        paths.append(path)
+    lst = os.path.join(tmp_path, "pages.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    frames, truth, _ = synth.frames(pages, 6, 640, 360)
+    vid = os.path.join(tmp_path, "v.slvf")
+    mt.RawVideo.write(vid, np.repeat(frames, 10, axis=0), fps=1.0)
+    out = subprocess.run([exe, lst, vid, "500", "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [tuple(int(x) for x in ln.split()) for ln in out.stdout.strip().splitlines()]
+    exp = []
+    for i, t in enumerate(truth):
+        nr = 0 if t < 0 else int(t) + 1
+        if not exp or exp[-1][1] != nr:
+            exp.append((i * 10000, nr))
+    if exp[-1][1] != 0:
+        exp.append((60000, 0))
+    assert got == exp
