@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
     ap.add_argument("--knn", default="mfma", choices=["mfma", "valu"], help="kNN engine (identical results)")
+    ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
@@ -123,6 +124,9 @@ def main():
         v, pending = None, None
         for _ in range(k):
             t = m.submit_dev(d_frames.data_ptr(), B, fw, fh, stream=stream)
+            if args.no_overlap:
+                v = finish(m.collect(t))
+                continue
             if pending is not None:
                 v = finish(m.collect(pending))
             pending = t

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
-    __shared__ uint8_t sc[FAST_SH][FAST_SW];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
     __shared__ uint16_t queue[FAST_SW * FAST_SH];
     __shared__ uint32_t qn;
     const int f = blockIdx.y;
@@ -186,29 +186,30 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         }
     }
     if (threadIdx.x == 0) qn = 0;
+    for (int i = threadIdx.x; i < FAST_SW * FAST_SH / 16; i += 256) reinterpret_cast<uint4*>(&sc[0][0])[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...,
     // lane covers sx = lane and lane + 64 (no divisions, constant LDS offsets).  Every arc of 9 contains one pixel of
     // each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out; the four
-    // pairs tested (axes, then diagonals) leave only corner-like pixels, which are queued for the full test.
+    // pairs tested (vertical first — a flat row segment leaves the whole wave there —, horizontal, then the diagonals)
+    // leave only corner-like pixels, which are queued for the full test.
     // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
     for (int sy = wave; sy < FAST_SH; sy += 4) {
         const int gy = y0 - 1 + sy;
+        if (gy > L.ry1) break;
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
             const int sx = lane + 64 * hx;
             const int gx = x0 - 1 + sx;
-            sc[sy][sx] = 0;
-            if (gx <= L.rx1 && gy <= L.ry1) {
-                const uint8_t* c = &raw[sy + 3][sx + 3 + xoff];
-                const int v = c[0];
-                bool maybe = (fast_differs(c[3 * FAST_RW], v, t) || fast_differs(c[-3 * FAST_RW], v, t)) &&
-                             (fast_differs(c[3], v, t) || fast_differs(c[-3], v, t));
-                if (maybe)
-                    maybe = (fast_differs(c[2 * FAST_RW + 2], v, t) || fast_differs(c[-2 * FAST_RW - 2], v, t)) &&
-                            (fast_differs(c[-2 * FAST_RW + 2], v, t) || fast_differs(c[2 * FAST_RW - 2], v, t));
-                if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + sx);
-            }
+            const uint8_t* c = &raw[sy + 3][sx + 3 + xoff];
+            const int v = c[0];
+            bool maybe = gx <= L.rx1 && (fast_differs(c[3 * FAST_RW], v, t) || fast_differs(c[-3 * FAST_RW], v, t));
+            if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) continue;
+            if (maybe) maybe = fast_differs(c[3], v, t) || fast_differs(c[-3], v, t);
+            if (maybe)
+                maybe = (fast_differs(c[2 * FAST_RW + 2], v, t) || fast_differs(c[-2 * FAST_RW - 2], v, t)) &&
+                        (fast_differs(c[-2 * FAST_RW + 2], v, t) || fast_differs(c[2 * FAST_RW - 2], v, t));
+            if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + sx);
         }
     }
     __syncthreads();
@@ -256,36 +257,41 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
                 score = best - 1;
             }
         }
-        sc[sy][sx] = (uint8_t)score;
+        sc[sy][sx] = (uint8_t)score;      // every other position keeps score 0
     }
     __syncthreads();
-    // NMS (strictly greater than all 8 neighbours) + emit; wave w takes output rows w, w+4, ...
+    // Phase C — NMS (strictly greater than all 8 neighbours) + emit, again only over the queue: a survivor is a
+    // queued corner inside the output tile and the keep-region.
     uint32_t* ccount = cand_count + (size_t)f * g.nlevels + l;
     uint32_t* clist = cand + (size_t)f * g.cand_per_frame + L.cand_ofs;
     uint32_t* h = hist + ((size_t)f * g.nlevels + l) * 256;
-    for (int py = wave; py < FAST_TH; py += 4) {
-        const int gy = y0 + py;
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-            const int px = lane + 64 * hx;
-            const int gx = x0 + px;
-            const uint8_t* c = &sc[py + 1][min(px, FAST_TW - 1) + 1];
-            const int s = c[0];
-            int m = max(max((int)c[-FAST_SW - 1], (int)c[-FAST_SW]), (int)c[-FAST_SW + 1]);
-            m = max(max(m, (int)c[-1]), (int)c[1]);
-            m = max(max(m, (int)c[FAST_SW - 1]), max((int)c[FAST_SW], (int)c[FAST_SW + 1]));
-            const bool keep = px < FAST_TW && s > m && gx < L.rx1 && gy < L.ry1;     // s > m >= 0 implies s > 0
-            const uint64_t msk = __builtin_amdgcn_ballot_w64(keep);
-            if (msk) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(msk));
-                base = __shfl(base, 0);
-                if (keep) {
-                    uint32_t pos = base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull));
-                    if (pos < (uint32_t)L.cand_cap)
-                        clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-                    atomicAdd(h + s, 1u);
-                }
+    for (uint32_t k0 = 0; k0 < nqueued; k0 += 256) {
+        const uint32_t kq = k0 + threadIdx.x;
+        bool keep = false;
+        int s = 0, gx = 0, gy = 0;
+        if (kq < nqueued) {
+            const int i = queue[kq];
+            const int sy = i >> 7, sx = i & 127;
+            gx = x0 - 1 + sx; gy = y0 - 1 + sy;
+            if (sx >= 1 && sx <= FAST_TW && sy >= 1 && sy <= FAST_TH && gx < L.rx1 && gy < L.ry1) {
+                const uint8_t* c = &sc[sy][sx];
+                s = c[0];
+                int m = max(max((int)c[-FAST_SW - 1], (int)c[-FAST_SW]), (int)c[-FAST_SW + 1]);
+                m = max(max(m, (int)c[-1]), (int)c[1]);
+                m = max(max(m, (int)c[FAST_SW - 1]), max((int)c[FAST_SW], (int)c[FAST_SW + 1]));
+                keep = s > m;                                        // s > m >= 0 implies s > 0
+            }
+        }
+        const uint64_t msk = __builtin_amdgcn_ballot_w64(keep);
+        if (msk) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(msk));
+            base = __shfl(base, 0);
+            if (keep) {
+                uint32_t pos = base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull));
+                if (pos < (uint32_t)L.cand_cap)
+                    clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+                atomicAdd(h + s, 1u);
             }
         }
     }
