@@ -33,7 +33,7 @@ struct LevelGeom {
     int32_t cand_ofs, cand_cap;  // candidate list slice (entries) inside one frame's list
     int32_t xtab_ofs, ytab_ofs;  // resize coefficient tables (entries), valid for level >= 1
     float scale;               // (float)pow(scale_factor, level)
-    int32_t _pad;
+    int32_t xctab_ofs;         // packed x weights (256-c1) | c1 << 16, same indexing as xtab_ofs
 };
 
 struct PyrGeom {
@@ -190,7 +190,16 @@ inline void build_pyr_geom(int w, int h, const slideo_config& c, PyrGeom& g, std
         L.cand_cap = rw > 0 ? ((rw + 1) / 2) * ((rh + 1) / 2) : 0;
         cand += L.cand_cap;
         if (l >= 1 && L.w > 0 && L.h > 0 && g.lv[l - 1].w > 0) {
+            // x tables: 16-byte aligned, padded to a multiple of 4 entries with copies of the last entry
+            // (resize_kernel reads them 4 entries at a time)
+            while (lin_tab.size() % 4) lin_tab.push_back(0);
             L.xtab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].w, L.w, lin_tab);
+            while (lin_tab.size() % 4) lin_tab.push_back(lin_tab.back());
+            L.xctab_ofs = (int32_t)lin_tab.size();
+            for (size_t i = (size_t)L.xtab_ofs, e = lin_tab.size(); i < e; ++i) {
+                uint32_t c1 = lin_tab[i] >> 16;
+                lin_tab.push_back((256u - c1) | (c1 << 16));
+            }
             L.ytab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].h, L.h, lin_tab);
         }
     }

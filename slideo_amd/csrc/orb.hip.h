@@ -68,61 +68,67 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ f
 
 // ---------------------------------------------------------------------------
 // [OCV A.2] INTER_LINEAR_EXACT: out = (cy0*(cx0*p00+cx1*p01) + cy1*(cx0*p10+cx1*p11) + 2^15) >> 16
-// grid (ceil(dw/4/256), dh, B)
 // ---------------------------------------------------------------------------
-// Each thread makes 4 adjacent outputs.  Their source span is <= 4*scale + 2 bytes, fetched as
-// (up to 4) aligned dwords per source row instead of 16 single-byte loads.
-__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, int i) {   // byte i (0..15) of 16 bytes
-    // (a dynamically indexed register array would be demoted to LDS by the compiler)
-    const uint64_t w = (i & 8) ? hi : lo;
-    return (uint32_t)(w >> ((i & 7) * 8)) & 0xffu;
+// One thread makes 4 adjacent outputs of one row; threads are numbered flat over (row, 4-pixel group)
+// so every wave is full whatever the level width.  The 4 outputs read <= 12 source bytes per row
+// (shrink factors < 2), fetched as 3 aligned dwords; the two taps of an output are picked with one
+// v_perm_b32 (selector built from the byte offset) and weighted with one v_dot2_u32_u16 against the
+// pre-packed (256-c1, c1) pair.  grid (ceil(nxq*dh/256), 1, B), nxq = ceil(dw/4).
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), 0u, false);
 }
 
 __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
                                                      LevelGeom src, LevelGeom dst,
-                                                     const uint32_t* __restrict__ lin_tab) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (x0 >= dst.w) return;
+                                                     const uint32_t* __restrict__ lin_tab, int nxq, uint32_t nxq_magic) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const int y = nxq_magic ? (int)__umulhi(t, nxq_magic) : (int)t;      // t / nxq (exact, see build_pyr_geom)
+    if (y >= dst.h) return;
+    const int x0 = ((int)t - y * nxq) * 4;
     uint8_t* base = pyr + (int64_t)blockIdx.z * pyr_frame_bytes;
     const uint32_t ye = lin_tab[dst.ytab_ofs + y];
     const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
     const uint8_t* r0 = base + src.ofs + (int64_t)yo * src.pitch;
     const uint8_t* r1 = base + src.ofs + (int64_t)min(yo + 1, src.h - 1) * src.pitch;
     const int nx = min(4, dst.w - x0);
-    uint32_t xe[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xe[i] = lin_tab[dst.xtab_ofs + min(x0 + i, dst.w - 1)];
-    const int xfirst = xe[0] & 0xffff;
-    const int xlast = min((int)(xe[nx - 1] & 0xffff) + 1, src.w - 1);
-    const int xa = xfirst & ~3;                       // aligned start; rows are 16-byte aligned with pitch % 16 == 0
-    uint32_t outv = 0;
-    if (xlast - xa < 16) {
+    // both x tables are 16-byte aligned and padded to a multiple of 4 entries with copies of the last one
+    const uint4 xq = *reinterpret_cast<const uint4*>(lin_tab + dst.xtab_ofs + x0);
+    const uint4 cq = *reinterpret_cast<const uint4*>(lin_tab + dst.xctab_ofs + x0);
+    const uint32_t xe[4] = {xq.x, xq.y, xq.z, xq.w};
+    const uint32_t cp[4] = {cq.x, cq.y, cq.z, cq.w};
+    const int xa = (int)(xe[0] & 0xffff) & ~3;         // aligned start; rows are 16-byte aligned with pitch % 16 == 0
+    uint32_t v[4];
+    if ((int)(xe[3] & 0xffff) + 1 - xa < 12) {
         const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
         const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0);
         const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1);
-        const int i0 = min(d0, maxd), i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd), i3 = min(d0 + 3, maxd);
-        const uint64_t alo = (uint64_t)p0[i0] | ((uint64_t)p0[i1] << 32), ahi = (uint64_t)p0[i2] | ((uint64_t)p0[i3] << 32);
-        const uint64_t blo = (uint64_t)p1[i0] | ((uint64_t)p1[i1] << 32), bhi = (uint64_t)p1[i2] | ((uint64_t)p1[i3] << 32);
+        const int i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd);
+        const uint32_t a0 = p0[d0], a1 = p0[i1], a2 = p0[i2];
+        const uint32_t b0 = p1[d0], b1 = p1[i1], b2 = p1[i2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // tap 2 is byte p+1 even at the right edge: there c1 == 0, so its value is irrelevant
+            const int p = (int)(xe[i] & 0xffff) - xa;                    // 0..10
+            const bool up = p >= 4;
+            const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
+            const uint32_t ta = __builtin_amdgcn_perm(up ? a2 : a1, up ? a1 : a0, sel);
+            const uint32_t tb = __builtin_amdgcn_perm(up ? b2 : b1, up ? b1 : b0, sel);
+            v[i] = (uint32_t)cy0 * dot2_u16(ta, cp[i]) + ((uint32_t)cy1 * dot2_u16(tb, cp[i]) + (1u << 15));
+        }
+    } else {      // (shrink factors >= 2; kept for generality)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
             const int xo1 = min(xo + 1, src.w - 1);
-            uint32_t h0 = (uint32_t)cx0 * byte_of(alo, ahi, xo - xa) + (uint32_t)cx1 * byte_of(alo, ahi, xo1 - xa);
-            uint32_t h1 = (uint32_t)cx0 * byte_of(blo, bhi, xo - xa) + (uint32_t)cx1 * byte_of(blo, bhi, xo1 - xa);
-            uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
-            outv |= v << (8 * i);
-        }
-    } else {      // (not reached for shrink factors < 3; kept for generality)
-        for (int i = 0; i < nx; ++i) {
-            const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
-            const int xo1 = min(xo + 1, src.w - 1);
             uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
             uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
-            uint32_t v = ((uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15)) >> 16;
-            outv |= v << (8 * i);
+            v[i] = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15);
         }
     }
+    // result byte = bits 16..23 of each v (v < 2^24)
+    const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
+                                                __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
     uint8_t* d = base + dst.ofs + (int64_t)y * dst.pitch + x0;
     if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
     else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));

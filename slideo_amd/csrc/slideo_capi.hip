@@ -210,8 +210,13 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
     }
     for (int l = 1; l < L; ++l) {
         if (g.lv[l].w <= 0 || g.lv[l].h <= 0) continue;
-        dim3 grid(cdiv(cdiv(g.lv[l].w, 4), 256), g.lv[l].h, n);
-        resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>());
+        // flat thread index t -> (row, 4-pixel group) = (t / nxq, t % nxq); magic = ceil(2^32 / nxq) divides
+        // exactly while nxq^2 * h < 2^32, which MAX_DIM guarantees
+        const int nxq = cdiv(g.lv[l].w, 4);
+        const uint32_t magic = nxq > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)nxq - 1) / (uint64_t)nxq) : 0u;
+        dim3 grid(cdiv(nxq * g.lv[l].h, 256), 1, n);
+        resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
+                                            nxq, magic);
         check_launch("resize_kernel");
     }
     if (g.fast_tiles > 0) {
