@@ -28,6 +28,7 @@
 // 16 KB, double buffered, one barrier per super-tile).  Fast path per tile and wave:
 // 4 ds_read_b128 + 8 MFMA + max-of-16 twice + 2 compares.
 #pragma once
+#include <limits.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,7 +42,12 @@ typedef float knn_v16f __attribute__((ext_vector_type(16)));
 constexpr int KM_WAVES = 8;                    // waves per block
 constexpr int KM_THREADS = KM_WAVES * 64;
 constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-query B tiles per wave)
-constexpr int KM_ST_ROWS = 128;                // rows per super-tile (one block barrier per super-tile)
+constexpr int KM_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
+constexpr int KM_RING = 4;                     // LDS ring slots (super-tiles resident per block)
+#ifndef KM_MFMA_PRIO
+#define KM_MFMA_PRIO 2
+#endif
+constexpr int KM_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
 constexpr int KM_STAGE = KM_ST_U4 / KM_THREADS;  // uint4 staged per thread and super-tile
 
@@ -85,7 +91,11 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 // Exactness: rows are offered in ascending 8-row groups and thresholds only tighten at a flush, so a
 // candidate with the k-th distance and a higher row than everything in the list is (correctly) rejected by the
 // strict filter, and nothing that belongs to the final top-k is ever filtered out.
-constexpr int KM_FLUSH_AT = 16;
+#ifndef KM_FLUSH_AT_
+#define KM_FLUSH_AT_ 16
+#endif
+constexpr int KM_FLUSH_AT = KM_FLUSH_AT_;
+constexpr int KM_FLUSH_BATCH = 4;
 constexpr int KM_PEND_CAP = 32;                      // >= KM_FLUSH_AT - 1 + 16 (a lane pushes <= 16 keys per tile and query)
 constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
 
@@ -97,9 +107,23 @@ constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
 __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t* __restrict__ q, int nq,
                                                                  const uint4* __restrict__ tx, int nt, int nt_pad,
                                                                  int st_per_seg, uint32_t* __restrict__ out,
-                                                                 uint32_t* __restrict__ pend_ws) {
-    __shared__ uint4 lds[2][KM_ST_U4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                                 uint32_t* __restrict__ pend_ws
+#ifdef KM_TIMING
+                                                                 , unsigned long long* dbg
+#endif
+                                                                 ) {
+#ifdef KM_TIMING
+    unsigned long long t_bar = 0, t_flush = 0, t_slow = 0, n_flush = 0, n_slow = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#define KM_T0 const unsigned long long t0_ = __builtin_readcyclecounter();
+#define KM_T1(acc) acc += __builtin_readcyclecounter() - t0_;
+#else
+#define KM_T0
+#define KM_T1(acc)
+#endif
+    __shared__ uint4 lds[KM_RING][KM_ST_U4];
+    __shared__ uint32_t s_filled[KM_RING], s_done[KM_RING];   // waves that wrote / finished reading each slot (monotonic)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: SGPR bases below)
     const int half = lane >> 5, ql = lane & 31;
     const int qbase = blockIdx.x * KM_QPB + wave * 64;
     const int qi = qbase + lane;                                    // the query whose list this lane owns
@@ -127,51 +151,95 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
         for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
     }
     float thrA = -1024.f, thrB = -1024.f;     // dot > thr  <=>  distance < current k-th distance of that query
+    int thrAi = INT_MIN, thrBi = INT_MIN;     // the same for the bit-pattern compare of the fast path (INT_MIN while thr < 0)
     uint32_t cntA = 0, cntB = 0;              // keys pending in this lane's private buffers
 
     // owners drain the pending buffers of their two source lanes into their sorted list
     auto flush = [&]() {
         const uint32_t cA_lo = __shfl(cntA, ql), cA_hi = __shfl(cntA, ql + 32);
         const uint32_t cB_lo = __shfl(cntB, ql), cB_hi = __shfl(cntB, ql + 32);
+        // the sibling waves of the block can run at most KM_AHEAD super-tiles ahead of a flushing wave, so the flush
+        // is the block's critical path: give it the SIMD's issue slots
         const uint32_t c_lo = half ? cB_lo : cA_lo, c_hi = half ? cB_hi : cA_hi;
-        const uint32_t* PP = half ? PB : PA;
+        const uint32_t* PP = (half ? PB : PA) + ql;
         uint32_t lst[32];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint4 v = my_list[i];
             lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w;
         }
-        for (uint32_t sidx = 0; __builtin_amdgcn_ballot_w64(sidx < c_lo) != 0ull; ++sidx)
-            knn_insert<32>(lst, sidx < c_lo ? PP[sidx * 64 + ql] : KNN_EMPTY);
-        for (uint32_t sidx = 0; __builtin_amdgcn_ballot_w64(sidx < c_hi) != 0ull; ++sidx)
-            knn_insert<32>(lst, sidx < c_hi ? PP[sidx * 64 + ql + 32] : KNN_EMPTY);
-        cntA = 0; cntB = 0;
+        // pending keys are fetched KM_FLUSH_BATCH at a time so that their (L2) latency is paid once per batch, not
+        // once per key; a key slot past a lane's count reads as KNN_EMPTY, whose insertion is a no-op
+        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KM_FLUSH_BATCH) {
+            uint32_t e[KM_FLUSH_BATCH];
+#pragma unroll
+            for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNN_EMPTY;
+#pragma unroll
+            for (int i = 0; i < KM_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+        }
+        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KM_FLUSH_BATCH) {
+            uint32_t e[KM_FLUSH_BATCH];
+#pragma unroll
+            for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNN_EMPTY;
+#pragma unroll
+            for (int i = 0; i < KM_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+        }
         if (owner_valid) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
         }
         const float t = 256.f - 2.f * (float)(lst[31] >> KNN_KEY_SHIFT);
+        cntA = 0; cntB = 0;
         thrA = __shfl(t, ql);
         thrB = __shfl(t, 32 + ql);
+        thrAi = thrA >= 0.f ? __float_as_int(thrA) : INT_MIN;
+        thrBi = thrB >= 0.f ? __float_as_int(thrB) : INT_MIN;
     };
 
-    if (st0 < st1) {
-#pragma unroll
-        for (int i = 0; i < KM_STAGE; ++i) lds[0][tid + i * KM_THREADS] = tx[(size_t)st0 * KM_ST_U4 + tid + i * KM_THREADS];
-    }
+    // No block barrier in the main loop: a barrier per super-tile kept the 8 waves in lock-step and cost a
+    // third of every wave's lifetime (one wave in the slow path or a flush stalls the other seven).  Instead the
+    // super-tiles go through a KM_RING-slot LDS ring guarded by two monotonic counters per slot:
+    //   s_filled[slot] += 1 by each wave once its share of a super-tile is written (consume when == 8 * use#)
+    //   s_done[slot]   += 1 by each wave once it has finished reading the slot       (overwrite when == 8 * use#)
+    // A wave stages super-tile j + KM_AHEAD at the end of its iteration j, so waves may drift apart by
+    // KM_AHEAD super-tiles in either direction before anyone waits.  LDS executes a wave's instructions in order,
+    // so "ds_write data; s_waitcnt; ds_add counter" publishes the data before the count.
+    auto signal = [&](uint32_t* f) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_ge = [&](uint32_t* f, uint32_t target) {
+        KM_T0
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        KM_T1(t_bar)
+    };
+    if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
-    int cur = 0;
-    for (int st = st0; st < st1; ++st) {
-        uint4 nx[KM_STAGE];
-        const bool more = st + 1 < st1;
-        if (more) {
+    const int nst = st1 - st0;
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) {
 #pragma unroll
-            for (int i = 0; i < KM_STAGE; ++i) nx[i] = tx[(size_t)(st + 1) * KM_ST_U4 + tid + i * KM_THREADS];
-        }
-        const uint4* L = lds[cur];
+        for (int i = 0; i < KM_STAGE; ++i) lds[j][tid + i * KM_THREADS] = tx[(size_t)(st0 + j) * KM_ST_U4 + tid + i * KM_THREADS];
+        signal(&s_filled[j]);
+    }
+    for (int j = 0; j < nst; ++j) {
+        const int st = st0 + j, slot = j % KM_RING;
+        const int jn = j + KM_AHEAD;
+        const bool more = jn < nst;
+        // (loaded unconditionally — past the end the last super-tile is re-read and dropped — so that the staging
+        // registers are plain values and not a conditionally initialised array, which the compiler kept in scratch)
+        static_assert(KM_STAGE == 2, "two staging registers per thread");
+        const uint4* nsrc = tx + (size_t)(st0 + min(jn, nst - 1)) * KM_ST_U4 + tid;
+        const uint4 nx0 = nsrc[0], nx1 = nsrc[KM_THREADS];
+        wait_ge(&s_filled[slot], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
+        const uint4* L = lds[slot];
 #pragma unroll 1
         for (int tile = 0; tile < KM_ST_ROWS / 32; ++tile) {
             knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+            // the matrix pipe needs one issue slot in eight; at equal priority the SIMD's arbiter serves the oldest
+            // wave's VALU epilogue first and the pipe idles, so MFMAs are issued at raised priority
+            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint4 a = L[tile * 256 + s * 64 + lane];
@@ -179,45 +247,100 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                 a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq0[s], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                 a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq1[s], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
             }
-            // per-lane group maxima: group g = registers 4g..4g+3 = rows 8g + 4*half + {0..3}
-            float g0[4], g1[4];
+            __builtin_amdgcn_s_setprio(0);
+            // rows past the end of the train set (only in its last tile) can never be candidates
+            const int tile_row0 = st * KM_ST_ROWS + tile * 32;
+            if (tile_row0 + 32 > nt) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                g0[g4] = fmaxf(fmaxf(a0[4 * g4], a0[4 * g4 + 1]), fmaxf(a0[4 * g4 + 2], a0[4 * g4 + 3]));
-                g1[g4] = fmaxf(fmaxf(a1[4 * g4], a1[4 * g4 + 1]), fmaxf(a1[4 * g4 + 2], a1[4 * g4 + 3]));
+                for (int r = 0; r < 16; ++r) {
+                    const bool pad = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nt;
+                    a0[r] = pad ? -1024.f : a0[r];
+                    a1[r] = pad ? -1024.f : a1[r];
+                }
             }
-            const float m0 = fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3]));
-            const float m1 = fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3]));
-            if (__builtin_amdgcn_ballot_w64(m0 > thrA || m1 > thrB) != 0ull) {
-                const int row0 = st * KM_ST_ROWS + tile * 32 + 4 * half;
+            // Fast path: does any of this lane's 2 x 16 dot products beat its query's threshold?  The maxima are taken
+            // on the raw bits with v_max3_i32 (f32 max would first canonicalise all 32 MFMA outputs): for thr >= 0 the
+            // integer order of the bit patterns decides "v > thr" exactly (a negative v has the sign bit set and
+            // compares below every thr >= 0; non-negative floats order like their bits), and a threshold < 0 (list not
+            // full yet, or tiny train sets) is kept as INT_MIN so that everything goes to the exact slow path.
+            int ia[16], ib[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float fa = a0[r], fb = a1[r];
+                ia[r] = __float_as_int(fa); ib[r] = __float_as_int(fb);
+            }
+            int ga[4], gb[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                          // group g = registers 4g..4g+3 = rows 8g + 4*half + {0..3}
+                ga[g4] = max(max(ia[4 * g4], ia[4 * g4 + 1]), max(ia[4 * g4 + 2], ia[4 * g4 + 3]));
+                gb[g4] = max(max(ib[4 * g4], ib[4 * g4 + 1]), max(ib[4 * g4 + 2], ib[4 * g4 + 3]));
+            }
+            const int m0 = max(max(ga[0], ga[1]), max(ga[2], ga[3]));
+            const int m1 = max(max(gb[0], gb[1]), max(gb[2], gb[3]));
+#if defined(KM_ABL) && KM_ABL >= 2
+            if (m0 + m1 == 12345) cntA++;
+            if (false) {
+#elif defined(KM_ABL)
+            if (__builtin_amdgcn_ballot_w64(m0 > thrAi || m1 > thrBi) == 0x1234ull) {
+#else
+            if (__builtin_amdgcn_ballot_w64(m0 > thrAi || m1 > thrBi) != 0ull) {
+#endif
+                KM_T0
+#ifdef KM_TIMING
+                ++n_slow;
+#endif
+                // Slow path (about one iteration in five): usually ONE value of ONE lane qualifies, so each of the
+                // candidate tests below is a wave-uniform "nobody" branch that falls through.
+                const uint32_t row0 = (uint32_t)(tile_row0 + 4 * half);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {                       // ascending 8-row groups
-                    if (__builtin_amdgcn_ballot_w64(g0[g4] > thrA || g1[g4] > thrB) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(ga[g4] > thrAi || gb[g4] > thrBi) == 0ull) continue;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int row = row0 + 8 * g4 + j;
                         const float v0 = a0[4 * g4 + j], v1 = a1[4 * g4 + j];
-                        if (v0 > thrA && row < nt) {                    // candidate for tile-0 query ql
-                            PA[cntA * 64 + lane] = ((uint32_t)(256 - (int)v0) << (KNN_KEY_SHIFT - 1)) | (uint32_t)row;
-                            ++cntA;
+                        const bool h0 = v0 > thrA, h1 = v1 > thrB;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h0) != 0ull, 0)) {
+                            if (h0) {                                   // candidate for tile-0 query ql
+                                PA[cntA * 64 + lane] = ((uint32_t)(256 - (int)v0) << (KNN_KEY_SHIFT - 1)) | (row0 + 8 * g4 + j);
+                                ++cntA;
+                            }
                         }
-                        if (v1 > thrB && row < nt) {                    // candidate for tile-1 query ql
-                            PB[cntB * 64 + lane] = ((uint32_t)(256 - (int)v1) << (KNN_KEY_SHIFT - 1)) | (uint32_t)row;
-                            ++cntB;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h1) != 0ull, 0)) {
+                            if (h1) {                                   // candidate for tile-1 query ql
+                                PB[cntB * 64 + lane] = ((uint32_t)(256 - (int)v1) << (KNN_KEY_SHIFT - 1)) | (row0 + 8 * g4 + j);
+                                ++cntB;
+                            }
                         }
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) flush();
+                KM_T1(t_slow)
+                if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) {
+                    KM_T0
+                    flush();
+                    KM_T1(t_flush)
+#ifdef KM_TIMING
+                    ++n_flush;
+#endif
+                }
             }
         }
+        signal(&s_done[slot]);
         if (more) {
-#pragma unroll
-            for (int i = 0; i < KM_STAGE; ++i) lds[cur ^ 1][tid + i * KM_THREADS] = nx[i];
+            const int ns = jn % KM_RING;
+            wait_ge(&s_done[ns], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
+            lds[ns][tid] = nx0;
+            lds[ns][tid + KM_THREADS] = nx1;
+            signal(&s_filled[ns]);
         }
-        __syncthreads();
-        cur ^= 1;
     }
     flush();
+#ifdef KM_TIMING
+    if (lane == 0) {
+        atomicAdd(dbg + 0, __builtin_readcyclecounter() - t_begin);
+        atomicAdd(dbg + 1, t_bar); atomicAdd(dbg + 2, t_flush); atomicAdd(dbg + 3, t_slow);
+        atomicAdd(dbg + 4, n_flush); atomicAdd(dbg + 5, n_slow); atomicAdd(dbg + 6, 1ull);
+    }
+#endif
 }
 
 }  // namespace slideo

@@ -333,8 +333,22 @@ void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const ui
     const KnnPlan p = knn_plan(m, nq, nt);
     knn_reserve(m, S, nq, nt);
     if (m->knn_engine == 0 && nt > 0) {
+#ifdef KM_TIMING
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) HIP_CHECK(hipMalloc(&dbg, 64));
+        HIP_CHECK(hipMemsetAsync(dbg, 0, 64, st));
+        knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
+                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), dbg);
+        unsigned long long hd[8];
+        HIP_CHECK(hipMemcpyAsync(hd, dbg, 64, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        fprintf(stderr, "KM_TIMING waves %llu: per wave total %.0f barrier %.0f flush %.0f slow %.0f cycles; flushes %.1f slow-iters %.1f (of %d iters)\n",
+                hd[6], (double)hd[0] / hd[6], (double)hd[1] / hd[6], (double)hd[2] / hd[6], (double)hd[3] / hd[6],
+                (double)hd[4] / hd[6], (double)hd[5] / hd[6], knn_pad_rows(nt) / 32);
+#else
         knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
                                                                         S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>());
+#endif
         check_launch("knn_mfma_kernel");
         if (p.nseg > 1) {
             knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
