@@ -42,12 +42,17 @@ typedef float knn_v16f __attribute__((ext_vector_type(16)));
 constexpr int KM_WAVES = 8;                    // waves per block
 constexpr int KM_THREADS = KM_WAVES * 64;
 constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-query B tiles per wave)
-constexpr int KM_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
-constexpr int KM_RING = 4;                     // LDS ring slots (super-tiles resident per block)
+#ifndef KM_ST_ROWS_
+#define KM_ST_ROWS_ 128
+#define KM_RING_ 4
+#define KM_AHEAD_ 2
+#endif
+constexpr int KM_ST_ROWS = KM_ST_ROWS_;                // rows per super-tile (the unit of LDS staging)
+constexpr int KM_RING = KM_RING_;                     // LDS ring slots (super-tiles resident per block)
 #ifndef KM_MFMA_PRIO
 #define KM_MFMA_PRIO 2
 #endif
-constexpr int KM_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
+constexpr int KM_AHEAD = KM_AHEAD_;                    // a super-tile is staged this many iterations before it is consumed
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
 constexpr int KM_STAGE = KM_ST_U4 / KM_THREADS;  // uint4 staged per thread and super-tile
 
@@ -201,9 +206,20 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     // super-tiles go through a KM_RING-slot LDS ring guarded by two monotonic counters per slot:
     //   s_filled[slot] += 1 by each wave once its share of a super-tile is written (consume when == 8 * use#)
     //   s_done[slot]   += 1 by each wave once it has finished reading the slot       (overwrite when == 8 * use#)
-    // A wave stages super-tile j + KM_AHEAD at the end of its iteration j, so waves may drift apart by
-    // KM_AHEAD super-tiles in either direction before anyone waits.  LDS executes a wave's instructions in order,
-    // so "ds_write data; s_waitcnt; ds_add counter" publishes the data before the count.
+    // A wave starts the DMA of its share of super-tile j + KM_AHEAD at the top of its iteration j and publishes it
+    // at the end of that iteration (s_waitcnt vmcnt(0), then the count), so waves may drift apart by about
+    // KM_AHEAD super-tiles in either direction before anyone waits.
+    // this wave's share (2 x 1 KiB) of a super-tile: global -> LDS by DMA (no staging registers, no ds_write pass);
+    // lane i of a wave-instruction lands at the wave-uniform LDS base + 16 i
+    auto stage = [&](int jj, int sl) {
+        constexpr int PER_WAVE = KM_ST_U4 / KM_WAVES;                  // uint4 per wave and super-tile
+        static_assert(PER_WAVE % 64 == 0, "whole wave-instructions");
+        const uint4* src = tx + (size_t)(st0 + jj) * KM_ST_U4 + wave * PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE / 64; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
+                                             (__attribute__((address_space(3))) void*)&lds[sl][wave * PER_WAVE + 64 * i], 16, 0, 0);
+    };
     auto signal = [&](uint32_t* f) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -218,39 +234,48 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
     const int nst = st1 - st0;
-    for (int j = 0; j < KM_AHEAD && j < nst; ++j) {
-#pragma unroll
-        for (int i = 0; i < KM_STAGE; ++i) lds[j][tid + i * KM_THREADS] = tx[(size_t)(st0 + j) * KM_ST_U4 + tid + i * KM_THREADS];
-        signal(&s_filled[j]);
-    }
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) signal(&s_filled[j]);
     for (int j = 0; j < nst; ++j) {
         const int st = st0 + j, slot = j % KM_RING;
-        const int jn = j + KM_AHEAD;
+        const int jn = j + KM_AHEAD, ns = jn % KM_RING;
         const bool more = jn < nst;
-        // (loaded unconditionally — past the end the last super-tile is re-read and dropped — so that the staging
-        // registers are plain values and not a conditionally initialised array, which the compiler kept in scratch)
-        static_assert(KM_STAGE == 2, "two staging registers per thread");
-        const uint4* nsrc = tx + (size_t)(st0 + min(jn, nst - 1)) * KM_ST_U4 + tid;
-        const uint4 nx0 = nsrc[0], nx1 = nsrc[KM_THREADS];
+        if (more) {                               // slot ns was last read for super-tile jn - KM_RING
+            wait_ge(&s_done[ns], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
+            stage(jn, ns);
+        }
         wait_ge(&s_filled[slot], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
-        const uint4* L = lds[slot];
+        const uint4* L = lds[slot] + lane;
+        const int first_pad_tile = (nt - st * KM_ST_ROWS) >> 5;          // tiles from here on hold rows >= nt
+        // A fragments: the first two of a tile are fetched one tile ahead (right after the previous tile's MFMAs are
+        // issued, so their LDS latency hides under the epilogue), the other two behind the tile's first four MFMAs
+        uint4 f0 = L[0], f1 = L[64];
 #pragma unroll 1
         for (int tile = 0; tile < KM_ST_ROWS / 32; ++tile) {
             knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
             // the matrix pipe needs one issue slot in eight; at equal priority the SIMD's arbiter serves the oldest
             // wave's VALU epilogue first and the pipe idles, so MFMAs are issued at raised priority
             __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint4 a = L[tile * 256 + s * 64 + lane];
-                knn_v8i av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
-                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq0[s], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq1[s], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            {
+                const uint4 f2 = L[tile * 256 + 128], f3 = L[tile * 256 + 192];
+                const knn_v8i v0 = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0}, v1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
+                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, bq0[0], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, bq1[0], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, bq0[1], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, bq1[1], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                const knn_v8i v2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w, 0, 0, 0, 0}, v3 = {(int)f3.x, (int)f3.y, (int)f3.z, (int)f3.w, 0, 0, 0, 0};
+                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, bq0[2], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, bq1[2], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, bq0[3], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, bq1[3], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                const uint4* Ln = L + min(tile + 1, KM_ST_ROWS / 32 - 1) * 256;
+                f0 = Ln[0]; f1 = Ln[64];
             }
             __builtin_amdgcn_s_setprio(0);
             // rows past the end of the train set (only in its last tile) can never be candidates
             const int tile_row0 = st * KM_ST_ROWS + tile * 32;
-            if (tile_row0 + 32 > nt) {
+            if (tile >= first_pad_tile) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool pad = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nt;
@@ -269,14 +294,15 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                 const float fa = a0[r], fb = a1[r];
                 ia[r] = __float_as_int(fa); ib[r] = __float_as_int(fb);
             }
-            int ga[4], gb[4];
+            // maxima of register triples {3k, 3k+1, 3k+2} (v_max3_i32), k = 0..4, + register 15: 8 instructions per tile
+            int ta[5], tb[5];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {                          // group g = registers 4g..4g+3 = rows 8g + 4*half + {0..3}
-                ga[g4] = max(max(ia[4 * g4], ia[4 * g4 + 1]), max(ia[4 * g4 + 2], ia[4 * g4 + 3]));
-                gb[g4] = max(max(ib[4 * g4], ib[4 * g4 + 1]), max(ib[4 * g4 + 2], ib[4 * g4 + 3]));
+            for (int k = 0; k < 5; ++k) {
+                ta[k] = max(max(ia[3 * k], ia[3 * k + 1]), ia[3 * k + 2]);
+                tb[k] = max(max(ib[3 * k], ib[3 * k + 1]), ib[3 * k + 2]);
             }
-            const int m0 = max(max(ga[0], ga[1]), max(ga[2], ga[3]));
-            const int m1 = max(max(gb[0], gb[1]), max(gb[2], gb[3]));
+            const int m0 = max(max(max(ia[15], ta[0]), ta[1]), max(max(ta[2], ta[3]), ta[4]));
+            const int m1 = max(max(max(ib[15], tb[0]), tb[1]), max(max(tb[2], tb[3]), tb[4]));
 #if defined(KM_ABL) && KM_ABL >= 2
             if (m0 + m1 == 12345) cntA++;
             if (false) {
@@ -290,24 +316,27 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                 ++n_slow;
 #endif
                 // Slow path (about one iteration in five): usually ONE value of ONE lane qualifies, so each of the
-                // candidate tests below is a wave-uniform "nobody" branch that falls through.
+                // candidate tests below is a wave-uniform "nobody" branch that falls through.  (Rows of one tile may
+                // be offered in any order: the lists only change in a flush, which runs between tiles.)
                 const uint32_t row0 = (uint32_t)(tile_row0 + 4 * half);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {                       // ascending 8-row groups
-                    if (__builtin_amdgcn_ballot_w64(ga[g4] > thrAi || gb[g4] > thrBi) == 0ull) continue;
+                for (int k = 0; k < 6; ++k) {
+                    const bool gate = k < 5 ? (ta[k < 5 ? k : 0] > thrAi || tb[k < 5 ? k : 0] > thrBi) : (ia[15] > thrAi || ib[15] > thrBi);
+                    if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v0 = a0[4 * g4 + j], v1 = a1[4 * g4 + j];
+                    for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
+                        const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
+                        const float v0 = a0[r], v1 = a1[r];
                         const bool h0 = v0 > thrA, h1 = v1 > thrB;
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(h0) != 0ull, 0)) {
                             if (h0) {                                   // candidate for tile-0 query ql
-                                PA[cntA * 64 + lane] = ((uint32_t)(256 - (int)v0) << (KNN_KEY_SHIFT - 1)) | (row0 + 8 * g4 + j);
+                                PA[cntA * 64 + lane] = ((uint32_t)(256 - (int)v0) << (KNN_KEY_SHIFT - 1)) | row;
                                 ++cntA;
                             }
                         }
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(h1) != 0ull, 0)) {
                             if (h1) {                                   // candidate for tile-1 query ql
-                                PB[cntB * 64 + lane] = ((uint32_t)(256 - (int)v1) << (KNN_KEY_SHIFT - 1)) | (row0 + 8 * g4 + j);
+                                PB[cntB * 64 + lane] = ((uint32_t)(256 - (int)v1) << (KNN_KEY_SHIFT - 1)) | row;
                                 ++cntB;
                             }
                         }
@@ -325,11 +354,8 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             }
         }
         signal(&s_done[slot]);
-        if (more) {
-            const int ns = jn % KM_RING;
-            wait_ge(&s_done[ns], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
-            lds[ns][tid] = nx0;
-            lds[ns][tid + KM_THREADS] = nx1;
+        if (more) {                               // the DMA issued a whole iteration ago has landed long since
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             signal(&s_filled[ns]);
         }
     }
