@@ -191,6 +191,13 @@ int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn
  * Both are exact and return identical results; the switch exists for A/B measurement. */
 int32_t     slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine);
 
+/* The matcher's kNN stage is fused with the acceptance rule of its only consumer, the tolerance vote
+ * (mo/lib.rs:268-282: a neighbour counts iff d < best * 1.05): by default it keeps the k-NN lists exact only
+ * for the neighbours that can still pass that test (every such neighbour, in canonical order), which spares
+ * most of the list maintenance.  Verdicts, votes and candidates are identical either way; on != 0 makes the
+ * stage keep the full exact k-NN lists (A/B measurement, tests).  slideo_knn_hamming is always exact. */
+int32_t     slideo_matcher_set_knn_exact_lists(slideo_matcher* m, int32_t on);
+
 #define SLIDEO_N_STAGES 4
 int32_t     slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable);
 int32_t     slideo_matcher_read_profile(slideo_matcher* m, double* ms_out /*[4]*/,

@@ -45,7 +45,7 @@ EXPORTS = [
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
-    "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine",
+    "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect",
 ]
 
@@ -226,6 +226,10 @@ class Matcher:
     def set_knn_engine(self, engine):
         """'mfma' (default, FP4 matrix cores) or 'valu' (integer popcount); identical results."""
         self._check(lib().slideo_matcher_set_knn_engine(self._h, {"mfma": 0, "valu": 1}[engine]))
+
+    def set_knn_exact_lists(self, on=True):
+        """Keep full exact k-NN lists in the matcher (default: only what the 5 % vote can use); same results."""
+        self._check(lib().slideo_matcher_set_knn_exact_lists(self._h, int(bool(on))))
 
     # ---- measurement ------------------------------------------------------------------
     def set_profiling(self, enable=True):

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 }
 
 // q: [nq][8] u32 packed; tx: expanded train (see above), nt valid rows, nt_pad padded rows.
+// prune_tol: 0 = exact k-NN lists; > 0 = lists are exact only for the neighbours with d < best * prune_tol (see flush).
 // Grid (ceil(nq / 512), nseg), block 512.  Segment s covers super-tiles [s*st_per_seg, ...).
 // out: [seg][nq][32] keys.
 //
@@ -112,7 +113,7 @@ constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
 __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t* __restrict__ q, int nq,
                                                                  const uint4* __restrict__ tx, int nt, int nt_pad,
                                                                  int st_per_seg, uint32_t* __restrict__ out,
-                                                                 uint32_t* __restrict__ pend_ws
+                                                                 uint32_t* __restrict__ pend_ws, float prune_tol
 #ifdef KM_TIMING
                                                                  , unsigned long long* dbg
 #endif
@@ -193,7 +194,14 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
 #pragma unroll
             for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
         }
-        const float t = 256.f - 2.f * (float)(lst[31] >> KNN_KEY_SHIFT);
+        float t = 256.f - 2.f * (float)(lst[31] >> KNN_KEY_SHIFT);
+        if (prune_tol > 0.f) {
+            // Fused vote filter: the only consumer of the lists keeps a neighbour iff (float)d < (float)best * tol
+            // (f32, strict; best = the query's smallest distance).  best only decreases, so a row that fails the test
+            // against the CURRENT best can never pass it: it is not worth a list slot.  d < lim  <=>  d <= ceil(lim) - 1.
+            const float lim = (float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol;       // (empty list: 511 * tol, no filter)
+            t = fmaxf(t, 255.f - 2.f * (ceilf(lim) - 1.f));
+        }
         cntA = 0; cntB = 0;
         thrA = __shfl(t, ql);
         thrB = __shfl(t, 32 + ql);
@@ -256,7 +264,9 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
             // the matrix pipe needs one issue slot in eight; at equal priority the SIMD's arbiter serves the oldest
             // wave's VALU epilogue first and the pipe idles, so MFMAs are issued at raised priority
+#if KM_MFMA_PRIO > 0
             __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
+#endif
             {
                 const uint4 f2 = L[tile * 256 + 128], f3 = L[tile * 256 + 192];
                 const knn_v8i v0 = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0}, v1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
@@ -272,7 +282,9 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                 const uint4* Ln = L + min(tile + 1, KM_ST_ROWS / 32 - 1) * 256;
                 f0 = Ln[0]; f1 = Ln[64];
             }
+#if KM_MFMA_PRIO > 0
             __builtin_amdgcn_s_setprio(0);
+#endif
             // rows past the end of the train set (only in its last tile) can never be candidates
             const int tile_row0 = st * KM_ST_ROWS + tile * 32;
             if (tile >= first_pad_tile) {

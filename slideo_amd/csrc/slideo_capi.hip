@@ -90,6 +90,7 @@ struct slideo_matcher {
     int64_t M = -1;
     DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
     int knn_engine = 0;     // 0 = FP4 MFMA (default), 1 = integer VALU popcount
+    int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
 
     // workspaces
     Slot slots[2];
@@ -326,7 +327,10 @@ void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt) {
 }
 
 // t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
-void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt) {
+// prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (MFMA engine; the VALU
+// engine always returns full lists)
+void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt,
+             float prune_tol) {
     if (nq <= 0) return;
     hipStream_t st = S.st;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
@@ -338,7 +342,7 @@ void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const ui
         if (!dbg) HIP_CHECK(hipMalloc(&dbg, 64));
         HIP_CHECK(hipMemsetAsync(dbg, 0, 64, st));
         knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
-                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), dbg);
+                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, dbg);
         unsigned long long hd[8];
         HIP_CHECK(hipMemcpyAsync(hd, dbg, 64, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -347,7 +351,7 @@ void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const ui
                 (double)hd[4] / hd[6], (double)hd[5] / hd[6], knn_pad_rows(nt) / 32);
 #else
         knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
-                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>());
+                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
 #endif
         check_launch("knn_mfma_kernel");
         if (p.nseg > 1) {
@@ -421,7 +425,10 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     uint32_t* flags = S.d_flags.as<uint32_t>();   // zeroed by orb_stage1
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M);
+        // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
+        // current best must still be kept, hence max(tol, 1)
+        const float prune = m->knn_exact_lists ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, prune);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
@@ -635,6 +642,12 @@ void slideo_matcher_destroy(slideo_matcher* m) {
 int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
     if (!m || engine < 0 || engine > 1) return SLIDEO_ERR_INVALID_ARG;
     m->knn_engine = engine;
+    return SLIDEO_OK;
+}
+
+int32_t slideo_matcher_set_knn_exact_lists(slideo_matcher* m, int32_t on) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    m->knn_exact_lists = on ? 1 : 0;
     return SLIDEO_OK;
 }
 
@@ -975,7 +988,7 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
     DevBuf tapx;
     if (m->knn_engine == 0 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
-    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt);
+    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt, 0.f);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");
