@@ -184,11 +184,22 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     {
         constexpr int ndw = FAST_RW / 4;
         const int maxd = (L.pitch >> 2) - 1;
-        for (int i = threadIdx.x; i < ndw * FAST_RH; i += 256) {
-            int ry = i / ndw, rd = i - ry * ndw;
-            int gy = min(max(y0 - 4 + ry, 0), L.h - 1);
-            int gd = min((xa >> 2) + rd, maxd);
-            reinterpret_cast<uint32_t*>(&raw[ry][0])[rd] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
+        // all of a thread's loads are issued before the first LDS store (a rolled loop waited for each one in turn,
+        // and the kernel spent 3/4 of its time there)
+        constexpr int NLD = (ndw * FAST_RH + 255) / 256;
+        uint32_t v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min((int)threadIdx.x + 256 * k, ndw * FAST_RH - 1);
+            const int ry = i / ndw, rd = i - ry * ndw;
+            const int gy = min(max(y0 - 4 + ry, 0), L.h - 1);
+            const int gd = min((xa >> 2) + rd, maxd);
+            v[k] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < ndw * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = v[k];
         }
     }
     if (threadIdx.x == 0) qn = 0;

@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256) void ssd_kernel(const uint8_t* __restrict__ a,
 // so the per-tap work is two LDS reads, two adds/shifts and one 3-byte gather.
 constexpr int RP_SPAN_X = 512, RP_SPAN_Y = 160;
 constexpr int RP_WIN_BYTES = 32 * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
+constexpr int RP_WIN_LD = 4;                 // window groups (of 4 pixels) loaded per thread at a time
 
 // grid (max tile rows, min(B, 65535)), block 256.  Block (ty, y) walks the pairs y, y + gridDim.y, ... of the compact
 // list built by rate_kernel and, for each, the whole row `ty` of 32x8 output tiles: the per-pair constants are
@@ -693,17 +694,31 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                         windowed = true; wx0 = px0; wy0 = by0;
                         const int nrows = by1 - by0 + 1;
                         const int last_dw = (stride >> 2) - 1;                    // stay inside the row allocation
-                        for (int i = threadIdx.x; i < npx4 * nrows; i += 256) {
-                            const int ry = i / npx4, g = i - ry * npx4;
-                            const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(by0 + ry) * stride);
-                            const int d0 = ((px0 >> 2) + g) * 3;
-                            const uint32_t a = row[min(d0, last_dw)], b = row[min(d0 + 1, last_dw)], c = row[min(d0 + 2, last_dw)];
-                            uint4 o4;                                             // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-                            o4.x = a & 0x00FFFFFFu;
-                            o4.y = (a >> 24) | ((b & 0xFFFFu) << 8);
-                            o4.z = (b >> 16) | ((c & 0xFFu) << 16);
-                            o4.w = c >> 8;
-                            reinterpret_cast<uint4*>(win)[i] = o4;
+                        // RP_WIN_LD groups (12 dword loads) are in flight per thread before the first LDS store: the
+                        // rolled loop waited for every group's loads in turn, which was most of this kernel's time
+                        const int total = npx4 * nrows;
+                        for (int i0 = threadIdx.x; i0 < total; i0 += 256 * RP_WIN_LD) {
+                            uint32_t a[RP_WIN_LD], b[RP_WIN_LD], c[RP_WIN_LD];
+#pragma unroll
+                            for (int u = 0; u < RP_WIN_LD; ++u) {
+                                const int i = min(i0 + 256 * u, total - 1);
+                                const int ry = i / npx4, g = i - ry * npx4;
+                                const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(by0 + ry) * stride);
+                                const int d0 = ((px0 >> 2) + g) * 3;
+                                a[u] = row[min(d0, last_dw)]; b[u] = row[min(d0 + 1, last_dw)]; c[u] = row[min(d0 + 2, last_dw)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < RP_WIN_LD; ++u) {
+                                const int i = i0 + 256 * u;
+                                if (i < total) {
+                                    uint4 o4;                                     // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                                    o4.x = a[u] & 0x00FFFFFFu;
+                                    o4.y = (a[u] >> 24) | ((b[u] & 0xFFFFu) << 8);
+                                    o4.z = (b[u] >> 16) | ((c[u] & 0xFFu) << 16);
+                                    o4.w = c[u] >> 8;
+                                    reinterpret_cast<uint4*>(win)[i] = o4;
+                                }
+                            }
                         }
                     }
                 }
