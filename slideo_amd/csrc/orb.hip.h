@@ -160,6 +160,9 @@ constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (hal
 constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;  // raw tile: halo 4 + up to 3 bytes alignment slack, rounded to a multiple of 4
 static_assert(FAST_SW == 128 && FAST_RW % 4 == 0, "fast_kernel maps one score row onto two wave-widths");
 
+typedef short fast_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fast_s2 fast_swap(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+
 __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsigned)(a - v + t) > (unsigned)(2 * t); }   // |a - v| > t
 
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
@@ -246,33 +249,38 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
             p[9] = raw[cy - 3][cx - 1]; p[10] = raw[cy - 2][cx - 2]; p[11] = raw[cy - 1][cx - 3];
             p[12] = raw[cy][cx - 3];    p[13] = raw[cy + 1][cx - 3]; p[14] = raw[cy + 2][cx - 2];
             p[15] = raw[cy + 3][cx - 1];
-            uint32_t bm = 0, dm = 0;
+            // cornerScore<16>: max over the 16 arcs of 9 of min(d) and of min(-d), d[k] = v - p[k]; the pixel is a
+            // corner iff that maximum exceeds t (an arc of 9 all brighter / all darker by more than t), and then its
+            // score is the maximum - 1.  Two arcs per instruction: P[k] = (d[k], d[k+8]) as packed i16, the circular
+            // shifts by 8 are half swaps.
+            fast_s2 P[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                bm |= (uint32_t)(p[k] < v - t) << k;   // centre brighter by > t
-                dm |= (uint32_t)(p[k] > v + t) << k;   // centre darker by > t
+            for (int k = 0; k < 8; ++k) P[k] = fast_s2{(short)(v - p[k]), (short)(v - p[k + 8])};
+            fast_s2 n1[8], x1[8], n2[8], x2[8], n3[8], x3[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                       // pairs: d[k], d[k+1]
+                const fast_s2 o = k < 7 ? P[k + 1] : fast_swap(P[0]);
+                n1[k] = __builtin_elementwise_min(P[k], o); x1[k] = __builtin_elementwise_max(P[k], o);
             }
-            if (run9(bm) || run9(dm)) {
-                // cornerScore<16>: max over the 16 arcs of 9 of min(d) and min(-d), minus 1
-                int d[16], mn[16], mx[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) d[k] = v - p[k];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-                int m2n[16], m2x[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { m2n[k] = min(mn[k], mn[(k + 2) & 15]); m2x[k] = max(mx[k], mx[(k + 2) & 15]); }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { mn[k] = min(m2n[k], m2n[(k + 4) & 15]); mx[k] = max(m2x[k], m2x[(k + 4) & 15]); }
-                int best = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    int a = min(mn[k], d[(k + 8) & 15]);        // min over 9-arc starting at k
-                    int b = max(mx[k], d[(k + 8) & 15]);        // max over the same arc
-                    best = max(best, max(a, -b));
-                }
-                score = best - 1;
+            for (int k = 0; k < 8; ++k) {                       // 4 elements from k
+                const fast_s2 on = k < 6 ? n1[k + 2] : fast_swap(n1[k - 6]), ox = k < 6 ? x1[k + 2] : fast_swap(x1[k - 6]);
+                n2[k] = __builtin_elementwise_min(n1[k], on); x2[k] = __builtin_elementwise_max(x1[k], ox);
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                       // 8 elements from k
+                const fast_s2 on = k < 4 ? n2[k + 4] : fast_swap(n2[k - 4]), ox = k < 4 ? x2[k + 4] : fast_swap(x2[k - 4]);
+                n3[k] = __builtin_elementwise_min(n2[k], on); x3[k] = __builtin_elementwise_max(x2[k], ox);
+            }
+            fast_s2 bestv = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                       // the 9th element of arcs k and k+8: d[k+8], d[k]
+                const fast_s2 o = fast_swap(P[k]);
+                const fast_s2 a9 = __builtin_elementwise_min(n3[k], o), b9 = __builtin_elementwise_max(x3[k], o);
+                bestv = __builtin_elementwise_max(bestv, __builtin_elementwise_max(a9, (fast_s2){0, 0} - b9));
+            }
+            const int best = max((int)bestv.x, (int)bestv.y);
+            score = best > t ? best - 1 : 0;
         }
         sc[sy][sx] = (uint8_t)score;      // every other position keeps score 0
     }
