@@ -85,12 +85,12 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const int y = nxq_magic ? (int)__umulhi(t, nxq_magic) : (int)t;      // t / nxq (exact, see build_pyr_geom)
     if (y >= dst.h) return;
-    const int x0 = ((int)t - y * nxq) * 4;
+    const int x0 = ((int)t - (int)__umul24(y, nxq)) * 4;
     uint8_t* base = pyr + (int64_t)blockIdx.z * pyr_frame_bytes;
     const uint32_t ye = lin_tab[dst.ytab_ofs + y];
     const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
-    const uint8_t* r0 = base + src.ofs + (int64_t)yo * src.pitch;
-    const uint8_t* r1 = base + src.ofs + (int64_t)min(yo + 1, src.h - 1) * src.pitch;
+    const uint8_t* r0 = base + src.ofs + __umul24(yo, src.pitch);
+    const uint8_t* r1 = base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch);
     const int nx = min(4, dst.w - x0);
     // both x tables are 16-byte aligned and padded to a multiple of 4 entries with copies of the last one
     const uint4 xq = *reinterpret_cast<const uint4*>(lin_tab + dst.xtab_ofs + x0);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
             const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
             const uint32_t ta = __builtin_amdgcn_perm(up ? a2 : a1, up ? a1 : a0, sel);
             const uint32_t tb = __builtin_amdgcn_perm(up ? b2 : b1, up ? b1 : b0, sel);
-            v[i] = (uint32_t)cy0 * dot2_u16(ta, cp[i]) + ((uint32_t)cy1 * dot2_u16(tb, cp[i]) + (1u << 15));
+            v[i] = __umul24(cy0, dot2_u16(ta, cp[i])) + (__umul24(cy1, dot2_u16(tb, cp[i])) + (1u << 15));   // 9 x 16 bits: full-rate 24-bit multiplies
         }
     } else {      // (shrink factors >= 2; kept for generality)
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     // result byte = bits 16..23 of each v (v < 2^24)
     const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
                                                 __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
-    uint8_t* d = base + dst.ofs + (int64_t)y * dst.pitch + x0;
+    uint8_t* d = base + dst.ofs + __umul24(y, dst.pitch) + x0;
     if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
     else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));
 }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
             for (int c = 0; c < 4; ++c) {
                 uint32_t a = 0;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a += k[j] * x[c + j];
+                for (int j = 0; j < 7; ++j) a += __umul24(k[j], x[c + j]);   // both < 2^16: full-rate v_mad_u32_u24 (a plain * is a quarter-rate v_mul_lo_u32)
                 o |= ((a + (1u << 15)) >> 16) << (8 * c);
             }
             const int gy = y0 + i;

@@ -697,12 +697,16 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                         // RP_WIN_LD groups (12 dword loads) are in flight per thread before the first LDS store: the
                         // rolled loop waited for every group's loads in turn, which was most of this kernel's time
                         const int total = npx4 * nrows;
+                        const float inv_npx4 = 1.0f / (float)npx4;
                         for (int i0 = threadIdx.x; i0 < total; i0 += 256 * RP_WIN_LD) {
                             uint32_t a[RP_WIN_LD], b[RP_WIN_LD], c[RP_WIN_LD];
 #pragma unroll
                             for (int u = 0; u < RP_WIN_LD; ++u) {
                                 const int i = min(i0 + 256 * u, total - 1);
-                                const int ry = i / npx4, g = i - ry * npx4;
+                                // i / npx4 without the integer-division sequence: i < 2^11, so the f32 product is off
+                                // by < (2^11 / npx4) * 2^-22, far below the 0.5 / npx4 distance of (i + 0.5) / npx4 to
+                                // the nearest integer
+                                const int ry = (int)(((float)i + 0.5f) * inv_npx4), g = i - __mul24(ry, npx4);
                                 const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(by0 + ry) * stride);
                                 const int d0 = ((px0 >> 2) + g) * 3;
                                 a[u] = row[min(d0, last_dw)]; b[u] = row[min(d0 + 1, last_dw)]; c[u] = row[min(d0 + 2, last_dw)];
