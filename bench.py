@@ -180,13 +180,17 @@ def main():
             alg_bytes = 32.0 * (q_per_launch + M) + q_per_launch * 32 * 4
             hbm_view = {"bound": "hbm", "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(alg_bytes)}
-            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.txt; FETCH_SIZE doubled
+            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/knn_traffic.json; FETCH_SIZE doubled
             # per the gfx950 correction).  Measured offline on this exact workload; null for any other.
             traffic = None
             if args.workload == "headline" and args.knn == "mfma" and not args.batch and not args.pages:
-                traffic = {"bytes_per_launch": int((2 * 34017044 + 28396166) / 3 * 1024), "fetch_kib_x2": int(2 * 34017044 / 3),
-                           "write_kib": int(28396166 / 3), "source": "profiles/r01_pmc_hbm_traffic.txt",
-                           "note": "served by the 256 MiB Infinity Cache: ~480 unsynchronised blocks re-stream the 66 MB FP4 train matrix; top-k list spills"}
+                try:
+                    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "knn_traffic.json")))
+                    fx2, wr, nd = 2 * tj["fetch_size_kib"], tj["write_size_kib"], tj["dispatches"]
+                    traffic = {"bytes_per_launch": int((fx2 + wr) / nd * 1024), "fetch_kib_x2": int(fx2 / nd), "write_kib": int(wr / nd),
+                               "source": tj["source"], "note": tj["note"]}
+                except (OSError, KeyError, ValueError):
+                    traffic = None
             common = {"traffic": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
                       "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
                       "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream", "hbm_view": hbm_view}
