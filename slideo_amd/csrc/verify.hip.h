@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                 }
             __syncthreads();
             // frame-space bounding box of the window: X, Y are monotone in x and in y, so the corners bound them
-            bool windowed = false;
+            bool windowed = false, all_in = false;
             int wx0 = 0, wy0 = 0, wpitch = 0;
             if (tabled) {
                 const int nx = sx_hi - sx_lo, ny = sy_hi - sy_lo;
@@ -683,8 +683,11 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                 };
                 int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
                 XY(0, 0, X00, Y00); XY(nx, 0, X10, Y10); XY(0, ny, X01, Y01); XY(nx, ny, X11, Y11);
-                int bx0 = max(min(min(X00, X10), min(X01, X11)), 0), bx1 = min(max(max(X00, X10), max(X01, X11)), fw - 1);
-                int by0 = max(min(min(Y00, Y10), min(Y01, Y11)), 0), by1 = min(max(max(Y00, Y10), max(Y01, Y11)), fh - 1);
+                const int ux0 = min(min(X00, X10), min(X01, X11)), ux1 = max(max(X00, X10), max(X01, X11));
+                const int uy0 = min(min(Y00, Y10), min(Y01, Y11)), uy1 = max(max(Y00, Y10), max(Y01, Y11));
+                all_in = ux0 >= 0 && ux1 < fw && uy0 >= 0 && uy1 < fh;        // no tap of this tile leaves the frame
+                int bx0 = max(ux0, 0), bx1 = min(ux1, fw - 1);
+                int by0 = max(uy0, 0), by1 = min(uy1, fh - 1);
                 if (bx1 >= bx0 && by1 >= by0) {
                     // window columns start at a multiple of 4 pixels so that 4 pixels = 3 aligned source dwords;
                     // stored as 4 bytes per pixel (B,G,R,0): one aligned ds_read_b32 per tap later
@@ -736,15 +739,19 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                     // 2 LDS reads and per tap 2 add/shift pairs, a bounds test and ONE aligned 4-byte LDS read.
                     // Out-of-frame taps and the padding taps (alpha 0) read the zero pixel kept at the end of `win`.
                     const int yb = idx[ag.yidx_ofs + dy], ye = idx[ag.yidx_ofs + dy + 1];
-                    auto run = [&](auto xb_tag) {
+                    // CHECK = false: every tap of the tile is inside the frame (all_in), so the in-frame test and the
+                    // zero-pixel select drop out; padding taps then repeat the last real tap with weight 0.
+                    auto run = [&](auto xb_tag, auto check_tag) {
                         constexpr int XB = decltype(xb_tag)::value;
+                        constexpr bool CHECK = decltype(check_tag)::value;
                         float al[XB]; int adk[XB], bdk[XB];
 #pragma unroll
                         for (int k = 0; k < XB; ++k) {
                             const bool in = xb + k < xe;
                             const AreaTap t = taps[ag.xtap_ofs + (in ? xb + k : xe - 1)];
                             al[k] = in ? t.alpha : 0.f;
-                            adk[k] = s_ad[t.si - sx_lo]; bdk[k] = in ? s_bd[t.si - sx_lo] : (int)0x40000000;   // padding taps land far outside the frame
+                            adk[k] = s_ad[t.si - sx_lo];
+                            bdk[k] = (in || !CHECK) ? s_bd[t.si - sx_lo] : (int)0x40000000;   // CHECK: padding taps land far outside the frame
                         }
                         float s0 = 0, s1 = 0, s2 = 0;
                         const int wbase = -wy0 * wpitch - 4 * wx0;
@@ -757,8 +764,8 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                                 const int X = (int)((uint32_t)X0 + (uint32_t)adk[k]) >> AB_BITS;
                                 const int Y = (int)((uint32_t)Y0 + (uint32_t)bdk[k]) >> AB_BITS;
                                 // (saturate_cast<short> of imgwarp.cpp cannot change the in-frame test for frames < 32768 px)
-                                const bool inb = (unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh;
-                                const int ofs = inb ? (int)__mul24(Y, wpitch) + 4 * X + wbase : RP_WIN_BYTES;
+                                int ofs = (int)__mul24(Y, wpitch) + 4 * X + wbase;
+                                if (CHECK) ofs = ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) ? ofs : RP_WIN_BYTES;
                                 const uint32_t px = *reinterpret_cast<const uint32_t*>(win + ofs);
                                 b0 = b0 + (float)(px & 255u) * al[k]; b1 = b1 + (float)((px >> 8) & 255u) * al[k]; b2 = b2 + (float)((px >> 16) & 255u) * al[k];
                             }
@@ -767,7 +774,10 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                         }
                         o[0] = sat_u8_f(s0); o[1] = sat_u8_f(s1); o[2] = sat_u8_f(s2);
                     };
-                    if (ag.max_xtaps <= 6) run(std::integral_constant<int, 6>{}); else run(std::integral_constant<int, 8>{});
+                    using T6 = std::integral_constant<int, 6>; using T8 = std::integral_constant<int, 8>;
+                    if (all_in) { if (ag.max_xtaps <= 6) run(T6{}, std::false_type{}); else run(T8{}, std::false_type{}); }
+                    else
+                    { if (ag.max_xtaps <= 6) run(T6{}, std::true_type{}); else run(T8{}, std::true_type{}); }
                 } else {
                     area_pixel_simple(ag, taps, idx, dx, dy, [&](int x, int y, uint8_t* p) {
                         const int adelta = sat_int_d(M[0] * x * AB_SCALE), bdelta = sat_int_d(M[3] * x * AB_SCALE);
