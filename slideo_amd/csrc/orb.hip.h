@@ -214,22 +214,28 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     // pairs tested (vertical first — a flat row segment leaves the whole wave there —, horizontal, then the diagonals)
     // leave only corner-like pixels, which are queued for the full test.
     // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
+    // (written without short-circuit operators: each && / || became an exec-masked branch around one ds_read_u8
+    // that was waited for on its own; now a stage's LDS reads are issued together and the tests are plain bit ops)
     for (int sy = wave; sy < FAST_SH; sy += 4) {
         const int gy = y0 - 1 + sy;
         if (gy > L.ry1) break;
+        const uint8_t* c0 = &raw[sy + 3][lane + 3 + xoff];
+        const uint8_t* c1 = c0 + 64;
+        const int v0 = c0[0], u0 = c0[-3 * FAST_RW], d0 = c0[3 * FAST_RW];
+        const int v1 = c1[0], u1 = c1[-3 * FAST_RW], d1 = c1[3 * FAST_RW];
+        const bool m0 = (x0 - 1 + lane <= L.rx1) & (fast_differs(d0, v0, t) | fast_differs(u0, v0, t));
+        const bool m1 = (x0 - 1 + lane + 64 <= L.rx1) & (fast_differs(d1, v1, t) | fast_differs(u1, v1, t));
+        if (__builtin_amdgcn_ballot_w64(m0 | m1) == 0ull) continue;
 #pragma unroll
         for (int hx = 0; hx < 2; ++hx) {
-            const int sx = lane + 64 * hx;
-            const int gx = x0 - 1 + sx;
-            const uint8_t* c = &raw[sy + 3][sx + 3 + xoff];
-            const int v = c[0];
-            bool maybe = gx <= L.rx1 && (fast_differs(c[3 * FAST_RW], v, t) || fast_differs(c[-3 * FAST_RW], v, t));
-            if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) continue;
-            if (maybe) maybe = fast_differs(c[3], v, t) || fast_differs(c[-3], v, t);
-            if (maybe)
-                maybe = (fast_differs(c[2 * FAST_RW + 2], v, t) || fast_differs(c[-2 * FAST_RW - 2], v, t)) &&
-                        (fast_differs(c[-2 * FAST_RW + 2], v, t) || fast_differs(c[2 * FAST_RW - 2], v, t));
-            if (maybe) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + sx);
+            const bool m = hx ? m1 : m0;
+            if (__builtin_amdgcn_ballot_w64(m) == 0ull) continue;
+            const uint8_t* c = hx ? c1 : c0;
+            const int v = hx ? v1 : v0;
+            const int e = c[3], w = c[-3], se = c[2 * FAST_RW + 2], nw = c[-2 * FAST_RW - 2], ne = c[-2 * FAST_RW + 2], sw = c[2 * FAST_RW - 2];
+            const bool keep = m & (fast_differs(e, v, t) | fast_differs(w, v, t)) &
+                              (fast_differs(se, v, t) | fast_differs(nw, v, t)) & (fast_differs(ne, v, t) | fast_differs(sw, v, t));
+            if (keep) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64 * hx);
         }
     }
     __syncthreads();
