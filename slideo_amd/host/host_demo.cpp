@@ -1,5 +1,5 @@
 // host_demo — drives the C++ trait-surface mirror the way crates/app/src/main.rs:69-93 drives the reference:
-//   host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating]
+//   host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating] [video_hash]
 // pages.txt: one PPM path per line (page order).  Prints "time_ms page_nr" per timeline entry (page_nr 0 = None).
 #include <cstdio>
 #include <cstdlib>
@@ -9,7 +9,7 @@
 #include "matching.hpp"
 
 struct PdfPage {                     // crates/app/src/pdf_to_images.rs:19-31
-    std::string path; int page_nr;
+    std::string path; int page_nr; std::string pdf_hash;
     std::string get_path() const { return path; }
     bool operator==(const PdfPage& o) const { return page_nr == o.page_nr; }
 };
@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
         std::vector<PdfPage> pages;
         std::ifstream lst(argv[1]);
         std::string line;
-        while (std::getline(lst, line)) if (!line.empty()) pages.push_back({line, (int)pages.size() + 1});
+        while (std::getline(lst, line)) if (!line.empty()) pages.push_back({line, (int)pages.size() + 1, "pdfhash"});
         slideo_config cfg; slideo_config_default(&cfg);
         if (argc > 3) cfg.nfeatures = std::atoi(argv[3]);
         if (argc > 4) cfg.min_rating = std::atof(argv[4]);
@@ -31,6 +31,12 @@ int main(int argc, char** argv) {
         auto task = vm->match_images_with_video(argv[2], rep);
         auto out = task->process();
         for (auto& m : out) std::printf("%lld %d\n", (long long)std::llround(m.video_time_s * 1000.0), m.image ? m.image->page_nr : 0);
+        if (argc > 5) {      // the app's output contract (db.rs:162-260): rows, then the viewer records of this pdf
+            const auto rows = slideo_host::videos_mapping_rows(out);
+            for (auto& r : rows) std::printf("row %u %s %u\n", r.video_ms, r.has_pdf ? r.pdf_hash.c_str() : "-", r.page);
+            for (auto& pm : slideo_host::pdf_video_matchings(rows, "pdfhash", argv[5]))
+                std::printf("pvm %u %s %s %u %u\n", pm.video_offset_ms, pm.pdf_hash.c_str(), pm.video_hash.c_str(), pm.page_idx, pm.duration_ms);
+        }
         std::fprintf(stderr, "progress callbacks ended at %llu\n", (unsigned long long)last);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "host_demo: %s\n", e.what());

@@ -43,6 +43,38 @@ private:
 };
 
 // matching::Matching<I> (crates/matching/src/lib.rs:35-40)
+// ---- timeline output contract of crates/app -----------------------------------------
+// videos_mapping rows (db.rs:162-191) and PdfVideoMatching records (db.rs:194-201, 209-260); host logic only.
+struct VideoMappingRow { uint32_t video_ms; bool has_pdf; std::string pdf_hash; uint32_t page; };
+struct PdfVideoMatching { uint32_t video_offset_ms; std::string pdf_hash, video_hash; uint32_t page_idx, duration_ms; };
+
+// I must expose .pdf_hash (std::string) and .page_nr (1-based), like PdfPage (pdf_to_images.rs:19-31)
+template <class MatchingT>
+inline std::vector<VideoMappingRow> videos_mapping_rows(const std::vector<MatchingT>& matchings) {
+    std::vector<VideoMappingRow> rows;
+    for (const auto& m : matchings) {
+        VideoMappingRow r;
+        r.video_ms = (uint32_t)(uint64_t)(m.video_time_s * 1000.0);           // as_millis() as u32   (db.rs:176)
+        r.has_pdf = (bool)m.image;
+        r.pdf_hash = m.image ? m.image->pdf_hash : std::string();             // db.rs:175
+        r.page = m.image ? (uint32_t)(m.image->page_nr - 1) : 0u;             // db.rs:177
+        rows.push_back(r);
+    }
+    return rows;
+}
+
+inline std::vector<PdfVideoMatching> pdf_video_matchings(std::vector<VideoMappingRow> rows, const std::string& pdf_hash,
+                                                        const std::string& video_hash) {
+    std::stable_sort(rows.begin(), rows.end(), [](const VideoMappingRow& a, const VideoMappingRow& b) { return a.video_ms < b.video_ms; });
+    std::vector<PdfVideoMatching> out;
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const uint32_t duration = i + 1 < rows.size() ? rows[i + 1].video_ms - rows[i].video_ms : 5000u;   // db.rs:239-245
+        if (rows[i].has_pdf && rows[i].pdf_hash == pdf_hash)
+            out.push_back({rows[i].video_ms, rows[i].pdf_hash, video_hash, rows[i].page, duration});
+    }
+    return out;
+}
+
 template <class I>
 struct Matching {
     double video_time_s;

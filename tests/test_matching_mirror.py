@@ -105,9 +105,10 @@ def test_cpp_host_mirror_matches_python_mirror(tmp_path, capi, synth):
     frames, truth, _ = synth.frames(pages, 6, 640, 360)
     vid = os.path.join(tmp_path, "v.slvf")
     mt.RawVideo.write(vid, np.repeat(frames, 10, axis=0), fps=1.0)
-    out = subprocess.run([exe, lst, vid, "500", "12"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, lst, vid, "500", "12", "vidhash"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    got = [tuple(int(x) for x in ln.split()) for ln in out.stdout.strip().splitlines()]
+    lines = out.stdout.strip().splitlines()
+    got = [tuple(int(x) for x in ln.split()) for ln in lines if ln[0].isdigit()]
     exp = []
     for i, t in enumerate(truth):
         nr = 0 if t < 0 else int(t) + 1
@@ -116,3 +117,13 @@ def test_cpp_host_mirror_matches_python_mirror(tmp_path, capi, synth):
     if exp[-1][1] != 0:
         exp.append((60000, 0))
     assert got == exp
+    # output contract: the C++ rows / viewer records equal the Python restatement's
+    from slideo_amd import timeline as tl
+
+    class Pg:
+        def __init__(self, nr): self.page_nr, self.pdf_hash = nr, "pdfhash"
+    ms = [mt.Matching(video_time=t / 1000.0, video_frame_idx=0, image=None if nr == 0 else Pg(nr)) for t, nr in exp]
+    rows = tl.videos_mapping_rows(ms)
+    assert [ln for ln in lines if ln.startswith("row ")] == ["row %d %s %d" % (r.video_ms, r.pdf_hash or "-", r.page) for r in rows]
+    assert [ln for ln in lines if ln.startswith("pvm ")] == ["pvm %d %s %s %d %d" % (p.video_offset_ms, p.pdf_hash, p.video_hash, p.page_idx, p.duration_ms)
+                                                           for p in tl.pdf_video_matchings(rows, "pdfhash", "vidhash")]
