@@ -69,12 +69,12 @@ HOST_DEMO = os.path.join(LIBDIR, "host_demo")
 def build_host_demo(force=False):
     """C++ host-side mirror of the trait surface (slideo_amd/host/matching.hpp) + its demo driver."""
     srcs = [os.path.join(HERE, "host", "host_demo.cpp"), os.path.join(HERE, "host", "matching.hpp"),
-            os.path.join(INCLUDE, "slideo_amd.h")]
+            os.path.join(HERE, "host", "png.hpp"), os.path.join(INCLUDE, "slideo_amd.h")]
     if not (force or _newer(HOST_DEMO, srcs + [HIP_LIB])):
         return HOST_DEMO
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", INCLUDE, "-I", os.path.join(HERE, "host"), "-o", HOST_DEMO, srcs[0],
                            "-L", LIBDIR, "-lslideo_amd", "-Wl,-rpath,$ORIGIN", "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
-                           "-lamdhip64"])
+                           "-lamdhip64", "-lz"])
     return HOST_DEMO
 
 

@@ -1,6 +1,7 @@
 // host_demo — drives the C++ trait-surface mirror the way crates/app/src/main.rs:69-93 drives the reference:
-//   host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating] [video_hash]
-// pages.txt: one PPM path per line (page order).  Prints "time_ms page_nr" per timeline entry (page_nr 0 = None).
+//   host_demo <pages.txt | page dir> <video.slvf> [nfeatures] [min_rating] [video_hash]
+//   host_demo --dump-image <file.png|.ppm>
+// pages.txt: one PPM/PNG path per line (page order); a directory is scanned like a pdftocairo target dir (p-<nr>.png).  Prints "time_ms page_nr" per timeline entry (page_nr 0 = None).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -8,19 +9,24 @@
 
 #include "matching.hpp"
 
-struct PdfPage {                     // crates/app/src/pdf_to_images.rs:19-31
-    std::string path; int page_nr; std::string pdf_hash;
-    std::string get_path() const { return path; }
-    bool operator==(const PdfPage& o) const { return page_nr == o.page_nr; }
-};
+using slideo_host::PdfPage;          // crates/app/src/pdf_to_images.rs:19-31
 
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: host_demo <pages.txt> <video.slvf> [nfeatures] [min_rating]\n"); return 2; }
     try {
+        if (std::string(argv[1]) == "--dump-image") {          // raw BGR of one image to stdout (decoder test)
+            auto im = slideo_host::load_image_bgr(argv[2]);
+            std::printf("%d %d\n", im.w, im.h);
+            std::fwrite(im.bgr.data(), 1, im.bgr.size(), stdout);
+            return 0;
+        }
         std::vector<PdfPage> pages;
-        std::ifstream lst(argv[1]);
-        std::string line;
-        while (std::getline(lst, line)) if (!line.empty()) pages.push_back({line, (int)pages.size() + 1, "pdfhash"});
+        if (std::filesystem::is_directory(argv[1])) pages = slideo_host::scan_page_dir(argv[1], "pdfhash");   // pdftocairo target dir
+        else {
+            std::ifstream lst(argv[1]);
+            std::string line;
+            while (std::getline(lst, line)) if (!line.empty()) pages.push_back({pages.size() + 1, line, "", "pdfhash"});
+        }
         slideo_config cfg; slideo_config_default(&cfg);
         if (argc > 3) cfg.nfeatures = std::atoi(argv[3]);
         if (argc > 4) cfg.min_rating = std::atof(argv[4]);
@@ -30,7 +36,7 @@ int main(int argc, char** argv) {
         auto vm = matcher.create_video_matcher(pages, rep);
         auto task = vm->match_images_with_video(argv[2], rep);
         auto out = task->process();
-        for (auto& m : out) std::printf("%lld %d\n", (long long)std::llround(m.video_time_s * 1000.0), m.image ? m.image->page_nr : 0);
+        for (auto& m : out) std::printf("%lld %d\n", (long long)std::llround(m.video_time_s * 1000.0), m.image ? (int)m.image->page_nr : 0);
         if (argc > 5) {      // the app's output contract (db.rs:162-260): rows, then the viewer records of this pdf
             const auto rows = slideo_host::videos_mapping_rows(out);
             for (auto& r : rows) std::printf("row %u %s %u\n", r.video_ms, r.has_pdf ? r.pdf_hash.c_str() : "-", r.page);

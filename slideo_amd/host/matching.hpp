@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <filesystem>
 #include <fstream>
 #include <functional>
 #include <memory>
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "slideo_amd.h"
+#include "png.hpp"
 
 namespace slideo_host {
 
@@ -96,6 +98,40 @@ inline Image8 load_ppm_bgr(const std::string& path) {
     f.read(reinterpret_cast<char*>(im.bgr.data()), (std::streamsize)im.bgr.size());
     for (size_t i = 0; i < im.bgr.size(); i += 3) std::swap(im.bgr[i], im.bgr[i + 2]);        // RGB -> BGR
     return im;
+}
+
+// imread stand-in of the page ingest (mo/lib.rs:98-104): PNG (what pdftocairo writes) or binary PPM, by extension
+inline Image8 load_image_bgr(const std::string& path) {
+    const auto dot = path.rfind('.');
+    std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+    for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == "png") { PngImage p = decode_png_bgr(path); Image8 im; im.w = p.w; im.h = p.h; im.bgr = std::move(p.bgr); return im; }
+    return load_ppm_bgr(path);
+}
+
+// Page list of one PDF as the app builds it: every entry of the pdftocairo target directory is
+// named "p-<nr>.png" (zero padded to the page count's width), page_nr = the number after "p-", pages sorted by it
+// (crates/pdftocairo/src/pdftocairo.rs:216-231); PdfPage{page_nr (1-based), image_path, pdf_path, pdf_hash}
+// (crates/app/src/pdf_to_images.rs:19-31,138-146).  A foreign file name is a panic there and an exception here.
+struct PdfPage {
+    size_t page_nr = 0; std::string image_path, pdf_path, pdf_hash;
+    std::string get_path() const { return image_path; }                                     // MatchableImage, pdf_to_images.rs:33-37
+    bool operator==(const PdfPage& o) const { return page_nr == o.page_nr && pdf_hash == o.pdf_hash; }
+};
+
+inline std::vector<PdfPage> scan_page_dir(const std::string& target_dir, const std::string& pdf_hash, const std::string& pdf_path = "") {
+    std::vector<PdfPage> pages;
+    for (const auto& item : std::filesystem::directory_iterator(target_dir)) {
+        const std::string file_name = item.path().filename().string();                     // e.g. p-01.png
+        const std::string stem = file_name.substr(0, file_name.find('.'));
+        size_t used = 0; unsigned long nr = 0;
+        bool ok = stem.size() > 2;
+        if (ok) { try { nr = std::stoul(stem.substr(2), &used); } catch (const std::exception&) { ok = false; } }
+        if (!ok || used != stem.size() - 2) throw std::runtime_error("unexpected file '" + file_name + "' in page directory '" + target_dir + "'");
+        pages.push_back({(size_t)nr, item.path().string(), pdf_path, pdf_hash});
+    }
+    std::stable_sort(pages.begin(), pages.end(), [](const PdfPage& a, const PdfPage& b) { return a.page_nr < b.page_nr; });
+    return pages;
 }
 
 // Raw BGR frame container standing in for VideoCapture (mo/video_capture.rs:16-40):
@@ -244,7 +280,7 @@ private:
 // I must provide `std::string get_path() const` (matching::MatchableImage, lib.rs:31-33) and operator==.
 class HipImageVideoMatcher {
 public:
-    explicit HipImageVideoMatcher(int device = 0, const slideo_config* cfg = nullptr, ImageLoader loader = load_ppm_bgr)
+    explicit HipImageVideoMatcher(int device = 0, const slideo_config* cfg = nullptr, ImageLoader loader = load_image_bgr)
         : device_(device), loader_(std::move(loader)) {
         slideo_config_default(&cfg_);
         if (cfg) cfg_ = *cfg;

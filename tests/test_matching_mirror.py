@@ -94,14 +94,12 @@ def test_cpp_host_mirror_matches_python_mirror(tmp_path, capi, synth):
     from slideo_amd import build
     exe = build.build_host_demo()
     pages = synth.pages(4, 800, 450)
-    paths = []
+    # a pdftocairo target directory: p-<nr>.png; the C++ mirror scans and decodes it itself
+    from PIL import Image
+    lst = os.path.join(tmp_path, "pages")
+    os.makedirs(lst)
     for i, p in enumerate(pages):
-        path = os.path.join(tmp_path, "p-%d.ppm" % (i + 1))
-        with open(path, "wb") as f:
-            f.write(b"P6\n800 450\n255\n" + p[:, :, ::-1].tobytes())
-        paths.append(path)
-    lst = os.path.join(tmp_path, "pages.txt")
-    open(lst, "w").write("\n".join(paths) + "\n")
+        Image.fromarray(np.ascontiguousarray(p[:, :, ::-1])).save(os.path.join(lst, "p-%d.png" % (i + 1)))
     frames, truth, _ = synth.frames(pages, 6, 640, 360)
     vid = os.path.join(tmp_path, "v.slvf")
     mt.RawVideo.write(vid, np.repeat(frames, 10, axis=0), fps=1.0)
