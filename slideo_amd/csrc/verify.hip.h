@@ -29,7 +29,7 @@ namespace slideo {
 
 constexpr int MAXC = 64;       // >= max_candidate_pages
 constexpr int MAXR = 16;       // >= max_rated
-constexpr int RANSAC_LDS_PTS = 2048;
+constexpr int RANSAC_LDS_PTS = 1024;    // point pairs kept in LDS (more go through global memory); 17 KB per 64-thread block = 9 blocks per CU
 
 struct FrameCands {            // one per frame of the batch, device resident
     int32_t ncand, nsurv;
