@@ -273,6 +273,22 @@ def test_end_to_end_1080p_reference_defaults(capi, oracle, synth):
     m.close()
 
 
+def test_end_to_end_larger_deck_traces(capi, oracle, synth):
+    """48 pages (about 24 k train descriptors, several kNN super-tiles and flushes per wave), 24 frames incl. "no slide"
+    frames: every candidate's votes / inliers / transform and every verdict against the oracle — this is the path
+    where the kNN stage keeps only the neighbours the vote can use."""
+    pages = synth.pages(48, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
+    assert m.descriptor_count == db.descriptor_count > 20000
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    m.set_knn_exact_lists(True)
+    v2 = m.match_frames(frames)
+    assert np.array_equal(v, v2)
+    m.close()
+
+
 def test_knn_engines_give_identical_verdicts(capi, cfg0_data):
     pages, frames, truth, _ = cfg0_data
     m = capi.Matcher(small_cfg(capi))
