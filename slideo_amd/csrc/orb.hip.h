@@ -161,6 +161,7 @@ constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;  // raw tile: halo 
 static_assert(FAST_SW == 128 && FAST_RW % 4 == 0, "fast_kernel maps one score row onto two wave-widths");
 
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short fast_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fast_s2 fast_swap(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 
 __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsigned)(a - v + t) > (unsigned)(2 * t); }   // |a - v| > t
@@ -214,29 +215,31 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     // pairs tested (vertical first — a flat row segment leaves the whole wave there —, horizontal, then the diagonals)
     // leave only corner-like pixels, which are queued for the full test.
     // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
-    // (written without short-circuit operators: each && / || became an exec-masked branch around one ds_read_u8
-    // that was waited for on its own; now a stage's LDS reads are issued together and the tests are plain bit ops)
+    // A lane tests positions sx = lane and lane + 64 together, as the two halves of packed-u16 registers:
+    // |a - v| = sat(a - v) | sat(v - a), "either pixel of a pair differs" = max of the two, "every pair" = min over the
+    // pairs, "> t" = a saturating subtract of t that leaves a non-zero half.  No short-circuit operators: a stage's
+    // LDS reads are issued together.
+    const fast_us2 tt = {(unsigned short)t, (unsigned short)t};
+    auto pk = [](int lo, int hi) { return fast_us2{(unsigned short)lo, (unsigned short)hi}; };
+    auto absd = [](fast_us2 a, fast_us2 v) { return __builtin_elementwise_sub_sat(a, v) | __builtin_elementwise_sub_sat(v, a); };
+    const uint32_t in0 = (x0 - 1 + lane <= L.rx1) ? 0xFFFFu : 0u, in1 = (x0 - 1 + lane + 64 <= L.rx1) ? 0xFFFF0000u : 0u;
+    const uint32_t inmask = in0 | in1;
     for (int sy = wave; sy < FAST_SH; sy += 4) {
         const int gy = y0 - 1 + sy;
         if (gy > L.ry1) break;
         const uint8_t* c0 = &raw[sy + 3][lane + 3 + xoff];
         const uint8_t* c1 = c0 + 64;
-        const int v0 = c0[0], u0 = c0[-3 * FAST_RW], d0 = c0[3 * FAST_RW];
-        const int v1 = c1[0], u1 = c1[-3 * FAST_RW], d1 = c1[3 * FAST_RW];
-        const bool m0 = (x0 - 1 + lane <= L.rx1) & (fast_differs(d0, v0, t) | fast_differs(u0, v0, t));
-        const bool m1 = (x0 - 1 + lane + 64 <= L.rx1) & (fast_differs(d1, v1, t) | fast_differs(u1, v1, t));
-        if (__builtin_amdgcn_ballot_w64(m0 | m1) == 0ull) continue;
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-            const bool m = hx ? m1 : m0;
-            if (__builtin_amdgcn_ballot_w64(m) == 0ull) continue;
-            const uint8_t* c = hx ? c1 : c0;
-            const int v = hx ? v1 : v0;
-            const int e = c[3], w = c[-3], se = c[2 * FAST_RW + 2], nw = c[-2 * FAST_RW - 2], ne = c[-2 * FAST_RW + 2], sw = c[2 * FAST_RW - 2];
-            const bool keep = m & (fast_differs(e, v, t) | fast_differs(w, v, t)) &
-                              (fast_differs(se, v, t) | fast_differs(nw, v, t)) & (fast_differs(ne, v, t) | fast_differs(sw, v, t));
-            if (keep) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64 * hx);
-        }
+        const fast_us2 v = pk(c0[0], c1[0]);
+        const fast_us2 m1 = __builtin_elementwise_max(absd(pk(c0[-3 * FAST_RW], c1[-3 * FAST_RW]), v), absd(pk(c0[3 * FAST_RW], c1[3 * FAST_RW]), v));
+        const uint32_t s1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(m1, tt)) & inmask;
+        if (__builtin_amdgcn_ballot_w64(s1 != 0u) == 0ull) continue;
+        const fast_us2 mh = __builtin_elementwise_max(absd(pk(c0[3], c1[3]), v), absd(pk(c0[-3], c1[-3]), v));
+        const fast_us2 md1 = __builtin_elementwise_max(absd(pk(c0[2 * FAST_RW + 2], c1[2 * FAST_RW + 2]), v), absd(pk(c0[-2 * FAST_RW - 2], c1[-2 * FAST_RW - 2]), v));
+        const fast_us2 md2 = __builtin_elementwise_max(absd(pk(c0[-2 * FAST_RW + 2], c1[-2 * FAST_RW + 2]), v), absd(pk(c0[2 * FAST_RW - 2], c1[2 * FAST_RW - 2]), v));
+        const fast_us2 mall = __builtin_elementwise_min(__builtin_elementwise_min(m1, mh), __builtin_elementwise_min(md1, md2));
+        const uint32_t s2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mall, tt)) & inmask;
+        if (s2 & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane);
+        if (s2 >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64);
     }
     __syncthreads();
     // Phase B — segment test + cornerScore<16> on the queued positions only
