@@ -55,6 +55,12 @@ struct DevBuf {
         HIP_CHECK(hipMalloc(&p, want));
         cap = want;
     }
+    void reserve_cap(size_t want) {            // exactly `want` bytes of capacity (no growth slack)
+        if (want <= cap) return;
+        release();
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -70,6 +76,7 @@ struct PinBuf {
         HIP_CHECK(hipHostMalloc(&p, bytes + 256, hipHostMallocDefault));
         cap = bytes + 256;
     }
+    void reserve_cap(size_t want) { if (want > cap) reserve(want - 256); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 

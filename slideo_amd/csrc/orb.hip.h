@@ -166,6 +166,42 @@ __device__ __forceinline__ fast_s2 fast_swap(fast_s2 a) { return __builtin_shuff
 
 __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsigned)(a - v + t) > (unsigned)(2 * t); }   // |a - v| > t
 
+// A block walks FAST_TPB consecutive tiles.  The raw pixels of tile i+1 are fetched into registers right after
+// tile i's have been committed to LDS, so the global-load latency (the longest single wait of a tile: about 10 k of
+// its 25 k cycles, per-wave s_memtime profile) overlaps tile i's three phases.
+constexpr int FAST_TPB = 8;
+constexpr int FAST_NDW = FAST_RW / 4;                                  // dwords per raw row
+constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dwords per thread and tile
+
+struct FastTile { int l, x0, y0, xa, xoff; };
+
+__device__ __forceinline__ FastTile fast_tile_geo(const PyrGeom& g, int tile_id) {
+    FastTile T;
+    T.l = level_of_tile(g, tile_id, false);
+    const LevelGeom& L = g.lv[T.l];
+    const int tile = tile_id - L.ftile0;
+    const int ty = tile / L.ftx, tx = tile - ty * L.ftx;
+    T.x0 = L.rx0 + tx * FAST_TW; T.y0 = L.ry0 + ty * FAST_TH;
+    T.xa = (T.x0 - 4) & ~3; T.xoff = (T.x0 - 4) - T.xa;                // raw columns start at the dword-aligned xa <= x0-4
+    return T;
+}
+
+// raw tile: rows y0-4 .. y0+TH+3, aligned dword loads, clamped to the level (clamped values are never scored)
+__device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTile& T, const uint8_t* __restrict__ frame_pyr,
+                                                 uint32_t (&v)[FAST_NLD]) {
+    const LevelGeom& L = g.lv[T.l];
+    const uint8_t* img = frame_pyr + L.ofs;
+    const int maxd = (L.pitch >> 2) - 1;
+#pragma unroll
+    for (int k = 0; k < FAST_NLD; ++k) {
+        const int i = min((int)threadIdx.x + 256 * k, FAST_NDW * FAST_RH - 1);
+        const int ry = i / FAST_NDW, rd = i - ry * FAST_NDW;
+        const int gy = min(max(T.y0 - 4 + ry, 0), L.h - 1);
+        const int gd = min((T.xa >> 2) + rd, maxd);
+        v[k] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
+    }
+}
+
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist) {
@@ -174,40 +210,29 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     __shared__ uint16_t queue[FAST_SW * FAST_SH];
     __shared__ uint32_t qn;
     const int f = blockIdx.y;
-    const int l = level_of_tile(g, blockIdx.x, false);
-    const LevelGeom L = g.lv[l];
-    const int tile = blockIdx.x - L.ftile0;
-    const int ty = tile / L.ftx, tx = tile - ty * L.ftx;
-    const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH;
-    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    const uint8_t* frame_pyr = pyr + (int64_t)f * g.frame_bytes;
     const int t = g.fast_thr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // raw tile: rows y0-4 .. y0+TH+3, columns from the dword-aligned xa <= x0-4; aligned dword loads
-    const int xa = (x0 - 4) & ~3, xoff = (x0 - 4) - xa;          // xoff in 0..3
-    {
-        constexpr int ndw = FAST_RW / 4;
-        const int maxd = (L.pitch >> 2) - 1;
-        // all of a thread's loads are issued before the first LDS store (a rolled loop waited for each one in turn,
-        // and the kernel spent 3/4 of its time there)
-        constexpr int NLD = (ndw * FAST_RH + 255) / 256;
-        uint32_t v[NLD];
+    const int first = blockIdx.x * FAST_TPB;
+    FastTile T = fast_tile_geo(g, first);
+    uint32_t pre[FAST_NLD];
+    fast_issue_loads(g, T, frame_pyr, pre);
+    for (int it = 0; it < FAST_TPB && first + it < g.fast_tiles; ++it) {
+    if (it) __syncthreads();                                   // the previous tile's readers of raw / sc / queue are done
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = min((int)threadIdx.x + 256 * k, ndw * FAST_RH - 1);
-            const int ry = i / ndw, rd = i - ry * ndw;
-            const int gy = min(max(y0 - 4 + ry, 0), L.h - 1);
-            const int gd = min((xa >> 2) + rd, maxd);
-            v[k] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = (int)threadIdx.x + 256 * k;
-            if (i < ndw * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = v[k];
-        }
+    for (int k = 0; k < FAST_NLD; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < FAST_NDW * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = pre[k];
     }
     if (threadIdx.x == 0) qn = 0;
     for (int i = threadIdx.x; i < FAST_SW * FAST_SH / 16; i += 256) reinterpret_cast<uint4*>(&sc[0][0])[i] = make_uint4(0, 0, 0, 0);
+    // next tile's pixels (always issued — past the end the last tile is re-read and dropped — so that `pre` stays a
+    // plain register array)
+    const FastTile Tn = fast_tile_geo(g, min(first + it + 1, g.fast_tiles - 1));
+    fast_issue_loads(g, Tn, frame_pyr, pre);
+    const int l = T.l;
+    const LevelGeom& L = g.lv[l];
+    const int x0 = T.x0, y0 = T.y0, xoff = T.xoff;
     __syncthreads();
     // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...,
     // lane covers sx = lane and lane + 64 (no divisions, constant LDS offsets).  Every arc of 9 contains one pixel of
@@ -329,6 +354,8 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
             }
         }
     }
+    T = Tn;
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------

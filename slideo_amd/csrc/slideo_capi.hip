@@ -61,6 +61,20 @@ struct Slot {
     int64_t ticket = 0;
     int n = 0;
     bool timed = false;
+
+    // Give this (idle) slot the capacities of `o`.  A slot used for the first time would otherwise grow its ~25 buffers
+    // (hipFree + hipMalloc, device-wide stalls, tens of ms for the GB-sized ones) in the middle of a steady-state
+    // stream of batches; sizing both slots when the first one grows keeps every later unit allocation-free.
+    void match_capacity(const Slot& o) {
+        DevBuf* mine[] = {&d_stage, &d_pyr, &d_blur, &d_cand, &d_hist, &d_candcount, &d_flags, &d_thr, &d_lvlofs, &d_kpcount, &d_qofs,
+                          &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs};
+        const DevBuf* theirs[] = {&o.d_stage, &o.d_pyr, &o.d_blur, &o.d_cand, &o.d_hist, &o.d_candcount, &o.d_flags, &o.d_thr, &o.d_lvlofs,
+                                  &o.d_kpcount, &o.d_qofs, &o.d_info, &o.d_items, &o.d_kp, &o.d_desc, &o.d_keys, &o.d_knn_pend, &o.d_votes,
+                                  &o.d_gpts, &o.d_gmask, &o.d_fcs, &o.d_verdicts, &o.d_pairs};
+        static_assert(sizeof(mine) / sizeof(mine[0]) == sizeof(theirs) / sizeof(theirs[0]), "same buffer lists");
+        for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); ++i) mine[i]->reserve_cap(theirs[i]->cap);
+        h_info.reserve_cap(o.h_info.cap); h_out.reserve_cap(o.h_out.cap);
+    }
 };
 
 }  // namespace
@@ -221,7 +235,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         check_launch("resize_kernel");
     }
     if (g.fast_tiles > 0) {
-        fast_kernel<<<dim3(g.fast_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
+        fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
         check_launch("fast_kernel");
     }
     if (g.blur_tiles > 0) {
@@ -838,6 +852,7 @@ int32_t slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames, cons
     S.ticket = m->next_ticket++;
     *ticket_out = S.ticket;
     m->next_slot ^= 1;
+    if (Slot& O = m->slots[m->next_slot]; !O.busy) O.match_capacity(S);     // the next unit finds its workspace sized
     API_CATCH(m)
 }
 
