@@ -407,19 +407,21 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
     for (int i = 0; i < 7; ++i) kk[i] = k[i] | (k[i] << 16);
     // ring of the last 7 source rows, each as two packed-u16 dwords: A = (p0,p1), B = (p2,p3)
     uint32_t ra[7], rb[7];
-    auto fetch = [&](int y, uint32_t& A, uint32_t& B) {
-        uint32_t d = blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs);
+    auto load = [&](int y) { return blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs); };
+    auto unpack = [&](uint32_t d, uint32_t& A, uint32_t& B) {
         A = __builtin_amdgcn_perm(0u, d, 0x0C010C00u);             // bytes: [p0, 0, p1, 0]
         B = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);             // bytes: [p2, 0, p3, 0]
     };
 #pragma unroll
-    for (int j = 0; j < 6; ++j) fetch(y0 - 3 + j, ra[j], rb[j]);
+    for (int j = 0; j < 6; ++j) unpack(load(y0 - 3 + j), ra[j], rb[j]);
     const bool inner = lane >= 1 && lane <= 62;
+    uint32_t dnext = load(y0 + 3);                                  // newest row of output row 0, one row ahead from here on
     for (int gI = 0; gI < BLUR_RH / 7; ++gI) {
 #pragma unroll
         for (int ph = 0; ph < 7; ++ph) {
             const int i = gI * 7 + ph;                              // output row y0 + i; taps are rows y0+i-3+j in ring[(ph+j)%7]
-            fetch(y0 + i + 3, ra[(ph + 6) % 7], rb[(ph + 6) % 7]);
+            unpack(dnext, ra[(ph + 6) % 7], rb[(ph + 6) % 7]);
+            dnext = load(y0 + i + 4);                               // in flight while this row is computed
             uint32_t va = 0, vb = 0;                                // packed vertical sums (<= 65280 each)
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
