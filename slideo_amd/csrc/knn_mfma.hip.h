@@ -21,12 +21,13 @@
 //   queries (B operand): lane l holds query (l & 31), expands packed dword 2s + (l >> 5) in
 //     registers at kernel start (16 VGPRs).
 //   accumulator: lane l holds column (query) l & 31, rows (r&3) + 8*(r>>2) + 4*(l>>5).
-//   top-k: 32 sorted keys in VGPRs of the query's owner lane; candidates reach it through a small
-//     pending buffer in LDS (see the kernel comment); train segments are merged by knn_merge_kernel.
+//   top-k: 32 sorted keys per query in the OUTPUT buffer; candidates are pushed to per-lane pending buffers in a
+//     global workspace and merged by the query's owner lane in a flush (see the kernel comment); train segments
+//     are merged by knn_merge_kernel.
 //
-// Block = 8 waves = 512 queries sharing the A tiles through LDS (super-tiles of 128 rows =
-// 16 KB, double buffered, one barrier per super-tile).  Fast path per tile and wave:
-// 4 ds_read_b128 + 8 MFMA + max-of-16 twice + 2 compares.
+// Block = 8 waves = 512 queries sharing the A tiles through LDS: super-tiles of 128 rows = 16 KB go through a
+// 4-slot ring filled by LDS-DMA and guarded by per-slot counters — no block barrier in the main loop.  Fast path
+// per tile and wave: 4 ds_read_b128 + 8 MFMA + 2 x 8 v_max3_i32 + 2 compares.
 #pragma once
 #include <limits.h>
 #include <hip/hip_runtime.h>
@@ -54,7 +55,6 @@ constexpr int KM_RING = KM_RING_;                     // LDS ring slots (super-t
 #endif
 constexpr int KM_AHEAD = KM_AHEAD_;                    // a super-tile is staged this many iterations before it is consumed
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
-constexpr int KM_STAGE = KM_ST_U4 / KM_THREADS;  // uint4 staged per thread and super-tile
 
 // 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if 0, 0xA (-1.0) if 1; bit i -> nibble i.
 __host__ __device__ __forceinline__ uint32_t fp4_expand8(uint32_t byte) {
@@ -89,14 +89,16 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 //
 // Epilogue, fast path (no cross-lane traffic): every lane keeps the thresholds of BOTH its queries
 // (thrA, thrB) and compares them with the maxima of its two accumulator tiles.
-// Slow path: a lane whose accumulator beats the threshold PUSHES the candidate key into the owner's small
-// pending buffer in LDS (ds_add_rtn slot + ds_write); nothing is inserted yet.  When some owner has
-// KM_FLUSH_AT pending keys the wave flushes: owners insert their pending keys (v_med3 chain), thresholds are
-// refreshed and re-broadcast.  This batches the divergent part: an insert costs the whole wave ~35 VALU
+// Slow path: a lane whose accumulator beats the threshold PUSHES the candidate key into its own pending buffer
+// (one per lane and query tile, global memory, count in a register); nothing is inserted yet.  When some lane has
+// KM_FLUSH_AT keys pending the wave flushes between two tiles: every owner lane loads its list, inserts the keys
+// its two source lanes pushed (v_med3 chain, KM_FLUSH_BATCH loads in flight), stores the list, and the new
+// thresholds are re-broadcast.  This batches the divergent part: an insert costs the whole wave ~35 VALU
 // instructions, and without batching it ran for what is usually ONE lane's candidate.
-// Exactness: rows are offered in ascending 8-row groups and thresholds only tighten at a flush, so a
-// candidate with the k-th distance and a higher row than everything in the list is (correctly) rejected by the
-// strict filter, and nothing that belongs to the final top-k is ever filtered out.
+// Exactness: thresholds only tighten, and only in a flush, which runs between tiles; every row of the tile being
+// scored is higher than every row already in a list, so a candidate with exactly the k-th distance is (correctly)
+// rejected by the strict filter, and nothing that belongs to the final top-k is ever filtered out.  With
+// prune_tol > 0 the threshold is additionally capped by the vote's acceptance bound (see the flush).
 #ifndef KM_FLUSH_AT_
 #define KM_FLUSH_AT_ 16
 #endif
