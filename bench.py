@@ -73,10 +73,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # SLIDEO_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks (ranks then
+    # share devices and the verdict all-gather goes through host memory); the driver's runs use nccl = RCCL.
+    backend = os.environ.get("SLIDEO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from slideo_amd import _capi, synth
 
@@ -109,8 +117,9 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()          # inputs resident in HBM before timing
     stream = torch.cuda.current_stream().cuda_stream
     verdict_words = 4
-    d_verdicts = torch.zeros((B, verdict_words), dtype=torch.int32, device="cuda")
-    d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device="cuda") if world > 1 else None
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    d_verdicts = torch.zeros((B, verdict_words), dtype=torch.int32, device=coll_dev)
+    d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device=coll_dev) if world > 1 else None
 
     def finish(v):
         if world > 1:
@@ -150,7 +159,7 @@ def main():
     prof, knn_pairs = m.read_profile()
     m.set_profiling(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -1,0 +1,49 @@
+"""bench.py output contract: one JSON line from rank 0 with the fields the driver reads, at N=1 and — control flow
+only, both ranks on one GPU over gloo — at N=2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    for k in REQUIRED + ["cpu_baseline"]:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["value"] > 0 and j["scaling"] == "weak" and j["data"] == "synthetic" and "workload" in j["config"]
+    rf = j["roofline"]
+    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["verdict_agreement_with_gpu"] == 1.0
+
+
+def test_two_ranks_control_flow_over_gloo():
+    env = dict(os.environ, SLIDEO_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and "cpu_baseline" not in j       # the CPU leg runs at N=1 only
+    assert j["config"]["frames_per_step_per_gpu"] == 16 and j["value"] > 0
