@@ -79,59 +79,78 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), 0u, false);
 }
 
+// A thread makes the same 4 columns of RESIZE_ROWS consecutive output rows: the x tables are fetched once, and
+// all of the thread's row-table entries, then all of its 6 x RESIZE_ROWS source dwords, are in flight together
+// (the kernel is latency bound: table -> address -> data is two dependent round trips per output dword).
+constexpr int RESIZE_ROWS = 4;
+
 __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
                                                      LevelGeom src, LevelGeom dst,
                                                      const uint32_t* __restrict__ lin_tab, int nxq, uint32_t nxq_magic) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    const int y = nxq_magic ? (int)__umulhi(t, nxq_magic) : (int)t;      // t / nxq (exact, see build_pyr_geom)
-    if (y >= dst.h) return;
-    const int x0 = ((int)t - (int)__umul24(y, nxq)) * 4;
+    const int yg = nxq_magic ? (int)__umulhi(t, nxq_magic) : (int)t;     // t / nxq (exact, see build_pyr_geom)
+    const int y0 = yg * RESIZE_ROWS;
+    if (y0 >= dst.h) return;
+    const int x0 = ((int)t - (int)__umul24(yg, nxq)) * 4;
     uint8_t* base = pyr + (int64_t)blockIdx.z * pyr_frame_bytes;
-    const uint32_t ye = lin_tab[dst.ytab_ofs + y];
-    const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
-    const uint8_t* r0 = base + src.ofs + __umul24(yo, src.pitch);
-    const uint8_t* r1 = base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch);
     const int nx = min(4, dst.w - x0);
     // both x tables are 16-byte aligned and padded to a multiple of 4 entries with copies of the last one
     const uint4 xq = *reinterpret_cast<const uint4*>(lin_tab + dst.xtab_ofs + x0);
     const uint4 cq = *reinterpret_cast<const uint4*>(lin_tab + dst.xctab_ofs + x0);
+    uint32_t ye[RESIZE_ROWS];
+#pragma unroll
+    for (int r = 0; r < RESIZE_ROWS; ++r) ye[r] = lin_tab[dst.ytab_ofs + min(y0 + r, dst.h - 1)];
     const uint32_t xe[4] = {xq.x, xq.y, xq.z, xq.w};
     const uint32_t cp[4] = {cq.x, cq.y, cq.z, cq.w};
     const int xa = (int)(xe[0] & 0xffff) & ~3;         // aligned start; rows are 16-byte aligned with pitch % 16 == 0
-    uint32_t v[4];
-    if ((int)(xe[3] & 0xffff) + 1 - xa < 12) {
-        const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
-        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0);
-        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1);
-        const int i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd);
-        const uint32_t a0 = p0[d0], a1 = p0[i1], a2 = p0[i2];
-        const uint32_t b0 = p1[d0], b1 = p1[i1], b2 = p1[i2];
+    const bool narrow = (int)(xe[3] & 0xffff) + 1 - xa < 12;
+    const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
+    const int i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd);
+    uint32_t a[RESIZE_ROWS][3], b[RESIZE_ROWS][3];     // (loaded unconditionally: a conditionally filled array would live in scratch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // tap 2 is byte p+1 even at the right edge: there c1 == 0, so its value is irrelevant
-            const int p = (int)(xe[i] & 0xffff) - xa;                    // 0..10
-            const bool up = p >= 4;
-            const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
-            const uint32_t ta = __builtin_amdgcn_perm(up ? a2 : a1, up ? a1 : a0, sel);
-            const uint32_t tb = __builtin_amdgcn_perm(up ? b2 : b1, up ? b1 : b0, sel);
-            v[i] = __umul24(cy0, dot2_u16(ta, cp[i])) + (__umul24(cy1, dot2_u16(tb, cp[i])) + (1u << 15));   // 9 x 16 bits: full-rate 24-bit multiplies
-        }
-    } else {      // (shrink factors >= 2; kept for generality)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
-            const int xo1 = min(xo + 1, src.w - 1);
-            uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
-            uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
-            v[i] = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15);
-        }
+    for (int r = 0; r < RESIZE_ROWS; ++r) {
+        const int yo = ye[r] & 0xffff;
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(base + src.ofs + __umul24(yo, src.pitch));
+        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch));
+        a[r][0] = p0[d0]; a[r][1] = p0[i1]; a[r][2] = p0[i2];
+        b[r][0] = p1[d0]; b[r][1] = p1[i1]; b[r][2] = p1[i2];
     }
-    // result byte = bits 16..23 of each v (v < 2^24)
-    const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
-                                                __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
-    uint8_t* d = base + dst.ofs + __umul24(y, dst.pitch) + x0;
-    if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
-    else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));
+#pragma unroll
+    for (int r = 0; r < RESIZE_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= dst.h) break;
+        const int yo = ye[r] & 0xffff, cy1 = ye[r] >> 16, cy0 = 256 - cy1;
+        uint32_t v[4];
+        if (narrow) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // tap 2 is byte p+1 even at the right edge: there c1 == 0, so its value is irrelevant
+                const int p = (int)(xe[i] & 0xffff) - xa;                    // 0..10
+                const bool up = p >= 4;
+                const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
+                const uint32_t ta = __builtin_amdgcn_perm(up ? a[r][2] : a[r][1], up ? a[r][1] : a[r][0], sel);
+                const uint32_t tb = __builtin_amdgcn_perm(up ? b[r][2] : b[r][1], up ? b[r][1] : b[r][0], sel);
+                v[i] = __umul24(cy0, dot2_u16(ta, cp[i])) + (__umul24(cy1, dot2_u16(tb, cp[i])) + (1u << 15));   // 9 x 16 bits: full-rate 24-bit multiplies
+            }
+        } else {      // (shrink factors >= 2; kept for generality)
+            const uint8_t* r0 = base + src.ofs + __umul24(yo, src.pitch);
+            const uint8_t* r1 = base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xo = xe[i] & 0xffff, cx1 = xe[i] >> 16, cx0 = 256 - cx1;
+                const int xo1 = min(xo + 1, src.w - 1);
+                uint32_t h0 = (uint32_t)cx0 * r0[xo] + (uint32_t)cx1 * r0[xo1];
+                uint32_t h1 = (uint32_t)cx0 * r1[xo] + (uint32_t)cx1 * r1[xo1];
+                v[i] = (uint32_t)cy0 * h0 + (uint32_t)cy1 * h1 + (1u << 15);
+            }
+        }
+        // result byte = bits 16..23 of each v (v < 2^24)
+        const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
+                                                    __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
+        uint8_t* d = base + dst.ofs + __umul24(y, dst.pitch) + x0;
+        if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
+        else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));
+    }
 }
 
 // ---------------------------------------------------------------------------

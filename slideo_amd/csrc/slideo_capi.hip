@@ -229,7 +229,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         // exactly while nxq^2 * h < 2^32, which MAX_DIM guarantees
         const int nxq = cdiv(g.lv[l].w, 4);
         const uint32_t magic = nxq > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)nxq - 1) / (uint64_t)nxq) : 0u;
-        dim3 grid(cdiv(nxq * g.lv[l].h, 256), 1, n);
+        dim3 grid(cdiv(nxq * cdiv(g.lv[l].h, RESIZE_ROWS), 256), 1, n);
         resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
                                             nxq, magic);
         check_launch("resize_kernel");
