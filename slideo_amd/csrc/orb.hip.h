@@ -647,15 +647,25 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
     const uint8_t* bl = blur + (int64_t)f * g.frame_bytes + L.ofs;
     const int half = g.half_patch;
     // intensity centroid over the disc |u| <= umax[|v|], lanes across u
+    // (rows are read 8 at a time, unconditionally — the whole square lies inside the level — and masked by the disc
+    // afterwards: the rolled, predicated loop waited for one byte load per row, 63 dependent L2 round trips per keypoint)
     int m10 = 0, m01 = 0;
     for (int u0 = -half; u0 <= half; u0 += 64) {
-        const int u = u0 + lane;
-        if (u <= half) {
-            for (int v = -half; v <= half; ++v) {
-                const int av = v < 0 ? -v : v;
-                if ((u < 0 ? -u : u) <= tab->umax[av]) {
-                    int p = img[(int64_t)(py + v) * L.pitch + px + u];
-                    m10 += u * p; m01 += v * p;
+        const int u = min(u0 + lane, half);
+        const bool lane_in = u0 + lane <= half;
+        const int au = u < 0 ? -u : u;
+        const uint8_t* col = img + (int64_t)(py - half) * L.pitch + px + u;
+        for (int v0 = -half; v0 <= half; v0 += 8) {
+            int p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = col[(int64_t)min(v0 + k + half, 2 * half) * L.pitch];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = v0 + k;
+                if (v <= half) {                                    // wave-uniform
+                    const int av = v < 0 ? -v : v;
+                    const int pv = (lane_in && au <= tab->umax[av]) ? p[k] : 0;
+                    m10 += u * pv; m01 += v * pv;
                 }
             }
         }
@@ -674,9 +684,9 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const int pair = lane + 64 * w;          // descriptor bit index
-        const int i0 = 2 * pair, i1 = i0 + 1;
-        const float p0x = (float)tab->pattern[2 * i0], p0y = (float)tab->pattern[2 * i0 + 1];
-        const float p1x = (float)tab->pattern[2 * i1], p1y = (float)tab->pattern[2 * i1 + 1];
+        const uint32_t pw = reinterpret_cast<const uint32_t*>(tab->pattern)[pair];          // (x0, y0, x1, y1) as int8
+        const float p0x = (float)(int8_t)(pw & 255), p0y = (float)(int8_t)((pw >> 8) & 255);
+        const float p1x = (float)(int8_t)((pw >> 16) & 255), p1y = (float)(int8_t)(pw >> 24);
         const float x0 = p0x * a - p0y * b, y0 = p0x * b + p0y * a;
         const float x1 = p1x * a - p1y * b, y1 = p1x * b + p1y * a;
         const int t0 = bl[(int64_t)(cy + (int)rintf(y0)) * L.pitch + cx + (int)rintf(x0)];
