@@ -26,6 +26,7 @@ using namespace slideo;
 namespace {
 
 constexpr int KLIST = 32;
+static_assert(KLIST == VOTE_KLIST, "vote_kernel reads whole key lists");
 
 struct GeomEntry {
     int w = 0, h = 0;

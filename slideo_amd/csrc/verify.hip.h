@@ -27,6 +27,7 @@
 
 namespace slideo {
 
+constexpr int VOTE_KLIST = 32;   // key-list stride of the kNN stage (KLIST in slideo_capi.hip; checked there)
 constexpr int MAXC = 64;       // >= max_candidate_pages
 constexpr int MAXR = 16;       // >= max_rated
 constexpr int RANSAC_LDS_PTS = 1024;    // point pairs kept in LDS (more go through global memory); 17 KB per 64-thread block = 9 blocks per CU
@@ -80,26 +81,32 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
 
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q0 = qofs[f], n = qofs[f + 1] - q0;
-    const int k = vp.k, KL = vp.klist;
+    const int k = vp.k;
     FrameCands& fc = fcs[f];
     for (int i = tid; i < npages; i += 256) { counts[i] = 0; rank[i] = 0xFF; }
     __syncthreads();
-    const uint32_t total = n * (uint32_t)k;
     // tolerance vote: d < best * tol (f32, strict)      lib.rs:275
-    auto passes = [&](uint32_t e, uint32_t& tidx) -> bool {
-        uint32_t q = e / (uint32_t)k, r = e - q * (uint32_t)k;
-        const uint32_t* kq = keys + (size_t)(q0 + q) * KL;
-        uint32_t key = kq[r];
-        if (key == KNN_EMPTY) return false;
-        float best = (float)(kq[0] >> KNN_KEY_SHIFT);
-        float lim = best * vp.tol;
-        tidx = key & KNN_IDX_MASK;
-        return (float)(key >> KNN_KEY_SHIFT) < lim;
+    // A thread owns a contiguous run of queries.  Per query it fetches the whole sorted key list with 8 x 16-byte
+    // loads in flight (entry by entry, every key cost a dependent round trip), and because the list is sorted the
+    // entries that pass `d < lim` are a prefix of it.
+    const uint32_t runq = (n + 255) / 256;
+    const uint32_t qa = min(n, (uint32_t)tid * runq), qb = min(n, qa + runq);
+    auto for_each_vote = [&](auto&& fn) {
+        for (uint32_t q = qa; q < qb; ++q) {
+            const uint4* kq4 = reinterpret_cast<const uint4*>(keys + (size_t)(q0 + q) * VOTE_KLIST);
+            uint32_t key[VOTE_KLIST];
+#pragma unroll
+            for (int i = 0; i < VOTE_KLIST / 4; ++i) { const uint4 v = kq4[i]; key[4 * i] = v.x; key[4 * i + 1] = v.y; key[4 * i + 2] = v.z; key[4 * i + 3] = v.w; }
+            const float lim = (float)(key[0] >> KNN_KEY_SHIFT) * vp.tol;
+#pragma unroll
+            for (int r = 0; r < VOTE_KLIST; ++r) {
+                const bool pass = r < k && key[r] != KNN_EMPTY && (float)(key[r] >> KNN_KEY_SHIFT) < lim;
+                if (!pass) break;                                        // sorted list: nothing further passes
+                fn(q, key[r] & KNN_IDX_MASK);
+            }
+        }
     };
-    for (uint32_t e = tid; e < total; e += 256) {
-        uint32_t t;
-        if (passes(e, t)) atomicAdd(&counts[train_page[t]], 1u);
-    }
+    for_each_vote([&](uint32_t, uint32_t t) { atomicAdd(&counts[train_page[t]], 1u); });
     __syncthreads();
     // top max_cand pages by (count desc, page asc)       lib.rs:284-295
     int nc = 0;
@@ -137,14 +144,9 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
     }
     __syncthreads();
     if (nc == 0) return;
-    // ordered placement: each thread owns a contiguous run of entries (q asc, r asc)
-    const uint32_t run = (total + 255) / 256;
-    const uint32_t e0 = min(total, tid * run), e1 = min(total, e0 + run);
+    // ordered placement: each thread owns a contiguous run of queries, i.e. of entries in (q asc, r asc) order
     for (int c = 0; c < nc; ++c) runcnt[c * 256 + tid] = 0;
-    for (uint32_t e = e0; e < e1; ++e) {
-        uint32_t t;
-        if (passes(e, t)) { uint8_t r = rank[train_page[t]]; if (r != 0xFF) runcnt[r * 256 + tid]++; }
-    }
+    for_each_vote([&](uint32_t, uint32_t t) { uint8_t r = rank[train_page[t]]; if (r != 0xFF) runcnt[r * 256 + tid]++; });
     __syncthreads();
     // exclusive scan over the 256 threads, per candidate (wave w takes candidates w, w+4, ...)
     for (int c = wave; c < nc; c += 4) {
@@ -160,16 +162,13 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
     }
     __syncthreads();
     uint2* vout = votes + (size_t)q0 * k;
-    for (uint32_t e = e0; e < e1; ++e) {
-        uint32_t t;
-        if (passes(e, t)) {
-            uint8_t r = rank[train_page[t]];
-            if (r != 0xFF) {
-                uint32_t pos = (uint32_t)s_ofs[r] + runcnt[r * 256 + tid]++;
-                vout[pos] = make_uint2(e / (uint32_t)k, t);
-            }
+    for_each_vote([&](uint32_t q, uint32_t t) {
+        uint8_t r = rank[train_page[t]];
+        if (r != 0xFF) {
+            uint32_t pos = (uint32_t)s_ofs[r] + runcnt[r * 256 + tid]++;
+            vout[pos] = make_uint2(q, t);
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------
