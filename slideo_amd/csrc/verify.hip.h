@@ -276,11 +276,22 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
     const uint2* vt = votes + vbase;
     float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
     uint8_t* mask = count <= RANSAC_LDS_PTS ? lmask : gmask + vbase;
-    for (int i = lane; i < count; i += 64) {
-        uint2 v = vt[i];
-        float2 s = page_xy[v.y];
-        const slideo_keypoint& kq = frame_kp[qofs[f] + v.x];
-        pts[i] = make_float4(s.x, s.y, kq.x, kq.y);     // from = slide pt, to = frame pt   lib.rs:299-302
+    // (4 votes per lane and round: the three dependent gathers of a vote — vote, slide point, frame keypoint — are
+    // each issued for all four before the first is used)
+    const uint32_t qbase_f = qofs[f];
+    for (int i0 = lane; i0 < count; i0 += 256) {
+        uint2 v[4]; float2 s[4]; float2 kq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = vt[min(i0 + 64 * u, count - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u] = page_xy[v[u].y];
+            const slideo_keypoint* kp = frame_kp + qbase_f + v[u].x;
+            kq[u] = *reinterpret_cast<const float2*>(&kp->x);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 64 * u < count) pts[i0 + 64 * u] = make_float4(s[u].x, s[u].y, kq[u].x, kq[u].y);   // from = slide pt, to = frame pt   lib.rs:299-302
     }
     __syncthreads();
     double bestM[6] = {0, 0, 0, 0, 0, 0};
