@@ -189,6 +189,7 @@ __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsi
 // tile i's have been committed to LDS, so the global-load latency (the longest single wait of a tile: about 10 k of
 // its 25 k cycles, per-wave s_memtime profile) overlaps tile i's three phases.
 constexpr int FAST_TPB = 8;
+constexpr int FAST_STAGE_CAP = 1024;                                   // survivors staged per block before one list append
 constexpr int FAST_NDW = FAST_RW / 4;                                  // dwords per raw row
 constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dwords per thread and tile
 
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
     __shared__ uint16_t queue[FAST_SW * FAST_SH];
     __shared__ uint32_t qn;
+    // survivors of the block's tiles are staged in LDS and appended to the level's candidate list with ONE returning
+    // global atomic per flush (a flush per tile kept every tile waiting for its own round trip); same for the histogram
+    __shared__ uint32_t stage[FAST_STAGE_CAP], shist[256], nstage, stage_end, stage_base;
     const int f = blockIdx.y;
     const uint8_t* frame_pyr = pyr + (int64_t)f * g.frame_bytes;
     const int t = g.fast_thr;
@@ -236,8 +240,32 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     FastTile T = fast_tile_geo(g, first);
     uint32_t pre[FAST_NLD];
     fast_issue_loads(g, T, frame_pyr, pre);
+    shist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { nstage = 0; stage_end = 0xFFFFFFFFu; }
+    int stage_level = T.l;
+    auto flush = [&](int lvl) {                                // called by the whole block, after a barrier
+        const uint32_t ns = min(min(nstage, (uint32_t)FAST_STAGE_CAP), stage_end);   // reservations are monotonic: the staged ones are a prefix
+        if (threadIdx.x == 0 && ns) stage_base = atomicAdd(cand_count + (size_t)f * g.nlevels + lvl, ns);
+        __syncthreads();
+        if (ns) {
+            const LevelGeom& Ls = g.lv[lvl];
+            uint32_t* clist = cand + (size_t)f * g.cand_per_frame + Ls.cand_ofs;
+            const uint32_t base = stage_base;
+            for (uint32_t i = threadIdx.x; i < ns; i += 256)
+                if (base + i < (uint32_t)Ls.cand_cap) clist[base + i] = stage[i];
+            const uint32_t hv = shist[threadIdx.x];
+            if (hv) atomicAdd(hist + ((size_t)f * g.nlevels + lvl) * 256 + threadIdx.x, hv);
+            shist[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { nstage = 0; stage_end = 0xFFFFFFFFu; }
+    };
     for (int it = 0; it < FAST_TPB && first + it < g.fast_tiles; ++it) {
-    if (it) __syncthreads();                                   // the previous tile's readers of raw / sc / queue are done
+    if (it) {
+        __syncthreads();                                       // the previous tile's readers of raw / sc / queue are done
+        if (T.l != stage_level || nstage > (uint32_t)FAST_STAGE_CAP / 2) flush(stage_level);
+        stage_level = T.l;
+    }
 #pragma unroll
     for (int k = 0; k < FAST_NLD; ++k) {
         const int i = (int)threadIdx.x + 256 * k;
@@ -362,19 +390,28 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         }
         const uint64_t msk = __builtin_amdgcn_ballot_w64(keep);
         if (msk) {
+            const uint32_t cnt = (uint32_t)__popcll(msk);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(ccount, (uint32_t)__popcll(msk));
+            if (lane == 0) base = atomicAdd(&nstage, cnt);             // LDS
             base = __shfl(base, 0);
-            if (keep) {
-                uint32_t pos = base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull));
-                if (pos < (uint32_t)L.cand_cap)
-                    clist[pos] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-                atomicAdd(h + s, 1u);
+            const uint32_t entry = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+            if (base + cnt <= (uint32_t)FAST_STAGE_CAP) {
+                if (keep) { stage[base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull))] = entry; atomicAdd(&shist[s], 1u); }
+            } else {                                                   // staging full (pathological tile): straight to the list
+                if (lane == 0) { atomicMin(&stage_end, base); base = atomicAdd(ccount, cnt); }
+                base = __shfl(base, 0);
+                if (keep) {
+                    uint32_t pos = base + (uint32_t)__popcll(msk & ((1ull << lane) - 1ull));
+                    if (pos < (uint32_t)L.cand_cap) clist[pos] = entry;
+                    atomicAdd(h + s, 1u);
+                }
             }
         }
     }
     T = Tn;
     }   // tile loop
+    __syncthreads();
+    flush(stage_level);
 }
 
 // ---------------------------------------------------------------------------
