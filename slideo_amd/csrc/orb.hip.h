@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ f
 // (shrink factors < 2), fetched as 3 aligned dwords; the two taps of an output are picked with one
 // v_perm_b32 (selector built from the byte offset) and weighted with one v_dot2_u32_u16 against the
 // pre-packed (256-c1, c1) pair.  grid (ceil(nxq*dh/256), 1, B), nxq = ceil(dw/4).
-__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b) {
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c = 0u) {      // a.lo*b.lo + a.hi*b.hi + c
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), 0u, false);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
 // A thread makes the same 4 columns of RESIZE_ROWS consecutive output rows: the x tables are fetched once, and
@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
     uint32_t kk[7];                                                // tap replicated in both halves for packed math
 #pragma unroll
     for (int i = 0; i < 7; ++i) kk[i] = k[i] | (k[i] << 16);
+    // tap pairs for the horizontal pass: (lo, hi) multiply the (lo, hi) column of a packed pair
+    const uint32_t k01 = k[0] | (k[1] << 16), k12 = k[1] | (k[2] << 16), k23 = k[2] | (k[3] << 16), k34 = k[3] | (k[4] << 16),
+                   k45 = k[4] | (k[5] << 16), k56 = k[5] | (k[6] << 16), k_0 = k[0] << 16, k6_ = k[6];
     // ring of the last 7 source rows, each as two packed-u16 dwords: A = (p0,p1), B = (p2,p3)
     uint32_t ra[7], rb[7];
     auto load = [&](int y) { return blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs); };
@@ -471,13 +474,14 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
 #pragma unroll
     for (int j = 0; j < 6; ++j) unpack(load(y0 - 3 + j), ra[j], rb[j]);
     const bool inner = lane >= 1 && lane <= 62;
-    uint32_t dnext = load(y0 + 3);                                  // newest row of output row 0, one row ahead from here on
+    uint32_t dn0 = load(y0 + 3), dn1 = load(y0 + 4), dn2 = load(y0 + 5);   // newest rows, 3 rows ahead (bandwidth = bytes in flight / latency)
     for (int gI = 0; gI < BLUR_RH / 7; ++gI) {
 #pragma unroll
         for (int ph = 0; ph < 7; ++ph) {
             const int i = gI * 7 + ph;                              // output row y0 + i; taps are rows y0+i-3+j in ring[(ph+j)%7]
-            unpack(dnext, ra[(ph + 6) % 7], rb[(ph + 6) % 7]);
-            dnext = load(y0 + i + 4);                               // in flight while this row is computed
+            unpack(dn0, ra[(ph + 6) % 7], rb[(ph + 6) % 7]);
+            dn0 = dn1; dn1 = dn2;
+            dn2 = load(min(y0 + i + 6, y0 + BLUR_RH + 2));          // (no row past the strip's last tap is fetched)
             uint32_t va = 0, vb = 0;                                // packed vertical sums (<= 65280 each)
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
@@ -488,18 +492,16 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
             // neighbours: left lane's (v1 | v2,v3), right lane's (v0,v1 | v2)
             const uint32_t la = __shfl_up(va, 1), lb = __shfl_up(vb, 1);
             const uint32_t rA = __shfl_down(va, 1), rB = __shfl_down(vb, 1);
-            uint32_t x[10];                                         // vertical sums of columns xs-3 .. xs+6
-            x[0] = la >> 16; x[1] = lb & 0xffff; x[2] = lb >> 16;
-            x[3] = va & 0xffff; x[4] = va >> 16; x[5] = vb & 0xffff; x[6] = vb >> 16;
-            x[7] = rA & 0xffff; x[8] = rA >> 16; x[9] = rB & 0xffff;
-            uint32_t o = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint32_t a = 0;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) a += __umul24(k[j], x[c + j]);   // both < 2^16: full-rate v_mad_u32_u24 (a plain * is a quarter-rate v_mul_lo_u32)
-                o |= ((a + (1u << 15)) >> 16) << (8 * c);
-            }
+            // horizontal pass on the packed pairs, two taps per v_dot2_u32_u16 (sums < 2^24, exact in u32):
+            //   la = (x-1, x0)  lb = (x1, x2)  va = (x3, x4)  vb = (x5, x6)  rA = (x7, x8)  rB = (x9, x10),  x_i = column xs-3+i
+            //   out0 = k0 x0 + (k1,k2).lb + (k3,k4).va + (k5,k6).vb        out1 = (k0,k1).lb + (k2,k3).va + (k4,k5).vb + k6 x7
+            //   out2 = k0 x2 + (k1,k2).va + (k3,k4).vb + (k5,k6).rA        out3 = (k0,k1).va + (k2,k3).vb + (k4,k5).rA + k6 x9
+            const uint32_t a0 = dot2_u16(vb, k56, dot2_u16(va, k34, dot2_u16(lb, k12, dot2_u16(la, k_0, 1u << 15))));
+            const uint32_t a1 = dot2_u16(vb, k45, dot2_u16(va, k23, dot2_u16(lb, k01, dot2_u16(rA, k6_, 1u << 15))));
+            const uint32_t a2 = dot2_u16(rA, k56, dot2_u16(vb, k34, dot2_u16(va, k12, dot2_u16(lb, k_0, 1u << 15))));
+            const uint32_t a3 = dot2_u16(rA, k45, dot2_u16(vb, k23, dot2_u16(va, k01, dot2_u16(rB, k6_, 1u << 15))));
+            // result byte = bits 16..23 of each sum
+            const uint32_t o = __builtin_amdgcn_perm(__builtin_amdgcn_perm(a3, a2, 0x0c0c0602u), __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), 0x05040100u);
             const int gy = y0 + i;
             if (inner && gy < L.h && xs < L.w) {
                 uint8_t* d = out + (int64_t)gy * L.pitch + xs;
