@@ -296,22 +296,36 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     auto absd = [](fast_us2 a, fast_us2 v) { return __builtin_elementwise_sub_sat(a, v) | __builtin_elementwise_sub_sat(v, a); };
     const uint32_t in0 = (x0 - 1 + lane <= L.rx1) ? 0xFFFFu : 0u, in1 = (x0 - 1 + lane + 64 <= L.rx1) ? 0xFFFF0000u : 0u;
     const uint32_t inmask = in0 | in1;
-    for (int sy = wave; sy < FAST_SH; sy += 4) {
-        const int gy = y0 - 1 + sy;
-        if (gy > L.ry1) break;
-        const uint8_t* c0 = &raw[sy + 3][lane + 3 + xoff];
-        const uint8_t* c1 = c0 + 64;
-        const fast_us2 v = pk(c0[0], c1[0]);
-        const fast_us2 m1 = __builtin_elementwise_max(absd(pk(c0[-3 * FAST_RW], c1[-3 * FAST_RW]), v), absd(pk(c0[3 * FAST_RW], c1[3 * FAST_RW]), v));
-        const uint32_t s1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(m1, tt)) & inmask;
-        if (__builtin_amdgcn_ballot_w64(s1 != 0u) == 0ull) continue;
+    // two score rows (sy, sy + 4) per round, so that each of the two dependent LDS round trips of a round — the vertical
+    // pair, then the other six pixels — serves 256 positions
+    auto stage1 = [&](const uint8_t* c0, const uint8_t* c1, fast_us2& v, fast_us2& m1) {
+        v = pk(c0[0], c1[0]);
+        m1 = __builtin_elementwise_max(absd(pk(c0[-3 * FAST_RW], c1[-3 * FAST_RW]), v), absd(pk(c0[3 * FAST_RW], c1[3 * FAST_RW]), v));
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(m1, tt)) & inmask;
+    };
+    auto stage2 = [&](const uint8_t* c0, const uint8_t* c1, fast_us2 v, fast_us2 m1) {
         const fast_us2 mh = __builtin_elementwise_max(absd(pk(c0[3], c1[3]), v), absd(pk(c0[-3], c1[-3]), v));
         const fast_us2 md1 = __builtin_elementwise_max(absd(pk(c0[2 * FAST_RW + 2], c1[2 * FAST_RW + 2]), v), absd(pk(c0[-2 * FAST_RW - 2], c1[-2 * FAST_RW - 2]), v));
         const fast_us2 md2 = __builtin_elementwise_max(absd(pk(c0[-2 * FAST_RW + 2], c1[-2 * FAST_RW + 2]), v), absd(pk(c0[2 * FAST_RW - 2], c1[2 * FAST_RW - 2]), v));
         const fast_us2 mall = __builtin_elementwise_min(__builtin_elementwise_min(m1, mh), __builtin_elementwise_min(md1, md2));
-        const uint32_t s2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mall, tt)) & inmask;
-        if (s2 & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane);
-        if (s2 >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64);
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mall, tt)) & inmask;
+    };
+    for (int sy = wave; sy < FAST_SH; sy += 8) {
+        if (y0 - 1 + sy > L.ry1) break;
+        const int syb = min(sy + 4, FAST_SH - 1);                       // (a clamped second row repeats work, never queues)
+        const bool rowb = sy + 4 < FAST_SH && y0 - 1 + sy + 4 <= L.ry1;
+        const uint8_t* a0 = &raw[sy + 3][lane + 3 + xoff];
+        const uint8_t* b0 = &raw[syb + 3][lane + 3 + xoff];
+        fast_us2 va, ma, vb, mb;
+        const uint32_t s1a = stage1(a0, a0 + 64, va, ma);
+        const uint32_t s1b = rowb ? stage1(b0, b0 + 64, vb, mb) : (stage1(b0, b0 + 64, vb, mb), 0u);
+        if (__builtin_amdgcn_ballot_w64((s1a | s1b) != 0u) == 0ull) continue;
+        const uint32_t s2a = stage2(a0, a0 + 64, va, ma);
+        const uint32_t s2b = rowb ? stage2(b0, b0 + 64, vb, mb) : 0u;
+        if (s2a & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane);
+        if (s2a >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64);
+        if (s2b & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(syb * FAST_SW + lane);
+        if (s2b >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(syb * FAST_SW + lane + 64);
     }
     __syncthreads();
     // Phase B — segment test + cornerScore<16> on the queued positions only
