@@ -626,7 +626,9 @@ __global__ __launch_bounds__(256) void ssd_kernel(const uint8_t* __restrict__ a,
 // so the per-tap work is two LDS reads, two adds/shifts and one 3-byte gather.
 constexpr int RP_SPAN_X = 512, RP_SPAN_Y = 160;
 constexpr int RP_WIN_BYTES = 32 * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
-constexpr int RP_WIN_LD = 4;                 // window groups (of 4 pixels) loaded per thread at a time
+constexpr int RP_PRE = 6;                    // window groups (of 4 pixels) per thread that are fetched one tile ahead
+constexpr int RP_MAX_TILES = 64;             // tiles per strip with a precomputed descriptor (small images up to 2048 px wide)
+struct RpTile { int sx_lo, sx_hi, tabled, windowed, all_in, wx0, wy0, wpitch, npx4, nrows; };
 
 // grid (max tile rows, min(B, 65535)), block 256.  Block (ty, y) walks the pairs y, y + gridDim.y, ... of the compact
 // list built by rate_kernel and, for each, the whole row `ty` of 32x8 output tiles: the per-pair constants are
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
     __shared__ unsigned long long red[4];
     __shared__ int s_ad[RP_SPAN_X], s_bd[RP_SPAN_X], s_x0[RP_SPAN_Y], s_y0[RP_SPAN_Y];
     __shared__ __attribute__((aligned(16))) uint8_t win[RP_WIN_BYTES + 16];   // + a zero pixel at RP_WIN_BYTES
+    __shared__ RpTile s_tile[RP_MAX_TILES];
     const uint32_t npairs = *pair_count;
     if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(win + RP_WIN_BYTES)[threadIdx.x] = 0;
     const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
@@ -667,79 +670,101 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                 s_x0[i] = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
                 s_y0[i] = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
             }
+        // ---- per-strip tile descriptors, one thread per tile: source span, frame-space bounding box of its taps and the
+        // LDS window layout.  (Computed per tile inside the loop, the two dependent table loads and the corner arithmetic
+        // sat on every tile's critical path, and the window could not be requested before the tile began.)
+        __syncthreads();                                              // s_x0 / s_y0 are complete
+        if ((int)threadIdx.x < tiles_x && (int)threadIdx.x < RP_MAX_TILES) {
+            const int tx = threadIdx.x;
+            RpTile T{};
+            const int dxa = tx * SM_TW, dxb = min(ag.dw, dxa + SM_TW) - 1;
+            if (ag.fast) { T.sx_lo = dxa * ag.iscale_x; T.sx_hi = min((dxb + 1) * ag.iscale_x - 1, ag.sw - 1); }
+            else { T.sx_lo = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxa]].si; T.sx_hi = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxb + 1] - 1].si; }
+            T.tabled = tabled_y && (T.sx_hi - T.sx_lo) < RP_SPAN_X;
+            if (T.tabled) {
+                // X, Y are monotone in x and in y, so the corners of the source span bound every tap
+                const int ny = sy_hi - sy_lo;
+                const int ad0 = sat_int_d(M[0] * T.sx_lo * AB_SCALE), adn = sat_int_d(M[0] * T.sx_hi * AB_SCALE);
+                const int bd0 = sat_int_d(M[3] * T.sx_lo * AB_SCALE), bdn = sat_int_d(M[3] * T.sx_hi * AB_SCALE);
+                auto XY = [&](int ad, int bd, int iy, int& X, int& Y) {
+                    X = (int)((uint32_t)s_x0[iy] + (uint32_t)ad) >> AB_BITS;
+                    Y = (int)((uint32_t)s_y0[iy] + (uint32_t)bd) >> AB_BITS;
+                };
+                int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
+                XY(ad0, bd0, 0, X00, Y00); XY(adn, bdn, 0, X10, Y10); XY(ad0, bd0, ny, X01, Y01); XY(adn, bdn, ny, X11, Y11);
+                const int ux0 = min(min(X00, X10), min(X01, X11)), ux1 = max(max(X00, X10), max(X01, X11));
+                const int uy0 = min(min(Y00, Y10), min(Y01, Y11)), uy1 = max(max(Y00, Y10), max(Y01, Y11));
+                T.all_in = ux0 >= 0 && ux1 < fw && uy0 >= 0 && uy1 < fh;      // no tap of this tile leaves the frame
+                const int bx0 = max(ux0, 0), bx1 = min(ux1, fw - 1);
+                const int by0 = max(uy0, 0), by1 = min(uy1, fh - 1);
+                if (bx1 >= bx0 && by1 >= by0) {
+                    // window columns start at a multiple of 4 pixels so that 4 pixels = 3 aligned source dwords;
+                    // stored as 4 bytes per pixel (B,G,R,0): one aligned ds_read_b32 per tap later
+                    const int px0 = bx0 & ~3, npx4 = (bx1 - px0 + 4) >> 2;        // groups of 4 pixels per row
+                    const int wpitch = npx4 * 16, nrows = by1 - by0 + 1;
+                    if ((int64_t)wpitch * nrows <= RP_WIN_BYTES && (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)stride) & 3) == 0) {
+                        T.windowed = 1; T.wx0 = px0; T.wy0 = by0; T.wpitch = wpitch; T.npx4 = npx4; T.nrows = nrows;
+                    }
+                }
+            }
+            s_tile[tx] = T;
+        }
+        __syncthreads();
+        // window groups of a tile: RP_PRE per thread travel through registers one tile ahead, the rest (large windows)
+        // are loaded when the tile starts
+        const int last_dw = (stride >> 2) - 1;                        // stay inside the row allocation
+        auto load_group = [&](const RpTile& T, int i, uint32_t& a, uint32_t& b, uint32_t& c) {
+            // i / npx4 without the integer-division sequence: i < 2^11, so the f32 product is off by < (2^11 / npx4) * 2^-22,
+            // far below the 0.5 / npx4 distance of (i + 0.5) / npx4 to the nearest integer
+            const int ry = (int)(((float)i + 0.5f) * (1.0f / (float)max(T.npx4, 1))), g = i - __mul24(ry, T.npx4);
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(T.wy0 + ry) * stride);
+            const int d0 = ((T.wx0 >> 2) + g) * 3;
+            a = row[min(d0, last_dw)]; b = row[min(d0 + 1, last_dw)]; c = row[min(d0 + 2, last_dw)];
+        };
+        auto store_group = [&](int i, uint32_t a, uint32_t b, uint32_t c) {
+            uint4 o4;                                                 // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            o4.x = a & 0x00FFFFFFu;
+            o4.y = (a >> 24) | ((b & 0xFFFFu) << 8);
+            o4.z = (b >> 16) | ((c & 0xFFu) << 16);
+            o4.w = c >> 8;
+            reinterpret_cast<uint4*>(win)[i] = o4;
+        };
+        uint32_t pa[RP_PRE], pb[RP_PRE], pc[RP_PRE];
+        auto prefetch = [&](const RpTile& T) {                        // (always issued, clamped: `p*` stay plain registers)
+            const int total = max(T.npx4 * T.nrows, 1);
+#pragma unroll
+            for (int u = 0; u < RP_PRE; ++u) load_group(T, min((int)threadIdx.x + 256 * u, total - 1), pa[u], pb[u], pc[u]);
+        };
+        const bool use_tiles = tiles_x <= RP_MAX_TILES;
+        prefetch(s_tile[0]);
         unsigned long long acc = 0;
         for (int tx = 0; tx < tiles_x; ++tx) {
             const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1));
-            const int dxa = tx * SM_TW, dxb = min(ag.dw, dxa + SM_TW) - 1;
-            int sx_lo, sx_hi;
-            if (ag.fast) { sx_lo = dxa * ag.iscale_x; sx_hi = min((dxb + 1) * ag.iscale_x - 1, ag.sw - 1); }
-            else { sx_lo = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxa]].si; sx_hi = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxb + 1] - 1].si; }
-            const bool tabled = tabled_y && (sx_hi - sx_lo) < RP_SPAN_X;
+            const RpTile T = s_tile[min(tx, RP_MAX_TILES - 1)];
+            const int sx_lo = T.sx_lo, sx_hi = T.sx_hi;
+            const bool tabled = use_tiles && T.tabled;
+            const bool windowed = tabled && T.windowed, all_in = T.all_in;
+            const int wx0 = T.wx0, wy0 = T.wy0, wpitch = T.wpitch;
             __syncthreads();                                          // previous tile's readers of s_ad / win are done
             if (tabled)
                 for (int i = threadIdx.x; i <= sx_hi - sx_lo; i += 256) {
                     const int x = sx_lo + i;
                     s_ad[i] = sat_int_d(M[0] * x * AB_SCALE); s_bd[i] = sat_int_d(M[3] * x * AB_SCALE);
                 }
-            __syncthreads();
-            // frame-space bounding box of the window: X, Y are monotone in x and in y, so the corners bound them
-            bool windowed = false, all_in = false;
-            int wx0 = 0, wy0 = 0, wpitch = 0;
-            if (tabled) {
-                const int nx = sx_hi - sx_lo, ny = sy_hi - sy_lo;
-                auto XY = [&](int ix, int iy, int& X, int& Y) {
-                    X = (int)((uint32_t)s_x0[iy] + (uint32_t)s_ad[ix]) >> AB_BITS;
-                    Y = (int)((uint32_t)s_y0[iy] + (uint32_t)s_bd[ix]) >> AB_BITS;
-                };
-                int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
-                XY(0, 0, X00, Y00); XY(nx, 0, X10, Y10); XY(0, ny, X01, Y01); XY(nx, ny, X11, Y11);
-                const int ux0 = min(min(X00, X10), min(X01, X11)), ux1 = max(max(X00, X10), max(X01, X11));
-                const int uy0 = min(min(Y00, Y10), min(Y01, Y11)), uy1 = max(max(Y00, Y10), max(Y01, Y11));
-                all_in = ux0 >= 0 && ux1 < fw && uy0 >= 0 && uy1 < fh;        // no tap of this tile leaves the frame
-                int bx0 = max(ux0, 0), bx1 = min(ux1, fw - 1);
-                int by0 = max(uy0, 0), by1 = min(uy1, fh - 1);
-                if (bx1 >= bx0 && by1 >= by0) {
-                    // window columns start at a multiple of 4 pixels so that 4 pixels = 3 aligned source dwords;
-                    // stored as 4 bytes per pixel (B,G,R,0): one aligned ds_read_b32 per tap later
-                    const int px0 = bx0 & ~3, npx4 = (bx1 - px0 + 4) >> 2;        // groups of 4 pixels per row
-                    wpitch = npx4 * 16;
-                    if ((int64_t)wpitch * (by1 - by0 + 1) <= RP_WIN_BYTES && (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)stride) & 3) == 0) {
-                        windowed = true; wx0 = px0; wy0 = by0;
-                        const int nrows = by1 - by0 + 1;
-                        const int last_dw = (stride >> 2) - 1;                    // stay inside the row allocation
-                        // RP_WIN_LD groups (12 dword loads) are in flight per thread before the first LDS store: the
-                        // rolled loop waited for every group's loads in turn, which was most of this kernel's time
-                        const int total = npx4 * nrows;
-                        const float inv_npx4 = 1.0f / (float)npx4;
-                        for (int i0 = threadIdx.x; i0 < total; i0 += 256 * RP_WIN_LD) {
-                            uint32_t a[RP_WIN_LD], b[RP_WIN_LD], c[RP_WIN_LD];
+            if (windowed) {
+                const int total = T.npx4 * T.nrows;
 #pragma unroll
-                            for (int u = 0; u < RP_WIN_LD; ++u) {
-                                const int i = min(i0 + 256 * u, total - 1);
-                                // i / npx4 without the integer-division sequence: i < 2^11, so the f32 product is off
-                                // by < (2^11 / npx4) * 2^-22, far below the 0.5 / npx4 distance of (i + 0.5) / npx4 to
-                                // the nearest integer
-                                const int ry = (int)(((float)i + 0.5f) * inv_npx4), g = i - __mul24(ry, npx4);
-                                const uint32_t* row = reinterpret_cast<const uint32_t*>(frame + (int64_t)(by0 + ry) * stride);
-                                const int d0 = ((px0 >> 2) + g) * 3;
-                                a[u] = row[min(d0, last_dw)]; b[u] = row[min(d0 + 1, last_dw)]; c[u] = row[min(d0 + 2, last_dw)];
-                            }
-#pragma unroll
-                            for (int u = 0; u < RP_WIN_LD; ++u) {
-                                const int i = i0 + 256 * u;
-                                if (i < total) {
-                                    uint4 o4;                                     // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-                                    o4.x = a[u] & 0x00FFFFFFu;
-                                    o4.y = (a[u] >> 24) | ((b[u] & 0xFFFFu) << 8);
-                                    o4.z = (b[u] >> 16) | ((c[u] & 0xFFu) << 16);
-                                    o4.w = c[u] >> 8;
-                                    reinterpret_cast<uint4*>(win)[i] = o4;
-                                }
-                            }
-                        }
-                    }
+                for (int u = 0; u < RP_PRE; ++u) {
+                    const int i = (int)threadIdx.x + 256 * u;
+                    if (i < total) store_group(i, pa[u], pb[u], pc[u]);
+                }
+                for (int i = (int)threadIdx.x + 256 * RP_PRE; i < total; i += 256) {      // windows beyond RP_PRE * 256 groups
+                    uint32_t a, b, c;
+                    load_group(T, i, a, b, c);
+                    store_group(i, a, b, c);
                 }
             }
+            prefetch(s_tile[min(tx + 1, min(tiles_x, RP_MAX_TILES) - 1)]);   // in flight during this tile's taps
             __syncthreads();
             if (dx < ag.dw && dy < ag.dh) {
                 uint8_t o[3];
