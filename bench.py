@@ -34,6 +34,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg1": dict(frame=(1920, 1080), page=(2001, 1125), pages=100, nfeatures=1000, batch=256,
                  name="configs[1]: 1080p batch=256 vs 100 pages, ORB-1000"),
+    # BASELINE.json configs[4] shape on one GPU: 4K frames, ORB-2000, 1000-page deck (2 M train descriptors)
+    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64,
+                 name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000"),
     # small, for smoke runs
     "tiny": dict(frame=(640, 360), page=(800, 450), pages=8, nfeatures=500, batch=16,
                  name="tiny: 640x360 vs 8 pages, ORB-500"),

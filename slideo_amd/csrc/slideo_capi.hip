@@ -320,9 +320,10 @@ KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
     if (m->knn_engine == 0 && nt > 0) {
         p.qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
-        // >= 1 block per 2 CUs already fills half of the matrix pipes and keeps the insert warm-up to one pass;
-        // fewer query blocks split the train set (each segment pays its own warm-up) to fill the chip
-        int nseg = p.qblocks >= 128 ? 1 : std::min(cdiv(512, p.qblocks), n_st);
+        // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
+        // segment pays its own list warm-up and the merge); fewer query blocks split the train set to fill the chip —
+        // measured at 236 query blocks (64 4K frames, 1.8 M rows): 1 segment 33.2 ms, 2 segments (472 blocks) 21 ms
+        int nseg = p.qblocks >= 384 ? 1 : std::min(cdiv(512, p.qblocks), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
     } else {
