@@ -458,7 +458,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         uint32_t* pair_count = S.d_pairs.as<uint32_t>();
         PairDesc* pair_list = reinterpret_cast<PairDesc*>(S.d_pairs.as<uint8_t>() + 64);
         HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));
-        rate_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
+        rate_kernel<<<n, 64, 0, st>>>(vp, n, S.d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
         check_launch("rate_kernel");
         int max_tile_rows = 0;
         for (const AreaGeom& ag : m->area_geoms) max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));

@@ -425,39 +425,42 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
 // ---------------------------------------------------------------------------
 // rate_kernel: one thread per frame.      lib.rs:329-333
 // ---------------------------------------------------------------------------
-__global__ void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict__ fcs, const PageInfo* __restrict__ pages,
-                            PairDesc* __restrict__ pair_list, uint32_t* __restrict__ pair_count) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per frame, lane = candidate slot.  The stable "rating desc" order (lib.rs:329) is each lane's rank =
+// number of candidates that beat it (higher rating, or equal rating and a lower slot); both filters are monotone in the
+// rating, so the survivors are the first `ns` of that order and survivor s is the lane with rank s.
+__global__ __launch_bounds__(64) void rate_kernel(VerifyParams vp, int nframes, FrameCands* __restrict__ fcs,
+                                                  const PageInfo* __restrict__ pages,
+                                                  PairDesc* __restrict__ pair_list, uint32_t* __restrict__ pair_count) {
+    static_assert(MAXC <= 64, "one lane per candidate");
+    const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= nframes) return;
     FrameCands& fc = fcs[f];
-    int order[MAXC];
     const int nc = fc.ncand;
-    for (int i = 0; i < nc; ++i) order[i] = i;
-    for (int i = 1; i < nc; ++i) {          // stable insertion sort, rating desc
-        int o = order[i], j = i;
-        while (j > 0 && fc.inliers[order[j - 1]] < fc.inliers[o]) { order[j] = order[j - 1]; --j; }
-        order[j] = o;
+    const bool mine = lane < nc;
+    const int inl = mine ? fc.inliers[lane] : -1;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int o = __shfl(inl, j);
+        rank += (j < nc && (o > inl || (o == inl && j < lane))) ? 1 : 0;
     }
     const int top = min(nc, vp.max_rated);
-    const double best = top > 0 ? (double)fc.inliers[order[0]] : 0.0;
-    int ns = 0;
-    for (int i = 0; i < top; ++i) {
-        double rating = (double)fc.inliers[order[i]];
-        if (rating > vp.min_rating && rating / best > vp.min_rating_ratio) {
-            fc.surv[ns] = order[i]; fc.ssd[ns] = 0ull; fc.sim[ns] = 0.f; ++ns;
-        }
-    }
-    fc.nsurv = ns;
-    if (ns > 0) {     // compact (frame, survivor) work list for reproject_kernel; order is irrelevant (sums are per pair)
-        const uint32_t base = atomicAdd(pair_count, (uint32_t)ns);
-        for (int i = 0; i < ns; ++i) {
-            const int r = fc.surv[i];
-            const PageInfo pg = pages[fc.page[r]];
-            PairDesc d;
-            d.f = f; d.s = i; d.area_idx = pg.area_idx; d._pad = 0; d.small_ofs = pg.small_ofs;
-            for (int j = 0; j < 6; ++j) d.M[j] = fc.M[r][j];
-            pair_list[base + i] = d;
-        }
+    const unsigned long long first = __builtin_amdgcn_ballot_w64(mine && rank == 0);
+    const double best = first ? (double)__shfl(inl, __builtin_ctzll(first)) : 0.0;
+    const double rating = (double)inl;
+    const bool pass = mine && rank < top && rating > vp.min_rating && rating / best > vp.min_rating_ratio;     // lib.rs:333
+    const int ns = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass));
+    uint32_t base = 0;
+    if (lane == 0) { fc.nsurv = ns; if (ns > 0) base = atomicAdd(pair_count, (uint32_t)ns); }
+    base = __shfl(base, 0);
+    if (pass) {       // compact (frame, survivor) work list for reproject_kernel; order is irrelevant (sums are per pair)
+        fc.surv[rank] = lane; fc.ssd[rank] = 0ull; fc.sim[rank] = 0.f;
+        const PageInfo pg = pages[fc.page[lane]];
+        PairDesc d;
+        d.f = f; d.s = rank; d.area_idx = pg.area_idx; d._pad = 0; d.small_ofs = pg.small_ofs;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d.M[j] = fc.M[lane][j];
+        pair_list[base + rank] = d;
     }
 }
 
