@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--pages", type=int, default=0)
     ap.add_argument("--knn", default="mfma", choices=["mfma", "valu"], help="kNN engine (identical results)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (<= the library's slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
@@ -133,17 +134,14 @@ def main():
     def run_steps(k):
         """k steps; a step = one batch of B frames through the whole hot path.  Two batches are kept in flight
         (submit i+1 before collecting i) so that ORB of the next batch overlaps kNN / verify of the current one."""
-        v, pending = None, None
+        v, pending = None, []
+        depth = 1 if args.no_overlap else max(1, args.inflight)
         for _ in range(k):
-            t = m.submit_dev(d_frames.data_ptr(), B, fw, fh, stream=stream)
-            if args.no_overlap:
-                v = finish(m.collect(t))
-                continue
-            if pending is not None:
-                v = finish(m.collect(pending))
-            pending = t
-        if pending is not None:
-            v = finish(m.collect(pending))
+            if len(pending) == depth:
+                v = finish(m.collect(pending.pop(0)))
+            pending.append(m.submit_dev(d_frames.data_ptr(), B, fw, fh, stream=stream))
+        while pending:
+            v = finish(m.collect(pending.pop(0)))
         return v
 
     def barrier():

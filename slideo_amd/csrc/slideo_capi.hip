@@ -25,6 +25,10 @@ using namespace slideo;
 
 namespace {
 
+#ifndef SLIDEO_NSLOTS
+#define SLIDEO_NSLOTS 2
+#endif
+constexpr int NSLOTS = SLIDEO_NSLOTS;      // units in flight (each with its own workspace and HIP stream)
 constexpr int KLIST = 32;
 static_assert(KLIST == VOTE_KLIST, "vote_kernel reads whole key lists");
 
@@ -108,7 +112,7 @@ struct slideo_matcher {
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
 
     // workspaces
-    Slot slots[2];
+    Slot slots[NSLOTS];
     int next_slot = 0;
     int64_t next_ticket = 1;
     DevBuf d_small, d_ssd, d_prev_small, d_tapq, d_tapt, d_tapidx, d_tapdist;
@@ -185,12 +189,12 @@ void upload_area(slideo_matcher* m) {
 // max frames of size (w,h) per unit under the workspace budget (two slots share it)
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
     size_t per = (size_t)g.frame_bytes * 2 + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
-    size_t fit = std::max<size_t>(1, (m->ws_budget / 2) / std::max<size_t>(per, 1));
+    size_t fit = std::max<size_t>(1, (m->ws_budget / NSLOTS) / std::max<size_t>(per, 1));
     return (int)std::min<size_t>({(size_t)std::max(n, 1), fit, (size_t)4096});
 }
 
 void require_idle(slideo_matcher* m) {
-    if (m->slots[0].busy || m->slots[1].busy) fail(SLIDEO_ERR_STATE, "a submitted unit has not been collected yet");
+    for (const Slot& S : m->slots) if (S.busy) fail(SLIDEO_ERR_STATE, "a submitted unit has not been collected yet");
 }
 
 // ---- ORB over `n` equally sized frames already on the device, in three steps -------------
@@ -537,14 +541,14 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
     try {
         for (int i = 0; i < n; i += unit) {
             const int cnt = std::min(unit, n - i);
-            if (pend.size() == 2) {
+            if ((int)pend.size() == NSLOTS) {
                 unit_collect(m, *pend[0].S, out + pend[0].ofs);
                 done += pend[0].S->n;
                 pend.erase(pend.begin());
                 if (m->progress) m->progress(m->progress_user, (uint64_t)done, (uint64_t)n, "Processing frames...");
             }
             Slot& S = m->slots[m->next_slot];
-            m->next_slot ^= 1;
+            m->next_slot = (m->next_slot + 1) % NSLOTS;
             const uint8_t* dev;
             int64_t fs = frame_stride;
             if (on_device) dev = frames + (int64_t)i * frame_stride;
@@ -838,14 +842,14 @@ int32_t slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames, cons
     if (n_frames < 1) fail(SLIDEO_ERR_INVALID_ARG, "submit needs at least one frame");
     HIP_CHECK(hipSetDevice(m->device));
     Slot& S = m->slots[m->next_slot];
-    if (S.busy) fail(SLIDEO_ERR_STATE, "both slots are in flight: collect ticket %lld first", (long long)S.ticket);
+    if (S.busy) fail(SLIDEO_ERR_STATE, "all slots are in flight: collect ticket %lld first", (long long)S.ticket);
     GeomEntry& ge = geom_for(m, width, height);
     if (n_frames > sub_batch_for(m, ge.g, n_frames))
         fail(SLIDEO_ERR_CAPACITY, "%d frames exceed the per-slot workspace budget (%d); submit smaller units or raise SLIDEO_WS_GB",
              n_frames, sub_batch_for(m, ge.g, n_frames));
     area_class_for(m, width, height);
     upload_area(m);
-    if (!m->slots[0].busy && !m->slots[1].busy) m->last_fcs.clear();
+    { bool any = false; for (const Slot& c : m->slots) any |= c.busy; if (!any) m->last_fcs.clear(); }
     if (hip_stream) {
         HIP_CHECK(hipEventRecord(S.ev_in, reinterpret_cast<hipStream_t>(hip_stream)));
         HIP_CHECK(hipStreamWaitEvent(S.st, S.ev_in, 0));
@@ -853,8 +857,8 @@ int32_t slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames, cons
     unit_submit(m, S, frames_dev, n_frames, width, height, stride_bytes, frame_stride_bytes);
     S.ticket = m->next_ticket++;
     *ticket_out = S.ticket;
-    m->next_slot ^= 1;
-    if (Slot& O = m->slots[m->next_slot]; !O.busy) O.match_capacity(S);     // the next unit finds its workspace sized
+    m->next_slot = (m->next_slot + 1) % NSLOTS;
+    for (Slot& O : m->slots) if (&O != &S && !O.busy) O.match_capacity(S);  // the next units find their workspace sized
     API_CATCH(m)
 }
 
