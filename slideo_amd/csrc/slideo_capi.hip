@@ -325,9 +325,11 @@ KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
         p.qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
-        // segment pays its own list warm-up and the merge); fewer query blocks split the train set to fill the chip —
-        // measured at 236 query blocks (64 4K frames, 1.8 M rows): 1 segment 33.2 ms, 2 segments (472 blocks) 21 ms
-        int nseg = p.qblocks >= 384 ? 1 : std::min(cdiv(512, p.qblocks), n_st);
+        // segment pays its own list warm-up and the merge); fewer query blocks split the train set so that the blocks
+        // fill the chip in ONE round (floor, not ceil: 1.4 rounds of smaller blocks lose more to the tail than the
+        // empty slots do).  Measured: 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
+        // 3 segments 23.5 ms; 239 query blocks x 517 k rows (128 1080p frames): 2 segments 6.24 ms, 3 segments 6.65 ms
+        int nseg = p.qblocks >= 384 ? 1 : std::min(std::max(512 / std::max(p.qblocks, 1), 1), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
     } else {
