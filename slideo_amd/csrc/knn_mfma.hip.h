@@ -43,17 +43,10 @@ typedef float knn_v16f __attribute__((ext_vector_type(16)));
 constexpr int KM_WAVES = 8;                    // waves per block
 constexpr int KM_THREADS = KM_WAVES * 64;
 constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-query B tiles per wave)
-#ifndef KM_ST_ROWS_
-#define KM_ST_ROWS_ 128
-#define KM_RING_ 4
-#define KM_AHEAD_ 2
-#endif
-constexpr int KM_ST_ROWS = KM_ST_ROWS_;                // rows per super-tile (the unit of LDS staging)
-constexpr int KM_RING = KM_RING_;                     // LDS ring slots (super-tiles resident per block)
-#ifndef KM_MFMA_PRIO
-#define KM_MFMA_PRIO 2
-#endif
-constexpr int KM_AHEAD = KM_AHEAD_;                    // a super-tile is staged this many iterations before it is consumed
+constexpr int KM_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
+constexpr int KM_RING = 4;                     // LDS ring slots (super-tiles resident per block)
+constexpr int KM_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
+constexpr int KM_MFMA_PRIO = 2;                // wave priority while its MFMAs are issued (0 elsewhere)
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
 
 // 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if 0, 0xA (-1.0) if 1; bit i -> nibble i.
@@ -99,10 +92,7 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 // scored is higher than every row already in a list, so a candidate with exactly the k-th distance is (correctly)
 // rejected by the strict filter, and nothing that belongs to the final top-k is ever filtered out.  With
 // prune_tol > 0 the threshold is additionally capped by the vote's acceptance bound (see the flush).
-#ifndef KM_FLUSH_AT_
-#define KM_FLUSH_AT_ 16
-#endif
-constexpr int KM_FLUSH_AT = KM_FLUSH_AT_;
+constexpr int KM_FLUSH_AT = 16;
 constexpr int KM_FLUSH_BATCH = 4;
 constexpr int KM_PEND_CAP = 32;                      // >= KM_FLUSH_AT - 1 + 16 (a lane pushes <= 16 keys per tile and query)
 constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
@@ -266,9 +256,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
             // the matrix pipe needs one issue slot in eight; at equal priority the SIMD's arbiter serves the oldest
             // wave's VALU epilogue first and the pipe idles, so MFMAs are issued at raised priority
-#if KM_MFMA_PRIO > 0
             __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
-#endif
             {
                 const uint4 f2 = L[tile * 256 + 128], f3 = L[tile * 256 + 192];
                 const knn_v8i v0 = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0}, v1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
@@ -284,9 +272,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                 const uint4* Ln = L + min(tile + 1, KM_ST_ROWS / 32 - 1) * 256;
                 f0 = Ln[0]; f1 = Ln[64];
             }
-#if KM_MFMA_PRIO > 0
             __builtin_amdgcn_s_setprio(0);
-#endif
             // rows past the end of the train set (only in its last tile) can never be candidates
             const int tile_row0 = st * KM_ST_ROWS + tile * 32;
             if (tile >= first_pad_tile) {
@@ -317,14 +303,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             }
             const int m0 = max(max(max(ia[15], ta[0]), ta[1]), max(max(ta[2], ta[3]), ta[4]));
             const int m1 = max(max(max(ib[15], tb[0]), tb[1]), max(max(tb[2], tb[3]), tb[4]));
-#if defined(KM_ABL) && KM_ABL >= 2
-            if (m0 + m1 == 12345) cntA++;
-            if (false) {
-#elif defined(KM_ABL)
-            if (__builtin_amdgcn_ballot_w64(m0 > thrAi || m1 > thrBi) == 0x1234ull) {
-#else
             if (__builtin_amdgcn_ballot_w64(m0 > thrAi || m1 > thrBi) != 0ull) {
-#endif
                 KM_T0
 #ifdef KM_TIMING
                 ++n_slow;
