@@ -227,6 +227,16 @@ int32_t     slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq,
                                const uint8_t* t, int32_t nt, int32_t k,
                                int32_t* idx_out, uint16_t* dist_out);
 
+/* North-star extension without a counterpart in the reference (BASELINE configs[2], SURVEY §8(d) "cfg2" / §8(f) N4):
+ * exact squared-L2 k-NN between 128-dimensional u8 descriptors (SIFT-shaped: OpenCV's SIFT descriptors are
+ * integer-valued 0..255), computed as an N x M x 128 integer contraction on the matrix cores
+ * (v_mfma_i32_32x32x32_i8 on centred components).  q: nq x 128 bytes, t: nt x 128 bytes (nt < 2^23), 1 <= k <= 32.
+ * idx_out[nq*k]: train row or -1; dist_out[nq*k]: squared distance (0xFFFFFFFF where idx is -1).  Neighbours in
+ * ascending (distance, row) order — what cv::BFMatcher(NORM_L2).knnMatch would return up to the square root.
+ * The parity target is this repository's CPU restatement (oracle so_knn_l2_u8). */
+int32_t     slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
+                             int32_t* idx_out, uint32_t* dist_out);
+
 /* to_small_image (mo/image_utils.rs:8-20) of one host image. */
 int32_t     slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
                                     int32_t height, int32_t stride_bytes, uint8_t* out,

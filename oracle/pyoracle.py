@@ -181,6 +181,15 @@ def knn_hamming(q, t, k):
     return idx, dist
 
 
+def knn_l2_u8(q, t, k):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 128)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 128)
+    idx = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.uint32)
+    lib().so_knn_l2_u8(_p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist))
+    return idx, dist
+
+
 def estimate_affine_partial(frm, to, cfg):
     frm = np.ascontiguousarray(frm, np.float32).reshape(-1, 2)
     to = np.ascontiguousarray(to, np.float32).reshape(-1, 2)

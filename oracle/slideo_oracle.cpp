@@ -1098,6 +1098,29 @@ void so_knn_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, i
     knn_hamming(q, nq, t, nt, k, idx, dist);
 }
 
+// Exact squared-L2 k-NN between 128-dimensional u8 descriptors (SURVEY §8(d) cfg2 / §8(f) N4 — a north-star extension
+// with no counterpart in the reference: this brute force IS the parity target of slideo_knn_l2_u8).  k smallest
+// (distance, row) pairs per query, ties to the lower row; missing neighbours: idx -1, dist 0xFFFFFFFF.
+void so_knn_l2_u8(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint32_t* dist) {
+    std::vector<std::pair<uint32_t, int32_t>> cand;
+    for (int i = 0; i < nq; ++i) {
+        cand.clear();
+        const uint8_t* a = q + (size_t)i * 128;
+        for (int j = 0; j < nt; ++j) {
+            const uint8_t* b = t + (size_t)j * 128;
+            uint32_t d = 0;
+            for (int c = 0; c < 128; ++c) { int e = (int)a[c] - (int)b[c]; d += (uint32_t)(e * e); }
+            cand.emplace_back(d, j);
+        }
+        const int kk = std::min(k, nt);
+        std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
+        for (int r = 0; r < k; ++r) {
+            idx[(size_t)i * k + r] = r < kk ? cand[r].second : -1;
+            dist[(size_t)i * k + r] = r < kk ? cand[r].first : 0xFFFFFFFFu;
+        }
+    }
+}
+
 int so_estimate_affine_partial(const float* from_xy, const float* to_xy, int n, const slideo_config* c,
                                double* M6, uint8_t* mask, int32_t* iters_run) {
     int it = 0;

@@ -44,7 +44,7 @@ EXPORTS = [
     "slideo_matcher_page_count", "slideo_matcher_descriptor_count", "slideo_matcher_get_page_features",
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
-    "slideo_knn_hamming", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
+    "slideo_knn_hamming", "slideo_knn_l2_u8", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect",
 ]
@@ -268,6 +268,15 @@ class Matcher:
         idx = np.empty((q.shape[0], k), np.int32)
         dist = np.empty((q.shape[0], k), np.uint16)
         self._check(lib().slideo_knn_hamming(self._h, _p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist)))
+        return idx, dist
+
+    def knn_l2_u8(self, q, t, k):
+        """Exact squared-L2 k-NN of 128-dim u8 descriptors on the matrix cores (north-star extension, see the header)."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 128)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 128)
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.uint32)
+        self._check(lib().slideo_knn_l2_u8(self._h, _p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist)))
         return idx, dist
 
     def small_image(self, bgr):

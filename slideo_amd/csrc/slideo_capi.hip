@@ -17,6 +17,7 @@
 #include "geom.h"
 #include "knn.hip.h"
 #include "knn_mfma.hip.h"
+#include "knn_l2.hip.h"
 #include "orb.hip.h"
 #include "slideo_amd.h"
 #include "verify.hip.h"
@@ -1017,6 +1018,45 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     check_launch("knn_unpack_kernel");
     HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 2, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    API_CATCH(m)
+}
+
+int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
+                         int32_t* idx_out, uint32_t* dist_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (nq < 0 || nt < 0 || k < 1 || k > KLIST) fail(SLIDEO_ERR_INVALID_ARG, "bad nq/nt/k (k must be 1..%d)", KLIST);
+    if ((nq && !q) || (nt && !t) || (nq && (!idx_out || !dist_out))) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    if (nq == 0) return SLIDEO_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
+    const int nt_pad = knn_pad_rows(nt);
+    const int qblocks = cdiv(nq, KM_QPB);
+    DevBuf d_q, d_t, d_tx, d_tn, d_keys, d_pend;
+    d_q.reserve((size_t)nq * 128); d_t.reserve(std::max<size_t>((size_t)nt * 128, 64));
+    d_tx.reserve((size_t)nt_pad * 128); d_tn.reserve((size_t)nt_pad * 4);
+    d_keys.reserve((size_t)nq * KLIST * 8); d_pend.reserve((size_t)qblocks * KM_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
+    HIP_CHECK(hipMemcpyAsync(d_q.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
+    if (nt) HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
+    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, d_tx.as<uint4>(), d_tn.as<int32_t>());
+    check_launch("knl_expand_train_kernel");
+    const int kl = k <= 8 ? 8 : KLIST;              // list length of the kernel instance (see knn_l2.hip.h)
+    if (kl == 8)
+        knn_l2_kernel<8><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+                                                          d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
+    else
+        knn_l2_kernel<KLIST><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+                                                              d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
+    check_launch("knn_l2_kernel");
+    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
+    knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(d_keys.as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
+    check_launch("knl_unpack_kernel");
+    HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     API_CATCH(m)
 }

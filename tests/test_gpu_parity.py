@@ -604,3 +604,62 @@ def test_mixed_page_sizes(capi, oracle, synth):
         v = m.match_frames(frames)
         _compare_traces(m, db, frames, v)
     m.close()
+
+
+# ---- north-star extension: squared-L2 k-NN of 128-dim u8 descriptors on the int8 matrix cores (BASELINE configs[2]) ----
+
+def _sift_like(rng, n):
+    """OpenCV-SIFT-shaped descriptors: non-negative, most mass in few bins, clipped to 255."""
+    x = rng.gamma(0.6, 40.0, (n, 128))
+    x *= 512.0 / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+
+
+def test_knn_l2_random_bit_exact(capi, oracle, mdef):
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 256, (700, 128), dtype=np.uint8)
+    t = rng.integers(0, 256, (3000, 128), dtype=np.uint8)
+    gi, gd = mdef.knn_l2_u8(q, t, 30)
+    oi, od = oracle.knn_l2_u8(q, t, 30)
+    assert np.array_equal(gd, od) and np.array_equal(gi, oi)
+
+
+def test_knn_l2_sift_like_ties_and_extremes(capi, oracle, mdef):
+    rng = np.random.default_rng(12)
+    t = _sift_like(rng, 2500)
+    t[100:140] = t[7]                                   # exact duplicates: ties broken by the lower row
+    t[500] = 0; t[501] = 255                            # extreme norms (centred -128 / +127 everywhere)
+    q = np.concatenate([_sift_like(rng, 300), t[[7, 500, 501, 2499]], np.zeros((1, 128), np.uint8), np.full((1, 128), 255, np.uint8)])
+    for k in (1, 2, 32):
+        gi, gd = mdef.knn_l2_u8(q, t, k)
+        oi, od = oracle.knn_l2_u8(q, t, k)
+        assert np.array_equal(gd, od) and np.array_equal(gi, oi), k
+
+
+def test_knn_l2_fewer_rows_than_k_and_unaligned(capi, oracle, mdef):
+    rng = np.random.default_rng(13)
+    q = rng.integers(0, 256, (65, 128), dtype=np.uint8)
+    for nt in (1, 5, 31, 33, 127, 129, 517):
+        t = rng.integers(0, 256, (nt, 128), dtype=np.uint8)
+        gi, gd = mdef.knn_l2_u8(q, t, 30)
+        oi, od = oracle.knn_l2_u8(q, t, 30)
+        assert np.array_equal(gd, od) and np.array_equal(gi, oi), nt
+        assert (gi[:, min(nt, 30):] == -1).all()
+
+
+def test_knn_l2_property_larger(capi, mdef):
+    """60 k x 40 k pairs: the first neighbour of a row queried against a set that contains it is itself (distance 0),
+    lists are sorted by (distance, row), and distances equal a numpy recomputation on a sample."""
+    rng = np.random.default_rng(14)
+    t = _sift_like(rng, 40000)
+    sel = rng.choice(40000, 6000, replace=False)
+    q = t[sel]
+    gi, gd = mdef.knn_l2_u8(q, t, 30)
+    assert (gd[:, 0] == 0).all()
+    firsts = gi[:, 0]
+    assert np.array_equal(np.minimum(firsts, sel), firsts)         # the lowest duplicate row, if duplicated
+    key = gd.astype(np.int64) * (1 << 32) + gi
+    assert (np.diff(key, axis=1) > 0).all()
+    for r in (0, 17, 5999):
+        d = ((q[r].astype(np.int64) - t[gi[r]].astype(np.int64)) ** 2).sum(1)
+        assert np.array_equal(d, gd[r].astype(np.int64))

@@ -161,3 +161,21 @@ def test_timeline_dedup(oracle):
     assert list(keep) == [0, 2, 4, 5]
     keep = oracle.timeline_dedup([10, 0, 5], [1, 1, 2])
     assert list(keep) == [1, 2, 0]
+
+
+def test_knn_l2_u8_known_answers(oracle):
+    """Squared-L2 k-NN restatement (north-star extension, BASELINE configs[2]): hand-checkable cases and a numpy cross-check."""
+    t = np.zeros((5, 128), np.uint8)
+    t[1, 0] = 3; t[2, :2] = (3, 4); t[3] = 255; t[4, 0] = 3          # rows 1 and 4 are duplicates
+    q = np.zeros((2, 128), np.uint8); q[1] = 255
+    idx, dist = oracle.knn_l2_u8(q, t, 4)
+    assert idx[0].tolist() == [0, 1, 4, 2] and dist[0].tolist() == [0, 9, 9, 25]          # tie 9/9 -> lower row first
+    assert idx[1, 0] == 3 and dist[1, 0] == 0 and dist[1, 1] == 128 * 255 * 255 - 2 * 255 * 3 - 2 * 255 * 4 + 9 + 16
+    idx, dist = oracle.knn_l2_u8(q, t[:2], 4)                                             # fewer rows than k
+    assert idx[0].tolist() == [0, 1, -1, -1] and dist[0, 2] == 0xFFFFFFFF
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (40, 128), dtype=np.uint8); t = rng.integers(0, 256, (300, 128), dtype=np.uint8)
+    idx, dist = oracle.knn_l2_u8(q, t, 7)
+    d = ((q[:, None, :].astype(np.int64) - t[None, :, :].astype(np.int64)) ** 2).sum(2)
+    order = np.lexsort((np.broadcast_to(np.arange(300), d.shape), d), axis=1)[:, :7]
+    assert np.array_equal(idx, order) and np.array_equal(dist, np.take_along_axis(d, order, 1))
