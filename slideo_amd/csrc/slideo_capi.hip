@@ -1044,10 +1044,13 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     if (nt) HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
     knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, d_tx.as<uint4>(), d_tn.as<int32_t>());
     check_launch("knl_expand_train_kernel");
-    const int kl = k <= 8 ? 8 : KLIST;              // list length of the kernel instance (see knn_l2.hip.h)
+    const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
         knn_l2_kernel<8><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
                                                           d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
+    else if (kl == 16)
+        knn_l2_kernel<16><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+                                                           d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     else
         knn_l2_kernel<KLIST><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
                                                               d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());

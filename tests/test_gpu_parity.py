@@ -630,7 +630,7 @@ def test_knn_l2_sift_like_ties_and_extremes(capi, oracle, mdef):
     t[100:140] = t[7]                                   # exact duplicates: ties broken by the lower row
     t[500] = 0; t[501] = 255                            # extreme norms (centred -128 / +127 everywhere)
     q = np.concatenate([_sift_like(rng, 300), t[[7, 500, 501, 2499]], np.zeros((1, 128), np.uint8), np.full((1, 128), 255, np.uint8)])
-    for k in (1, 2, 32):
+    for k in (1, 2, 9, 16, 32):                       # the three kernel instances (lists of 8, 16, 32)
         gi, gd = mdef.knn_l2_u8(q, t, k)
         oi, od = oracle.knn_l2_u8(q, t, k)
         assert np.array_equal(gd, od) and np.array_equal(gi, oi), k
