@@ -663,3 +663,41 @@ def test_knn_l2_property_larger(capi, mdef):
     for r in (0, 17, 5999):
         d = ((q[r].astype(np.int64) - t[gi[r]].astype(np.int64)) ** 2).sum(1)
         assert np.array_equal(d, gd[r].astype(np.int64))
+
+
+# ---- ORB geometry other than the reference's literals: the kernels take them from slideo_config ----------------------
+
+@pytest.mark.parametrize("over", [
+    dict(scale_factor=1.5, nlevels=5),                     # coarser pyramid
+    dict(scale_factor=3.0, nlevels=3),                     # shrink factor >= 2: the generic resize path
+    dict(nlevels=1),                                       # no pyramid at all
+    dict(patch_size=40, edge_threshold=34),                # other BRIEF / centroid radius and border
+    dict(fast_threshold=8),                                # many more corners
+    dict(fast_threshold=60, nfeatures=150),
+], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_orb_bit_exact_other_geometries(capi, oracle, cfg0_data, over):
+    pages, frames, _, _ = cfg0_data
+    kw = dict(nfeatures=500)
+    kw.update(over)
+    m = capi.Matcher(capi.default_config(**kw))
+    oc = oracle.default_config(**kw)
+    n = 0
+    for img in list(frames[:2]) + [pages[0]]:
+        n += _cmp_orb(capi, oracle, m, oc, img)
+    assert n > 50
+    m.close()
+
+
+@pytest.mark.parametrize("over", [
+    dict(knn_k=12, max_candidate_pages=7, max_rated=3),
+    dict(ransac_threshold=1.5, ransac_max_iters=300, ransac_confidence=0.9, refine_iters=0),
+    dict(min_rating=5.0, min_rating_ratio=0.05, min_similarity=0.3, small_area=60000),
+    dict(knn_k=32, max_candidate_pages=64, max_rated=16, refine_iters=3),
+], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_end_to_end_other_verify_parameters(capi, oracle, cfg0_data, over):
+    """Vote / RANSAC / rating / re-projection parameters other than the reference's literals, traces against the oracle."""
+    pages, frames, truth, _ = cfg0_data
+    m, db = _build_both(capi, oracle, small_cfg(capi, **over), small_cfg(oracle, **over), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    m.close()
