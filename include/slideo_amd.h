@@ -19,7 +19,10 @@
  *   - "page" = one rasterised PDF page, "frame" = one decoded video frame,
  *     page indices are 0-based positions in the order pages were added.
  *   - there is NO CPU fallback: without a gfx950 device every compute entry
- *     point fails with SLIDEO_ERR_NO_DEVICE.
+ *     point fails with SLIDEO_ERR_NO_DEVICE;
+ *   - a matcher is NOT re-entrant: calls on one handle must come from one thread at
+ *     a time (the reference's caller is single threaded, crates/app/src/main.rs:77-93,
+ *     and parallelism lives inside the call); different handles are independent.
  */
 #ifndef SLIDEO_AMD_H
 #define SLIDEO_AMD_H
