@@ -9,8 +9,10 @@
 // engine (knn_mfma.hip.h), whose structure this kernel shares: tile-major train operand (a 128-byte row is 8 chunks of
 // 16 B, exactly the FP4 layout), 512-query blocks, two 32-query B tiles per wave, LDS ring filled by LDS-DMA and
 // guarded by per-slot counters, per-lane thresholds, pushed candidates and batched flushes.  Differences:
-//   * the score of a pair is s = 2 <q',t'> - |t'|^2 (larger is nearer; d^2 = |q'|^2 - s), so the negated row norms
-//     travel with every super-tile (512 B) and cost one v_lshl_add per accumulator register;
+//   * the score of a pair is s = 2 <q',t'> - |t'|^2 (larger is nearer; d^2 = |q'|^2 - s).  The train rows are laid out in
+//     ascending norm order (a permutation built when the set is prepared), so within a 32-row tile the norms are almost
+//     equal and the fast path needs no per-register correction: 2 max(<q',t'>) - (the tile's smallest norm) bounds every s;
+//     the exact norms (512 B per super-tile, staged next to it) are only touched in the slow path;
 //   * d^2 needs 23 bits and the row 23: keys are 64-bit (d^2 << 32 | row), lists are 32 x u64 per query.
 // Ties go to the lower row; pad rows carry a norm of 2^30 and can never qualify.
 #pragma once
@@ -30,28 +32,40 @@ constexpr int KNL_PAD_NORM = 1 << 30;
 constexpr int KNL_THR_OPEN = -(1 << 30) + (1 << 24);
 constexpr size_t KNL_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64 * 2;      // u64 keys
 
-// train [nt][128] u8 -> centred i8, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]), padded to a multiple of
-// KM_ST_ROWS rows; neg_norm[row] = -|t'|^2 (pad rows: -2^30).  One thread per (row, chunk).
-__global__ __launch_bounds__(256) void knl_expand_train_kernel(const uint8_t* __restrict__ t, int nt, int nt_pad,
-                                                               uint4* __restrict__ out, int32_t* __restrict__ neg_norm) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nt_pad * 8) return;
-    const int row = i >> 3, c = i & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
+// |t'|^2 of every train row (centred components), one thread per row
+__global__ __launch_bounds__(256) void knl_norms_kernel(const uint8_t* __restrict__ t, int nt, int32_t* __restrict__ norm) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nt) return;
+    const uint4* p = reinterpret_cast<const uint4*>(t + (size_t)row * 128);
     int ss = 0;
-    if (row < nt) {
-        v = reinterpret_cast<const uint4*>(t + (size_t)row * 128)[c];
-        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 v = p[c];
+        const uint32_t w[4] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int b = 0; b < 4; ++b) { const int x = (int)(int8_t)(w[k] >> (8 * b)); ss += x * x; }
     }
+    norm[row] = ss;
+}
+
+// train [nt][128] u8 -> centred i8, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]) IN NORM ORDER: sorted row i
+// is the caller's row perm[i] (ascending |t'|^2, ties by row), padded to a multiple of KM_ST_ROWS rows;
+// neg_norm[i] = -|t'|^2 (pad rows: -2^30, perm -1).  One thread per (sorted row, chunk).
+__global__ __launch_bounds__(256) void knl_expand_train_kernel(const uint8_t* __restrict__ t, int nt, int nt_pad,
+                                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ norm,
+                                                               uint4* __restrict__ out, int32_t* __restrict__ neg_norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt_pad * 8) return;
+    const int row = i >> 3, c = i & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nt) {
+        v = reinterpret_cast<const uint4*>(t + (size_t)perm[row] * 128)[c];
+        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+    }
     out[(size_t)(row >> 5) * 256 + c * 32 + (row & 31)] = v;
-    // the 8 chunk threads of a row are 8 consecutive lanes
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
-    if (c == 0) neg_norm[row] = row < nt ? -ss : -KNL_PAD_NORM;
+    if (c == 0) neg_norm[row] = row < nt ? -norm[perm[row]] : -KNL_PAD_NORM;
 }
 
 template <int KL>
@@ -73,7 +87,8 @@ __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsign
 template <int KL>
 __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq,
                                                                const uint4* __restrict__ tx, const int32_t* __restrict__ tnn,
-                                                               int nt_pad, unsigned long long* __restrict__ out,
+                                                               const int32_t* __restrict__ perm, int nt_pad,
+                                                               unsigned long long* __restrict__ out,
                                                                unsigned long long* __restrict__ pend_ws) {
     __shared__ uint4 lds[KM_RING][KM_ST_U4];
     __shared__ __attribute__((aligned(16))) int32_t lds_nn[KM_RING][KM_ST_ROWS];
@@ -215,41 +230,50 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
                 f0 = Ln[0]; f1 = Ln[64];
             }
             __builtin_amdgcn_s_setprio(0);
-            // scores s = 2 <q',t'> - |t'|^2; register r of a lane is row (r & 3) + 8 (r >> 2) + 4 half of the tile
-            int ia[16], ib[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int4 nn = *reinterpret_cast<const int4*>(&lds_nn[slot][tile * 32 + 8 * g + 4 * half]);
-                const int n4[4] = {nn.x, nn.y, nn.z, nn.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = a0[4 * g + k], y = a1[4 * g + k];
-                    ia[4 * g + k] = 2 * x + n4[k]; ib[4 * g + k] = 2 * y + n4[k];
-                }
-            }
-            int ta[5], tb[5];
+            // Fast path.  The score of a pair is s = 2 <q',t'> - |t'|^2.  The train rows are sorted by norm, so the 32 rows
+            // of a tile have almost the same |t'|^2 and  s <= 2 max(<q',t'>) + nnmax  with nnmax = the tile's largest
+            // negated norm (its first row) is nearly tight: one v_max3 ladder on the raw accumulators and one shift-add
+            // per query tile decide whether anything can reach the threshold — no per-register norm correction.
+            const int nnmax = lds_nn[slot][tile * 32];
+            int ma[5], mb[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                ta[k] = max(max(ia[3 * k], ia[3 * k + 1]), ia[3 * k + 2]);
-                tb[k] = max(max(ib[3 * k], ib[3 * k + 1]), ib[3 * k + 2]);
+                ma[k] = max(max(a0[3 * k], a0[3 * k + 1]), a0[3 * k + 2]);
+                mb[k] = max(max(a1[3 * k], a1[3 * k + 1]), a1[3 * k + 2]);
             }
-            const int m0 = max(max(max(ia[15], ta[0]), ta[1]), max(max(ta[2], ta[3]), ta[4]));
-            const int m1 = max(max(max(ib[15], tb[0]), tb[1]), max(max(tb[2], tb[3]), tb[4]));
-            if (__builtin_amdgcn_ballot_w64(m0 > thrA || m1 > thrB) != 0ull) {
+            const int m0 = 2 * max(max(max(a0[15], ma[0]), ma[1]), max(max(ma[2], ma[3]), ma[4])) + nnmax;
+            const int m1 = 2 * max(max(max(a1[15], mb[0]), mb[1]), max(max(mb[2], mb[3]), mb[4])) + nnmax;
+            if (__builtin_amdgcn_ballot_w64(m0 >= thrA || m1 >= thrB) != 0ull) {
+                // Slow path: exact scores; register r of a lane is row (r & 3) + 8 (r >> 2) + 4 half of the tile.  The test is
+                // non-strict (d^2 <= k-th d^2): in norm order a later row may have a LOWER original index than the list's
+                // k-th entry, and the exact insert decides.
+                int ia[16], ib[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int4 nn = *reinterpret_cast<const int4*>(&lds_nn[slot][tile * 32 + 8 * g + 4 * half]);
+                    const int n4[4] = {nn.x, nn.y, nn.z, nn.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = a0[4 * g + k], y = a1[4 * g + k];
+                        ia[4 * g + k] = 2 * x + n4[k]; ib[4 * g + k] = 2 * y + n4[k];
+                    }
+                }
                 const uint32_t row0 = (uint32_t)(j * KM_ST_ROWS + tile * 32 + 4 * half);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    const bool gate = k < 5 ? (ta[k < 5 ? k : 0] > thrA || tb[k < 5 ? k : 0] > thrB) : (ia[15] > thrA || ib[15] > thrB);
-                    if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
+                    const int ga = k < 5 ? max(max(ia[3 * (k < 5 ? k : 0)], ia[3 * (k < 5 ? k : 0) + 1]), ia[3 * (k < 5 ? k : 0) + 2]) : ia[15];
+                    const int gb = k < 5 ? max(max(ib[3 * (k < 5 ? k : 0)], ib[3 * (k < 5 ? k : 0) + 1]), ib[3 * (k < 5 ? k : 0) + 2]) : ib[15];
+                    if (__builtin_amdgcn_ballot_w64(ga >= thrA || gb >= thrB) == 0ull) continue;
 #pragma unroll
                     for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
                         const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
-                        const bool h0 = ia[r] > thrA, h1 = ib[r] > thrB;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h0) != 0ull, 0)) {
-                            if (h0) { PA[cntA * 64 + lane] = ((unsigned long long)(uint32_t)(nqA - ia[r]) << 32) | row; ++cntA; }
-                        }
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h1) != 0ull, 0)) {
-                            if (h1) { PB[cntB * 64 + lane] = ((unsigned long long)(uint32_t)(nqB - ib[r]) << 32) | row; ++cntB; }
+                        const bool h0 = ia[r] >= thrA, h1 = ib[r] >= thrB;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h0 || h1) != 0ull, 0)) {
+                            if (h0 || h1) {
+                                const unsigned long long orig = (uint32_t)perm[row];          // row of the caller's train matrix
+                                if (h0) { PA[cntA * 64 + lane] = ((unsigned long long)(uint32_t)(nqA - ia[r]) << 32) | orig; ++cntA; }
+                                if (h1) { PB[cntB * 64 + lane] = ((unsigned long long)(uint32_t)(nqB - ib[r]) << 32) | orig; ++cntB; }
+                            }
                         }
                     }
                 }

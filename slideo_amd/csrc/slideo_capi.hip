@@ -1036,23 +1036,37 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     hipStream_t st = S.st;
     const int nt_pad = knn_pad_rows(nt);
     const int qblocks = cdiv(nq, KM_QPB);
-    DevBuf d_q, d_t, d_tx, d_tn, d_keys, d_pend;
+    DevBuf d_q, d_t, d_tx, d_tn, d_norm, d_perm, d_keys, d_pend;
     d_q.reserve((size_t)nq * 128); d_t.reserve(std::max<size_t>((size_t)nt * 128, 64));
     d_tx.reserve((size_t)nt_pad * 128); d_tn.reserve((size_t)nt_pad * 4);
+    d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64)); d_perm.reserve((size_t)nt_pad * 4);
     d_keys.reserve((size_t)nq * KLIST * 8); d_pend.reserve((size_t)qblocks * KM_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
     HIP_CHECK(hipMemcpyAsync(d_q.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
-    if (nt) HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
-    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, d_tx.as<uint4>(), d_tn.as<int32_t>());
+    // train-set preparation (once per set; here per call, this being a tap): norms on the device, the norm order on the
+    // host (a stable index sort), then the centred tile-major operand gathered in that order
+    std::vector<int32_t> h_norm((size_t)std::max(nt, 1)), h_perm((size_t)nt_pad, -1);
+    if (nt) {
+        HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
+        knl_norms_kernel<<<cdiv(nt, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, d_norm.as<int32_t>());
+        check_launch("knl_norms_kernel");
+        HIP_CHECK(hipMemcpyAsync(h_norm.data(), d_norm.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < nt; ++i) h_perm[i] = i;
+        std::stable_sort(h_perm.begin(), h_perm.begin() + nt, [&](int32_t a, int32_t b) { return h_norm[a] < h_norm[b]; });
+    }
+    HIP_CHECK(hipMemcpyAsync(d_perm.p, h_perm.data(), (size_t)nt_pad * 4, hipMemcpyHostToDevice, st));
+    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, d_perm.as<int32_t>(), d_norm.as<int32_t>(),
+                                                                   d_tx.as<uint4>(), d_tn.as<int32_t>());
     check_launch("knl_expand_train_kernel");
     const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
-        knn_l2_kernel<8><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+        knn_l2_kernel<8><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                           d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     else if (kl == 16)
-        knn_l2_kernel<16><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+        knn_l2_kernel<16><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                            d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     else
-        knn_l2_kernel<KLIST><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), nt_pad,
+        knn_l2_kernel<KLIST><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                               d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     check_launch("knn_l2_kernel");
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
