@@ -81,8 +81,8 @@ __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsign
 
 // q: [nq][128] u8; tx / tnn: expanded train and negated norms (above); out: [nq][KL] u64 keys (one segment).
 // KL = list length: 8 serves k <= 8 (the k = 2 of a ratio test) with 16 list registers and few insertions
-// (17.8 ms per 126.6e9 pairs), 16 serves k <= 16 (about 22 ms), 32 serves k <= 32, whose 64 list registers make the
-// flush spill (still exact, 28.4 ms).
+// (15.8 ms per 126.6e9 pairs), 16 serves k <= 16 (18.0 ms), 32 serves k <= 32, whose 64 list registers make the
+// flush spill (still exact, 26.4 ms).
 // Grid ceil(nq / 512), block 512.
 template <int KL>
 __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq,
