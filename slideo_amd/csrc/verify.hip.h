@@ -331,8 +331,14 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
                 float e = ea * ea + eb * eb;
                 good += (e <= thr2) ? 1 : 0;
             }
-            // sequential acceptance over the 64 iterations of this chunk
+            // sequential acceptance over the 64 iterations of this chunk.  max_good only grows, so if no iteration of the
+            // chunk beats the current best none is accepted and the scan is skipped (the usual case for the many
+            // candidates without a consistent model, which otherwise spent most of their time here).
             bool stop = false;
+            if (__builtin_amdgcn_ballot_w64(good > max(max_good, 1) && base + lane < niters) == 0ull) {
+                if (base + 64 >= niters) break;
+                continue;
+            }
             for (int i = 0; i < 64; ++i) {
                 if (base + i >= niters) { stop = true; break; }
                 int g = __shfl(good, i);
