@@ -457,11 +457,14 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
         check_launch("vote_kernel");
-        ransac_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(),
-                                                                     m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                                                                     m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(),
-                                                                     S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
-        check_launch("ransac_kernel");
+        ransac_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
+            vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+            m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+        check_launch("ransac_kernel (small)");
+        ransac_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
+            vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+            m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+        check_launch("ransac_kernel (large)");
         uint32_t* pair_count = S.d_pairs.as<uint32_t>();
         PairDesc* pair_list = reinterpret_cast<PairDesc*>(S.d_pairs.as<uint8_t>() + 64);
         HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));

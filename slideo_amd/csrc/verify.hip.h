@@ -30,6 +30,7 @@ namespace slideo {
 constexpr int VOTE_KLIST = 32;   // key-list stride of the kNN stage (KLIST in slideo_capi.hip; checked there)
 constexpr int MAXC = 64;       // >= max_candidate_pages
 constexpr int MAXR = 16;       // >= max_rated
+constexpr int RANSAC_SMALL_PTS = 256;   // candidates with at most this many votes go to the small-LDS instance
 constexpr int RANSAC_LDS_PTS = 1024;    // point pairs kept in LDS (more go through global memory); 17 KB per 64-thread block = 9 blocks per CU
 
 struct FrameCands {            // one per frame of the batch, device resident
@@ -260,22 +261,27 @@ __device__ __forceinline__ double lm_eval(const float4* pts, const uint8_t* mask
     return S;
 }
 
+// Two instances share the grid: <RANSAC_SMALL_PTS> takes the candidates with few votes (most of the <= 40 per frame;
+// 4 KB of LDS, so the register file and not LDS bounds the occupancy), <RANSAC_LDS_PTS> the rest; a block whose
+// candidate belongs to the other instance exits at once.
+template <int LDS_PTS, int MIN_COUNT>
 __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                     const slideo_keypoint* __restrict__ frame_kp,
                                                     const float2* __restrict__ page_xy,
                                                     const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
                                                     FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
                                                     uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
-    __shared__ float4 lpts[RANSAC_LDS_PTS];
-    __shared__ uint8_t lmask[RANSAC_LDS_PTS];
+    __shared__ float4 lpts[LDS_PTS];
+    __shared__ uint8_t lmask[LDS_PTS];
     const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     FrameCands& fc = fcs[f];
     if (r >= fc.ncand) return;
     const int count = fc.count[r];
+    if (count < MIN_COUNT || (MIN_COUNT == 0 && count > LDS_PTS)) return;      // the other instance's candidate
     const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
     const uint2* vt = votes + vbase;
-    float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
-    uint8_t* mask = count <= RANSAC_LDS_PTS ? lmask : gmask + vbase;
+    float4* pts = count <= LDS_PTS ? lpts : gpts + vbase;
+    uint8_t* mask = count <= LDS_PTS ? lmask : gmask + vbase;
     // (4 votes per lane and round: the three dependent gathers of a vote — vote, slide point, frame keypoint — are
     // each issued for all four before the first is used)
     const uint32_t qbase_f = qofs[f];
@@ -310,15 +316,31 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
             uint32_t b = rng_tab[pos + 2 * lane + 1] % (uint32_t)count;
             if (__builtin_amdgcn_ballot_w64(a == b) == 0ull) pos += 128;
             else {
-                uint32_t p = pos;
-                for (int it = 0; it < 64; ++it) {
-                    uint32_t i0 = rng_tab[min(p, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count, i1;
-                    ++p;
-                    do { i1 = rng_tab[min(p, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count; ++p; } while (i1 == i0 && p < (uint32_t)RNG_TABLE);
-                    if (it == lane) { a = i0; b = i1; }
+                // Some iteration redraws its second index, which shifts the stream position of every later iteration:
+                // start_{j+1} = start_j + 2 + e_j, e_j = redraws of iteration j.  Instead of replaying the 64 iterations one
+                // after the other, every lane evaluates its iteration from a guessed start (pos + 2 lane + shift) and the
+                // shifts are corrected by a prefix sum of the e_j until nothing moves: lane 0 is right from the start, a lane
+                // is right one round after all the lanes before it, and a round that changes no shift satisfies the recurrence.
+                uint32_t shift = 0, total = 0;
+                for (;;) {
+                    const uint32_t p0 = pos + 2 * lane + shift;
+                    const uint32_t i0 = rng_tab[min(p0, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count;
+                    uint32_t e = 0, i1;
+                    for (;;) {
+                        i1 = rng_tab[min(p0 + 1 + e, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count;
+                        if (i1 != i0 || p0 + 1 + e >= (uint32_t)RNG_TABLE - 1) break;
+                        ++e;
+                    }
+                    uint32_t inc = e;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+                    const uint32_t nshift = inc - e;
+                    const bool changed = nshift != shift;
+                    shift = nshift;
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0ull) { a = i0; b = i1; total = __shfl(inc, 63); break; }
                 }
-                if (p >= (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
-                pos = p;
+                pos += 128 + total;
+                if (pos >= (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
             }
             double M[6];
             similarity_from_2(pts[a], pts[b], M);
