@@ -17,7 +17,9 @@
  * published algorithms as restated in SURVEY.md Appendix A (cited as [OCV A.n],
  * upstream file named).  The self-consistency constants of SURVEY.md Appendix B
  * (pattern SHA-256, quotas, umax, pyramid sizes, RNG draws) are asserted by
- * tests/test_oracle_constants.py.
+ * tests/test_oracle_constants.py; tests/test_oracle_crosscheck.py holds the
+ * primitives to an independent implementation (scikit-image / SciPy known
+ * answers in tests/golden/crosscheck.npz) — definitions, not OpenCV's rounding.
  *
  * Deliberate, documented departures from what the reference *runs*:
  *   - kNN is exact brute force, not FLANN-LSH (north_star);
