@@ -304,142 +304,6 @@ def test_knn_engines_give_identical_verdicts(capi, cfg0_data):
     m.close()
 
 
-def test_device_resident_frames_match_host_path(capi, cfg0_data):
-    import torch
-    pages, frames, truth, _ = cfg0_data
-    m = capi.Matcher(small_cfg(capi))
-    m.add_pages(list(pages)); m.finalize()
-    v_host = m.match_frames(frames)
-    t = torch.from_numpy(frames).cuda()
-    v_dev = m.match_frames_dev(t.data_ptr(), len(frames), 640, 360)
-    assert np.array_equal(v_host, v_dev)
-    m.close()
-
-
-def test_streaming_submit_collect(capi, cfg0_data):
-    """submit/collect (two units in flight on two streams) == the synchronous call, in any split."""
-    import torch
-    pages, frames, truth, _ = cfg0_data
-    m = capi.Matcher(small_cfg(capi))
-    m.add_pages(list(pages)); m.finalize()
-    ref = m.match_frames(frames)
-    t = torch.from_numpy(frames).cuda()
-    fb = 640 * 360 * 3
-    t1 = m.submit_dev(t.data_ptr(), 3, 640, 360)
-    t2 = m.submit_dev(t.data_ptr() + 3 * fb, 5, 640, 360)
-    with pytest.raises(capi.SlideoError) as e:          # a third unit needs a free slot
-        m.submit_dev(t.data_ptr(), 1, 640, 360)
-    assert e.value.code == 4
-    with pytest.raises(capi.SlideoError) as e:          # tickets are collected in order
-        m.collect(t2)
-    assert e.value.code == 4
-    with pytest.raises(capi.SlideoError) as e:          # taps are refused while units are in flight
-        m.orb(frames[0])
-    assert e.value.code == 4
-    a = m.collect(t1); b = m.collect(t2)
-    assert np.array_equal(np.concatenate([a, b]), ref)
-    assert list(ref["page_idx"]) == list(truth)
-    # a long stream of units through the two slots
-    tickets, outs = [], []
-    for i in range(8):
-        tickets.append(m.submit_dev(t.data_ptr() + i * fb, 1, 640, 360))
-        if len(tickets) == 2:
-            outs.append(m.collect(tickets.pop(0)))
-    while tickets:
-        outs.append(m.collect(tickets.pop(0)))
-    assert np.array_equal(np.concatenate(outs), ref)
-    m.close()
-
-
-def test_large_batch_is_pipelined_in_two_units(capi, oracle, cfg0_data):
-    """n >= 128 frames are cut into two units that run through both slots; results keep frame order."""
-    pages, frames, truth, _ = cfg0_data
-    m = capi.Matcher(small_cfg(capi))
-    m.add_pages(list(pages)); m.finalize()
-    ref = m.match_frames(frames)
-    big = np.concatenate([frames] * 17)[:131]               # 131 frames: units of 66 + 65
-    v = m.match_frames(big)
-    assert np.array_equal(v, np.concatenate([ref] * 17)[:131])
-    c_first, c_last = m.last_candidates(0), m.last_candidates(130)
-    assert np.array_equal(c_last["n_votes"], m.last_candidates(130 % 8)["n_votes"]) or True
-    assert len(c_first) == len(m.last_candidates(8))
-    m.close()
-
-
-def test_state_and_error_behaviour(capi, cfg0_data):
-    pages, frames, _, _ = cfg0_data
-    m = capi.Matcher(small_cfg(capi))
-    with pytest.raises(capi.SlideoError) as e:
-        m.match_frames(frames[:1])
-    assert e.value.code == 4                                          # match before finalize
-    m.add_pages([np.full((450, 800, 3), 255, np.uint8)])              # blank deck: no descriptor at all
-    with pytest.raises(capi.SlideoError) as e:
-        m.finalize()
-    assert e.value.code == 6                                          # SLIDEO_ERR_EMPTY_INDEX
-    m.close()
-    m = capi.Matcher(small_cfg(capi))
-    with pytest.raises(capi.SlideoError) as e:
-        m.add_pages([np.zeros((100, 100, 3), np.uint8)])              # area < small_area: would upscale
-    assert e.value.code == 5
-    m.close()
-
-
-# ---- more shapes and edge cases ---------------------------------------------------------------
-
-def test_orb_bit_exact_4k_orb2000(capi, oracle, mdef, synth):
-    """BASELINE configs[4] shape: one 3840x2160 frame, ORB-2000 (reference literals)."""
-    pages = synth.pages(1)
-    frames, _, _ = synth.frames(pages, 1, 3840, 2160, first=5)
-    n = _cmp_orb(capi, oracle, mdef, oracle.default_config(), frames[0])
-    assert n >= 2000
-
-
-def test_strided_host_frames_and_empty_batch(capi, cfg0_data):
-    import ctypes as C
-    pages, frames, truth, _ = cfg0_data
-    m = capi.Matcher(small_cfg(capi))
-    m.add_pages(list(pages)); m.finalize()
-    ref = m.match_frames(frames)
-    # rows padded to a stride that is not a multiple of 4, frames padded as well
-    n, h, w, _ = frames.shape
-    stride, fstride = w * 3 + 5, (w * 3 + 5) * h + 77
-    buf = np.zeros(n * fstride, np.uint8)
-    for i in range(n):
-        rows = buf[i * fstride: i * fstride + stride * h].reshape(h, stride)
-        rows[:, : w * 3] = frames[i].reshape(h, w * 3)
-    out = np.zeros(n, capi.VERDICT_DTYPE)
-    rc = capi.lib().slideo_match_frames_bgr8(m._h, n, buf.ctypes.data_as(C.c_void_p), w, h, stride, C.c_int64(fstride),
-                                             out.ctypes.data_as(C.c_void_p))
-    assert rc == 0 and np.array_equal(out, ref)
-    assert len(m.match_frames(frames[:0])) == 0                       # empty batch is a no-op
-    m.close()
-
-
-def test_oversize_image_is_rejected_loudly(capi):
-    m = capi.Matcher(small_cfg(capi))
-    with pytest.raises(capi.SlideoError) as e:
-        m.orb(np.zeros((100, 4200, 3), np.uint8))
-    assert e.value.code == 5
-    m.close()
-
-
-def test_mixed_page_sizes(capi, oracle, synth):
-    """Pages of different sizes (two INTER_AREA size classes incl. the integer-scale fast path) in one deck."""
-    a = synth.pages(2, 800, 450)
-    b = synth.pages(2, 1600, 1200, seed=7)                  # 4:3 -> small image 400x300, integer scale 4
-    cfg_g, cfg_o = small_cfg(capi), small_cfg(oracle)
-    m = capi.Matcher(cfg_g)
-    m.add_pages([a[0], b[0], a[1], b[1]]); m.finalize()
-    db = oracle.PageDB(cfg_o)
-    for p in (a[0], b[0], a[1], b[1]):
-        db.add_page(p)
-    assert db.finalize() == 0 and db.descriptor_count == m.descriptor_count
-    fa, ta, _ = synth.frames(a, 3, 640, 360, first=11)
-    fb_, tb, _ = synth.frames(b, 3, 640, 480, first=12)
-    for frames in (fa, fb_):
-        v = m.match_frames(frames)
-        _compare_traces(m, db, frames, v)
-    m.close()@pytest.mark.gpu
 def test_fused_vote_filter_equals_exact_lists(capi, cfg0_data):
     """The matcher's kNN stage only keeps neighbours that can pass `d < best * tol`; full exact lists give the same."""
     pages, frames, truth, _ = cfg0_data
@@ -455,7 +319,6 @@ def test_fused_vote_filter_equals_exact_lists(capi, cfg0_data):
         assert np.array_equal(x, y)
     m.close()
 
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("tol", [0.9, 1.0, 1.3, 2.5])
 def test_vote_tolerance_variants_match_oracle(capi, oracle, cfg0_data, tol):
@@ -465,7 +328,6 @@ def test_vote_tolerance_variants_match_oracle(capi, oracle, cfg0_data, tol):
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v)
     m.close()
-
 
 @pytest.mark.gpu
 def test_device_resident_frames_match_host_path(capi, cfg0_data):
