@@ -319,7 +319,7 @@ def test_fused_vote_filter_equals_exact_lists(capi, cfg0_data):
         assert np.array_equal(x, y)
     m.close()
 
-@pytest.mark.gpu
+
 @pytest.mark.parametrize("tol", [0.9, 1.0, 1.3, 2.5])
 def test_vote_tolerance_variants_match_oracle(capi, oracle, cfg0_data, tol):
     """Other vote tolerances (incl. <= 1, where rows below the current best must still be kept) vs the oracle."""
@@ -329,7 +329,7 @@ def test_vote_tolerance_variants_match_oracle(capi, oracle, cfg0_data, tol):
     _compare_traces(m, db, frames, v)
     m.close()
 
-@pytest.mark.gpu
+
 def test_device_resident_frames_match_host_path(capi, cfg0_data):
     import torch
     pages, frames, truth, _ = cfg0_data
