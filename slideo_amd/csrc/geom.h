@@ -83,6 +83,30 @@ inline void umax_table(int half, int* umax /* half+2 */) {
     }
 }
 
+// Weights of the intensity-centroid disc for describe_kernel: entry (row v + half, dword column c) -> two dwords of
+// four byte weights each: (u + half) inside the disc else 0, and 1 inside the disc else 0, for u = 4c + j - half.
+// `shift` = log2 of the padded dword columns per row; the table is zero-padded to a multiple of 64 entries.
+inline void ic_weight_table(int half, const int* umax, std::vector<uint32_t>& tab, int& shift) {
+    const int n = 2 * half + 1, ncol = (n + 3) / 4;
+    shift = 0;
+    while ((1 << shift) < ncol) ++shift;
+    const int ncp = 1 << shift;
+    size_t entries = ((size_t)n * ncp + 63) & ~(size_t)63;
+    tab.assign(entries * 2, 0u);
+    for (int r = 0; r < n; ++r) {
+        const int v = r - half, av = v < 0 ? -v : v;
+        for (int c = 0; c < ncol; ++c) {
+            uint32_t wu = 0, wm = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int uu = 4 * c + j, u = uu - half, au = u < 0 ? -u : u;
+                if (uu < n && au <= umax[av]) { wu |= (uint32_t)uu << (8 * j); wm |= 1u << (8 * j); }
+            }
+            tab[((size_t)r * ncp + c) * 2] = wu;
+            tab[((size_t)r * ncp + c) * 2 + 1] = wm;
+        }
+    }
+}
+
 // [OCV A.7] cv::RNG (64-bit multiply-with-carry)
 struct CvRng {
     uint64_t state;

@@ -680,13 +680,36 @@ __device__ __forceinline__ float fast_atan2f_cv(float y, float x) {
     return a;
 }
 
+// Window geometry of describe_kernel (host side: describe_window()).  The rotated pattern reaches
+// ceil(half_patch * sqrt 2) pixels from the centre and the 7x7 blur 3 more: R = that + 3.  A wave stages the
+// (2R+1) rows x wpd dwords around its keypoint (x aligned down to 4) in LDS, padded to whole wave-instructions.
+constexpr int DESC_LDS_ROWS = 4;            // tap rows 0..3 of a sample from LDS, 4..6 from global (measured: 3 -> 1.81, 4 -> 1.53, 5 -> 1.56, 7 -> 1.91 ms)
+struct DescWin { int32_t R, wpd, dwords; };
+inline DescWin describe_window(int half_patch) {
+    DescWin d;
+    d.R = (int)ceil((double)half_patch * sqrt(2.0)) + 3;
+    d.wpd = ((2 * d.R + 1 + 3) + 3) / 4;
+    d.wpd |= 1;                                                  // odd dword pitch: rows start in different banks
+    d.dwords = (((2 * d.R + 1) * d.wpd + 2) + 63) & ~63;         // + 2: the 8-byte read of the last tap row may run past the row
+    return d;
+}
+
+// The blurred level is never materialised for the descriptors: each of the 512 samples of a keypoint needs one value
+// of the 7x7 fixed-point Gaussian, 25 k multiply-adds per keypoint against 90 k per keypoint for blurring the whole
+// pyramid (the 95 x 95 patches of 1000 keypoints cover more than the pyramid's area, so a sparse blur saves nothing),
+// and the full blur's write + read of the pyramid disappears.  Integer-exact: sum_r k_r (sum_j k_j p) is what
+// blur_kernel rounds, in any order.  The intensity centroid reads the same window.  (blur_kernel stays for the
+// pyramid tap, which is how the parity tests see the blurred levels.)
+// One wave per keypoint, 4 keypoints per block, dynamic LDS 4 * dw.dwords * 4 bytes.
 __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
-                                                       const uint8_t* __restrict__ blur,
                                                        const OrbTables* __restrict__ tab,
                                                        const uint32_t* __restrict__ qofs, int nframes,
-                                                       const uint64_t* __restrict__ items, uint32_t qtot,
+                                                       const uint64_t* __restrict__ items, uint32_t qtot, DescWin dw,
+                                                       const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
                                                        slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc) {
-    const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) uint32_t desc_lds[];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
     if (gi >= qtot) return;
     // frame of this keypoint: last f with qofs[f] <= gi (wave-uniform binary search)
@@ -697,42 +720,81 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
     const int score = (int)(it & 255), px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
     const LevelGeom L = g.lv[l];
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
-    const uint8_t* bl = blur + (int64_t)f * g.frame_bytes + L.ofs;
     const int half = g.half_patch;
-    // intensity centroid over the disc |u| <= umax[|v|], lanes across u
-    // (rows are read 8 at a time, unconditionally — the whole square lies inside the level — and masked by the disc
-    // afterwards: the rolled, predicated loop waited for one byte load per row, 63 dependent L2 round trips per keypoint)
-    int m10 = 0, m01 = 0;
-    for (int u0 = -half; u0 <= half; u0 += 64) {
-        const int u = min(u0 + lane, half);
-        const bool lane_in = u0 + lane <= half;
-        const int au = u < 0 ? -u : u;
-        const uint8_t* col = img + (int64_t)(py - half) * L.pitch + px + u;
-        for (int v0 = -half; v0 <= half; v0 += 8) {
-            int p[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) p[k] = col[(int64_t)min(v0 + k + half, 2 * half) * L.pitch];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int v = v0 + k;
-                if (v <= half) {                                    // wave-uniform
-                    const int av = v < 0 ? -v : v;
-                    const int pv = (lane_in && au <= tab->umax[av]) ? p[k] : 0;
-                    m10 += u * pv; m01 += v * pv;
-                }
-            }
+    const float sf = L.scale;
+    const float kx = (float)px * sf, ky = (float)py * sf;
+    // computeOrbDescriptors: centre = cvRound(pt * (1/scale)) on the level
+    const float inv = 1.f / sf;
+    const int cx = (int)rintf(kx * inv), cy = (int)rintf(ky * inv);
+
+    // ---- stage the window: rows cy-R .. cy+R, bytes xa .. xa + 4 wpd (config_supported keeps it inside the level) ----
+    const int R = dw.R, wpd = dw.wpd, WP = wpd * 4, wrows = 2 * R + 1;
+    uint32_t* win32 = desc_lds + wave * dw.dwords;
+    const uint8_t* win = reinterpret_cast<const uint8_t*>(win32);
+    const int x0w = cx - R, xa = x0w & ~3, xoff = x0w - xa;
+    {
+        const uint8_t* src0 = img + (int64_t)(cy - R) * L.pitch + xa;
+        const int drow = 64 / wpd, dcol = 64 - drow * wpd;           // flat index + 64 = (row + drow, col + dcol), carry once
+        int row = lane / wpd, col = lane - row * wpd;
+        for (int i = 0; i < dw.dwords; i += 64) {
+            const int rr = min(row, wrows - 1);                       // pad lanes re-read the last row
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (int64_t)rr * L.pitch + col * 4),
+                                             (__attribute__((address_space(3))) void*)(win32 + i), 4, 0, 0);
+            row += drow; col += dcol;
+            if (col >= wpd) { col -= wpd; ++row; }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- intensity centroid over the disc |u| <= umax[|v|] on the unblurred level ----
+    // a lane takes 4 pixels (one dword of a disc row) per step; the disc mask and the u weights come as byte weights
+    // from ic_tab (geom.h ic_weight_table), so a step is one LDS dword, one table entry, two dot4 and a multiply-add:
+    //   m10 = sum (u + half) p - half sum p,   m01 = sum_rows v * (row sum)
+    int m10, m01 = 0;
+    {
+        const int ic0 = (py - cy + R - half) * WP + (px - cx + R - half) + xoff;      // byte of (u, v) = (-half, -half)
+        const int ncm = (1 << ic_shift) - 1;
+        uint32_t accU = 0, accS = 0;
+        for (int e = lane; e < ic_entries; e += 64) {
+            const int row = e >> ic_shift, c = e & ncm;
+            uint32_t d;
+            __builtin_memcpy(&d, win + ic0 + row * WP + 4 * c, 4);     // pad entries read past the disc with weight 0
+            const uint2 wgt = ic_tab[e];
+            const uint32_t srow = __builtin_amdgcn_udot4(d, wgt.y, 0u, false);
+            accU = __builtin_amdgcn_udot4(d, wgt.x, accU, false);
+            accS += srow;
+            m01 += (row - half) * (int)srow;
+        }
+        m10 = (int)accU - half * (int)accS;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
     const float angle = fast_atan2f_cv((float)m01, (float)m10);
-    const float sf = L.scale;
-    const float kx = (float)px * sf, ky = (float)py * sf;
-    // computeOrbDescriptors: centre = cvRound(pt * (1/scale)) on the blurred level
-    const float inv = 1.f / sf;
     const float ang = angle * (float)(3.14159265358979323846 / 180.f);
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
-    const int cx = (int)rintf(kx * inv), cy = (int)rintf(ky * inv);
+
+    // ---- 256 comparisons of blurred samples; the blur is evaluated at the sample: 7 rows x (8 bytes, 2 dot4), 7 mads ----
+    const uint32_t g0 = (uint32_t)tab->gk[0], g1 = (uint32_t)tab->gk[1], g2 = (uint32_t)tab->gk[2], g3 = (uint32_t)tab->gk[3],
+                   g4 = (uint32_t)tab->gk[4], g5 = (uint32_t)tab->gk[5], g6 = (uint32_t)tab->gk[6];
+    const uint32_t k0123 = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), k456 = g4 | (g5 << 8) | (g6 << 16);
+    const uint32_t gr[7] = {g0, g1, g2, g3, g4, g5, g6};
+    const int s0 = (R - 3) * WP + (R - 3) + xoff;                     // byte of the top-left tap of the sample at offset (0, 0)
+    auto blurred = [&](int sx, int sy) -> uint32_t {
+        const uint8_t* pp = win + s0 + sy * WP + sx;
+        uint32_t acc = 1u << 15;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            uint64_t v8;
+            // random 8-byte gathers are bank-conflict bound in LDS (about 10 % of its peak): the last rows go through
+            // the vector L1 instead, where the window's lines sit after the staging pass, and the two queues drain in parallel
+            if (r >= DESC_LDS_ROWS) __builtin_memcpy(&v8, img + (int64_t)(cy + sy + r - 3) * L.pitch + (cx + sx - 3), 8);
+            else __builtin_memcpy(&v8, pp + r * WP, 8);                // unaligned ds_read_b64
+            uint32_t hsum = __builtin_amdgcn_udot4((uint32_t)v8, k0123, 0u, false);
+            hsum = __builtin_amdgcn_udot4((uint32_t)(v8 >> 32), k456, hsum, false);
+            acc += __umul24(hsum, gr[r]);                             // hsum <= 255 * 256
+        }
+        return acc >> 16;
+    };
     uint64_t bits[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -742,8 +804,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
         const float p1x = (float)(int8_t)((pw >> 16) & 255), p1y = (float)(int8_t)(pw >> 24);
         const float x0 = p0x * a - p0y * b, y0 = p0x * b + p0y * a;
         const float x1 = p1x * a - p1y * b, y1 = p1x * b + p1y * a;
-        const int t0 = bl[(int64_t)(cy + (int)rintf(y0)) * L.pitch + cx + (int)rintf(x0)];
-        const int t1 = bl[(int64_t)(cy + (int)rintf(y1)) * L.pitch + cx + (int)rintf(x1)];
+        const uint32_t t0 = blurred((int)rintf(x0), (int)rintf(y0));
+        const uint32_t t1 = blurred((int)rintf(x1), (int)rintf(y1));
         bits[w] = __builtin_amdgcn_ballot_w64(t0 < t1);
     }
     if (lane < 4) reinterpret_cast<uint64_t*>(desc + (size_t)gi * 32)[lane] = bits[lane];

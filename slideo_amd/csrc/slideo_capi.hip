@@ -94,7 +94,8 @@ struct slideo_matcher {
     void* progress_user = nullptr;
     size_t ws_budget = (size_t)12 << 30;
 
-    DevBuf d_tables, d_rng;
+    DevBuf d_tables, d_rng, d_ictab;
+    int ic_shift = 0, ic_entries = 0;     // intensity-centroid weight table of describe_kernel (geom.h ic_weight_table)
     std::vector<std::unique_ptr<GeomEntry>> geoms;
 
     // INTER_AREA size classes
@@ -200,13 +201,15 @@ void require_idle(slideo_matcher* m) {
 
 // ---- ORB over `n` equally sized frames already on the device, in three steps -------------
 // stage 1: gray, pyramid, FAST+NMS, blur, retainBest thresholds, per-frame offsets; copies {Qtot, max, flags} to pinned memory
-void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
+// `with_blur`: also materialise the blurred pyramid (only the pyramid tap wants it; describe_kernel blurs at its samples)
+void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+                bool with_blur = false) {
     hipStream_t st = S.st;
     GeomEntry& ge = geom_for(m, w, h);
     const PyrGeom& g = ge.g;
     const int L = g.nlevels;
-    S.d_pyr.reserve((size_t)g.frame_bytes * n);
-    S.d_blur.reserve((size_t)g.frame_bytes * n);
+    S.d_pyr.reserve((size_t)g.frame_bytes * n + 256);      // + slack: describe_kernel stages whole dwords past a window's last byte
+    if (with_blur) S.d_blur.reserve((size_t)g.frame_bytes * n);
     S.d_cand.reserve(std::max<size_t>((size_t)g.cand_per_frame * n * 4, 16));
     const size_t n_cc = (size_t)n * L;
     S.d_hist.reserve(n_cc * 256 * 4);
@@ -244,7 +247,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
         check_launch("fast_kernel");
     }
-    if (g.blur_tiles > 0) {
+    if (with_blur && g.blur_tiles > 0) {
         blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
         check_launch("blur_kernel");
     }
@@ -288,16 +291,18 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
     while ((uint32_t)np2 < maxc) np2 <<= 1;
     sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(S.d_qofs.as<uint32_t>(), S.d_items.as<uint64_t>(), np2);
     check_launch("sort_kernel");
-    describe_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
-                                                        S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot,
-                                                        S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>());
+    const DescWin dw = describe_window(g.half_patch);
+    describe_kernel<<<cdiv((int)qtot, 4), 256, (size_t)dw.dwords * 16, st>>>(g, S.d_pyr.as<uint8_t>(), m->d_tables.as<OrbTables>(),
+                                                                             S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot, dw,
+                                                                             m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
+                                                                             S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>());
     check_launch("describe_kernel");
 }
 
 // synchronous ORB (page ingest, taps).  Leaves: d_qofs[n+1], d_kp[qtot], d_desc[qtot*32]; S.orb filled.
 void run_orb(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
-             bool keep_host_qofs) {
-    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride);
+             bool keep_host_qofs, bool with_blur = false) {
+    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride, with_blur);
     orb_wait_info(m, S);
     orb_stage2(m, S, w, h);
     if (keep_host_qofs) {
@@ -643,12 +648,21 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     brief_pattern(cfg->patch_size, t.pattern);
     mm->d_tables.reserve(sizeof(OrbTables));
     HIP_CHECK(hipMemcpy(mm->d_tables.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> ict;
+        ic_weight_table(cfg->patch_size / 2, t.umax, ict, mm->ic_shift);
+        mm->ic_entries = (int)(ict.size() / 2);
+        mm->d_ictab.reserve(ict.size() * 4);
+        HIP_CHECK(hipMemcpy(mm->d_ictab.p, ict.data(), ict.size() * 4, hipMemcpyHostToDevice));
+    }
     std::vector<uint32_t> rng(RNG_TABLE);
     CvRng r((uint64_t)-1);
     for (auto& v : rng) v = r.next();
     mm->d_rng.reserve(rng.size() * 4);
     HIP_CHECK(hipMemcpy(mm->d_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  describe_window(cfg->patch_size / 2).dwords * 16));
     m = mm.release();
     *out = m;
     API_CATCH(nullptr)
@@ -987,7 +1001,7 @@ int32_t slideo_pyramid_level_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t
     const size_t fb = (size_t)height * stride_bytes;
     S.d_stage.reserve(fb + 16);
     HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, st));
-    run_orb(m, S, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, false);
+    run_orb(m, S, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, false, blurred != 0);
     const LevelGeom& L = geom_for(m, width, height).g.lv[level];
     *lw = L.w; *lh = L.h;
     if ((int64_t)L.w * L.h > out_capacity) fail(SLIDEO_ERR_CAPACITY, "level needs %lld bytes", (long long)L.w * L.h);
