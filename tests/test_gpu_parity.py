@@ -563,3 +563,35 @@ def test_end_to_end_other_verify_parameters(capi, oracle, cfg0_data, over):
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v)
     m.close()
+
+
+# ---- size-independent properties at the headline shapes (no CPU oracle at this size) -----------------------------
+def test_headline_shape_properties(capi, synth):
+    """1080p frames against full-size pages with the reference's literal parameters (ORB-1000, k = 30, min rating 50):
+    the verdicts must not depend on how frames are batched or ordered, repeat exactly, and assign the right page."""
+    P, B = 120, 96
+    pages = synth.pages(P, 2001, 1125)
+    frames, truth, _ = synth.frames(pages, B, 1920, 1080)
+    m = capi.Matcher(capi.default_config(nfeatures=1000))
+    for i in range(0, P, 40):
+        m.add_pages(list(pages[i:i + 40]))
+    m.finalize()
+    assert m.descriptor_count > 100000
+    v = m.match_frames(frames)
+    assert np.array_equal(v, m.match_frames(frames))                          # idempotent
+    # batch composition: a sub-batch alone, and a permuted batch
+    assert np.array_equal(v[16:48], m.match_frames(frames[16:48]))
+    perm = np.random.default_rng(5).permutation(B)
+    assert np.array_equal(v[perm], m.match_frames(np.ascontiguousarray(frames[perm])))
+    # the streaming form in two units gives the same records
+    import torch
+    t = torch.from_numpy(frames).cuda()
+    t1 = m.submit_dev(t[:40].data_ptr(), 40, 1920, 1080)
+    t2 = m.submit_dev(t[40:].data_ptr(), B - 40, 1920, 1080)
+    w = np.concatenate([m.collect(t1), m.collect(t2)])
+    assert np.array_equal(v, w)
+    # page assignment against the generator's ground truth
+    got = v["page_idx"]
+    assert (got == truth).mean() >= 0.97
+    assert ((got >= 0) & (got != truth)).sum() <= 2                            # misses are "none", hardly ever another page
+    m.close()
