@@ -131,17 +131,18 @@ def main():
             dist.all_gather_into_tensor(d_all, d_verdicts)      # the one collective of the path (RCCL over xGMI)
         return v
 
-    def run_steps(k):
+    def run_steps(k, depth=None, local=False):
         """k steps; a step = one batch of B frames through the whole hot path.  Two batches are kept in flight
         (submit i+1 before collecting i) so that ORB of the next batch overlaps kNN / verify of the current one."""
         v, pending = None, []
-        depth = 1 if args.no_overlap else max(1, args.inflight)
+        depth = depth or (1 if args.no_overlap else max(1, args.inflight))
+        done = (lambda x: x) if local else finish           # local: no collective (only this rank runs these steps)
         for _ in range(k):
             if len(pending) == depth:
-                v = finish(m.collect(pending.pop(0)))
+                v = done(m.collect(pending.pop(0)))
             pending.append(m.submit_dev(d_frames.data_ptr(), B, fw, fh, stream=stream))
         while pending:
-            v = finish(m.collect(pending.pop(0)))
+            v = done(m.collect(pending.pop(0)))
         return v
 
     def barrier():
@@ -159,6 +160,15 @@ def main():
     dt = time.perf_counter() - t0
     prof, knn_pairs = m.read_profile()
     m.set_profiling(False)
+    # outside the timed region: the same launches with one batch in flight, i.e. each kernel alone on the GPU
+    # (under overlap the kNN shares the CUs with the other batch's ORB / verify kernels and its launches stretch)
+    prof_alone = None
+    if rank == 0 and not args.no_overlap and args.inflight > 1:
+        m.set_profiling(True)
+        run_steps(3, depth=1, local=True)
+        torch.cuda.synchronize()
+        prof_alone, pairs_alone = m.read_profile()
+        m.set_profiling(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -217,7 +227,16 @@ def main():
                 out["roofline"] = dict({"kernel": "knn_hamming_kernel<32> (v_xor_b32 + v_bcnt_u32_b32)", "bound": "valu",
                                         "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
                                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR}, **common)
+            if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
+                a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
+                unit_work = (2.0 * 256 if args.knn == "mfma" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
+                out["roofline"]["one_batch_in_flight"] = {
+                    "avg_launch_ms": round(a_s * 1e3, 4), "achieved": round(unit_work / a_s, 2),
+                    "frac": round(unit_work / a_s / out["roofline"]["peak"], 4),
+                    "note": "same kernel and input, 3 launches after the timed region with nothing else on the GPU"}
         out["stage_ms_per_step"] = {k: round(ms / max(args.steps, 1), 3) for k, (ms, n) in prof.items()}
+        if prof_alone:
+            out["stage_ms_one_batch_in_flight"] = {k: round(ms / max(n, 1), 3) for k, (ms, n) in prof_alone.items()}
         # ORB stage: algorithmic bytes per frame = 3wh + 5*Pi + 3.6 kB * K
         ws = [fw]; hs = [fh]
         for l in range(1, cfg.nlevels):

@@ -27,6 +27,11 @@ def main(path):
               (k[:44], a["n"], a["tot"] / 1e3, a["tot"] / a["n"] / 1e3, a["mn"] / 1e3, a["mx"] / 1e3,
                100.0 * a["tot"] / total, a["vg"], a["sg"], a["lds"], "x".join(map(str, a["grid"])), a["wg"]))
     print("total kernel time: %.1f us over %d dispatches" % (total / 1e3, len(rows)))
+    # the dominant kernel launch by launch, in start order: bench.py issues <warmup> launches, <steps> timed ones and
+    # (two-stream mode only) 3 more with one batch in flight after the timed region
+    dom = max((kv for kv in agg.items() if "rocclr" not in kv[0]), key=lambda kv: kv[1]["tot"], default=(None, None))[0]
+    durs = [dur / 1e3 for name, dur, *_ in rows if re.sub(r"\(.*", "", name) == dom]
+    print("%s launches in start order (us): %s" % (dom, " ".join("%.0f" % d for d in durs)))
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ def test_two_ranks_control_flow_over_gloo():
     env = dict(os.environ, SLIDEO_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
-                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--warmup", "1"], capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     for k in REQUIRED:
