@@ -27,7 +27,8 @@
 //
 // Block = 8 waves = 512 queries sharing the A tiles through LDS: super-tiles of 128 rows = 16 KB go through a
 // 4-slot ring filled by LDS-DMA and guarded by per-slot counters — no block barrier in the main loop.  Fast path
-// per tile and wave: 4 ds_read_b128 + 8 MFMA + 2 x 8 v_max3_i32 + 2 compares.
+// per tile and wave: 4 ds_read_b128 + 8 MFMA + 2 x 8 v_max3_i32 + 2 compares; the two accumulators of a wave run half
+// a tile apart so that each one's max tree is issued between the other's MFMAs (KM_SKEW).
 #pragma once
 #include <limits.h>
 #include <hip/hip_runtime.h>
@@ -46,7 +47,10 @@ constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-quer
 constexpr int KM_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
 constexpr int KM_RING = 4;                     // LDS ring slots (super-tiles resident per block)
 constexpr int KM_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
-constexpr int KM_MFMA_PRIO = 2;                // wave priority while its MFMAs are issued (0 elsewhere)
+#ifndef KM_MFMA_PRIO_V
+#define KM_MFMA_PRIO_V 1
+#endif
+constexpr int KM_MFMA_PRIO = KM_MFMA_PRIO_V;   // wave priority while its MFMAs are issued (0 elsewhere)
 constexpr int KM_ST_U4 = KM_ST_ROWS * 128 / 16;  // uint4 per super-tile (1024)
 
 // 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if 0, 0xA (-1.0) if 1; bit i -> nibble i.
@@ -88,13 +92,21 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 // its two source lanes pushed (v_med3 chain, KM_FLUSH_BATCH loads in flight), stores the list, and the new
 // thresholds are re-broadcast.  This batches the divergent part: an insert costs the whole wave ~35 VALU
 // instructions, and without batching it ran for what is usually ONE lane's candidate.
-// Exactness: thresholds only tighten, and only in a flush, which runs between tiles; every row of the tile being
+// Exactness: thresholds only tighten — in a flush, which runs between tiles, and (prune_tol > 0) right after a slow
+// path from the best row just pushed; every row of the tile being
 // scored is higher than every row already in a list, so a candidate with exactly the k-th distance is (correctly)
 // rejected by the strict filter, and nothing that belongs to the final top-k is ever filtered out.  With
 // prune_tol > 0 the threshold is additionally capped by the vote's acceptance bound (see the flush).
 constexpr int KM_FLUSH_AT = 16;
 constexpr int KM_FLUSH_BATCH = 4;
+#ifndef KM_SKEW
+#define KM_SKEW 1                                    // 1 = skewed main loop (see the kernel), 0 = the tile-synchronous loop before it
+#endif
+#if KM_SKEW
+constexpr int KM_PEND_CAP = 64;                      // >= KM_FLUSH_AT - 1 + 2 * 16 (flush test every second tile; a lane pushes <= 16 keys per tile and query)
+#else
 constexpr int KM_PEND_CAP = 32;                      // >= KM_FLUSH_AT - 1 + 16 (a lane pushes <= 16 keys per tile and query)
+#endif
 constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
 
 // Pending buffers: every lane has a PRIVATE buffer per query tile in a global workspace (L2 resident; the
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     uint32_t* const PB = PA + (size_t)KM_PEND_CAP * 64;
 
     knn_v8i bq0[4], bq1[4];
-    {
+    auto load_queries = [&]() {
         const uint32_t* q0 = q + (size_t)min(qbase + ql, nq - 1) * 8;
         const uint32_t* q1 = q + (size_t)min(qbase + 32 + ql, nq - 1) * 8;
 #pragma unroll
@@ -141,7 +153,8 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             bq0[s] = knn_v8i{(int)fp4_expand8(w0), (int)fp4_expand8(w0 >> 8), (int)fp4_expand8(w0 >> 16), (int)fp4_expand8(w0 >> 24), 0, 0, 0, 0};
             bq1[s] = knn_v8i{(int)fp4_expand8(w1), (int)fp4_expand8(w1 >> 8), (int)fp4_expand8(w1 >> 16), (int)fp4_expand8(w1 >> 24), 0, 0, 0, 0};
         }
-    }
+    };
+    load_queries();
     uint4* const my_list = reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qi, nq - 1)) * 32);
     const bool owner_valid = qi < nq;
     if (owner_valid) {
@@ -233,6 +246,149 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     };
     if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
+#if KM_SKEW
+    const int nst = st1 - st0;
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    // Skewed main loop.  The two accumulators of a wave run half a tile apart: while the four MFMAs of one are in the
+    // matrix pipe the wave's own VALU slots take the other's epilogue (max tree + threshold test), interleaved in
+    // program order (sched_group_barrier), so a wave keeps the pipe busy by itself instead of relying on a sibling
+    // wave being in its epilogue at the right moment (with two blocks per CU the younger block ran alone, two waves
+    // per SIMD, for the last quarter of the kernel with the pipe under half busy).  Tile t of the segment:
+    //     half 1:  a1 = F(t) x tile-1 queries      ||  test a0 (tile t)       -> candidates of a0
+    //     half 2:  a0 = F(t+1) x tile-0 queries    ||  test a1 (tile t)       -> candidates of a1
+    // a0 therefore reads the ring one tile ahead of a1: a slot is acquired when a0 enters its super-tile and released
+    // when a1 leaves it.  Rows past the end of the train set are not masked in the test (a spurious trip to the slow
+    // path in the last tile at worst); the slow path drops them by row index.
+    constexpr int TPS = KM_ST_ROWS / 32;                               // tiles per super-tile
+    const int T = nst * TPS;
+    auto acquire = [&](int j) {                                        // a0 is about to read super-tile j
+        const int jp = j - 1 + KM_AHEAD, jn = j + KM_AHEAD;
+        if (j > 0 && jp < nst) {                                       // publish this wave's share staged at acquire(j - 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            signal(&s_filled[jp % KM_RING]);
+        }
+        if (jn < nst) {                                                // slot was last read for super-tile jn - KM_RING
+            wait_ge(&s_done[jn % KM_RING], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
+            stage(jn, jn % KM_RING);
+        }
+        wait_ge(&s_filled[j % KM_RING], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
+    };
+    auto frag = [&](int t, int s) -> uint4 { return lds[(t / TPS) % KM_RING][(t % TPS) * 256 + 64 * s + lane]; };
+    auto mfma = [&](knn_v16f acc, const uint4& f, const knn_v8i& b) {
+        const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    };
+    // maxima of the raw bit patterns (see the fast-path note below): triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
+    auto tree = [&](const knn_v16f& acc, int* tk) -> int {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            tk[k] = max(max(__float_as_int(acc[3 * k]), __float_as_int(acc[3 * k + 1])), __float_as_int(acc[3 * k + 2]));
+        return max(max(max(__float_as_int(acc[15]), tk[0]), tk[1]), max(max(tk[2], tk[3]), tk[4]));
+    };
+    // Fast path test: for thr >= 0 the integer order of the bit patterns decides "v > thr" exactly (a negative v has the
+    // sign bit set and compares below every thr >= 0; non-negative floats order like their bits); a threshold < 0 (list
+    // not full yet, or tiny train sets) is kept as INT_MIN so that everything goes to the exact slow path.
+    // Slow path (about one tile in twenty): usually ONE value of ONE lane qualifies, so each of the candidate tests is
+    // a wave-uniform "nobody" branch that falls through.
+    auto candidates = [&](const knn_v16f& acc, const int* tk, int t, float& thr, int& thri, uint32_t* P, uint32_t& cnt) {
+        KM_T0
+#ifdef KM_TIMING
+        ++n_slow;
+#endif
+        const uint32_t row0 = (uint32_t)((st0 * TPS + t) * 32 + 4 * half);
+        float vbest = -1024.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool gate = k < 5 ? tk[k < 5 ? k : 0] > thri : __float_as_int(acc[15]) > thri;
+            if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
+#pragma unroll
+            for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
+                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
+                const float v = acc[r];
+                const bool h = v > thr && row < (uint32_t)nt;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(h) != 0ull, 0)) {
+                    if (h) {
+                        P[cnt * 64 + lane] = ((uint32_t)(256 - (int)v) << (KNN_KEY_SHIFT - 1)) | row;
+                        ++cnt;
+                        vbest = fmaxf(vbest, v);
+                    }
+                }
+            }
+        }
+        if (prune_tol > 0.f) {
+            // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
+            // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
+            // valid, and so is the one its partner lane (the other 16 rows of the same query) derived.  A looser
+            // threshold is never wrong, so nothing else has to agree.
+            float tn = 255.f - 2.f * (ceilf((256.f - vbest) * 0.5f * prune_tol) - 1.f);
+            tn = fmaxf(tn, __shfl_xor(tn, 32));
+            thr = fmaxf(thr, tn);
+            thri = thr >= 0.f ? __float_as_int(thr) : INT_MIN;
+        }
+        KM_T1(t_slow)
+    };
+    if (T > 0) {
+        knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+        const knn_v16f zero = a0;
+        acquire(0);
+        uint4 x0 = frag(0, 0), x1 = frag(0, 1), x2 = frag(0, 2), x3 = frag(0, 3);          // F(t)
+        uint4 y0, y1, y2, y3;                                                              // F(t + 1)
+        a0 = mfma(zero, x0, bq0[0]); a0 = mfma(a0, x1, bq0[1]); a0 = mfma(a0, x2, bq0[2]); a0 = mfma(a0, x3, bq0[3]);
+        // one tile: (c*) = F(t) are live on entry, (n*) = F(t+1) on exit
+#define KM_TILE(t, c0, c1, c2, c3, n0, n1, n2, n3)                                                                    \
+        {                                                                                                             \
+            const int tn_ = min((t) + 1, T - 1);                 /* the tile after the last: recomputed, never tested */ \
+            if (tn_ % TPS == 0 && (t) + 1 < T) acquire(tn_ / TPS);                                                    \
+            n0 = frag(tn_, 0); n1 = frag(tn_, 1);                                                                     \
+            int tk_[5];                                                                                               \
+            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            a1 = mfma(zero, c0, bq1[0]); a1 = mfma(a1, c1, bq1[1]); a1 = mfma(a1, c2, bq1[2]); a1 = mfma(a1, c3, bq1[3]); \
+            const int m0_ = tree(a0, tk_);                                                                            \
+            KM_INTERLEAVE                                                                                             \
+            asm volatile("" : "+v"(a1));                         /* keeps the MFMAs above the branch below */          \
+            __builtin_amdgcn_s_setprio(0);                                                                            \
+            n2 = frag(tn_, 2); n3 = frag(tn_, 3);                                                                     \
+            if (__builtin_amdgcn_ballot_w64(m0_ > thrAi) != 0ull) candidates(a0, tk_, (t), thrA, thrAi, PA, cntA);    \
+            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            a0 = mfma(zero, n0, bq0[0]); a0 = mfma(a0, n1, bq0[1]); a0 = mfma(a0, n2, bq0[2]); a0 = mfma(a0, n3, bq0[3]); \
+            const int m1_ = tree(a1, tk_);                                                                            \
+            KM_INTERLEAVE                                                                                             \
+            asm volatile("" : "+v"(a0));                                                                              \
+            __builtin_amdgcn_s_setprio(0);                                                                            \
+            if (__builtin_amdgcn_ballot_w64(m1_ > thrBi) != 0ull) candidates(a1, tk_, (t), thrB, thrBi, PB, cntB);    \
+            if (((t) + 1) % TPS == 0) signal(&s_done[((t) / TPS) % KM_RING]);                                         \
+        }
+        // one MFMA, then two of the other accumulator's max3, four times over
+#define KM_INTERLEAVE                                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#pragma unroll 1
+        for (int t = 0; t < T; t += 2) {                         // T is a multiple of TPS = 4
+            KM_TILE(t, x0, x1, x2, x3, y0, y1, y2, y3)
+            KM_TILE(t + 1, y0, y1, y2, y3, x0, x1, x2, x3)
+            if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) {
+                KM_T0
+                flush();
+                KM_T1(t_flush)
+#ifdef KM_TIMING
+                ++n_flush;
+#endif
+                // everything the loop carries is rebuilt after the (rare) flush instead of kept alive across it: the flush
+                // needs 32 registers for the list, and values live across it would be spilled on every path
+                load_queries();
+                const int tr = min(t + 2, T - 1);
+                x0 = frag(tr, 0); x1 = frag(tr, 1); x2 = frag(tr, 2); x3 = frag(tr, 3);
+                a0 = mfma(zero, x0, bq0[0]); a0 = mfma(a0, x1, bq0[1]); a0 = mfma(a0, x2, bq0[2]); a0 = mfma(a0, x3, bq0[3]);
+            }
+        }
+#undef KM_TILE
+#undef KM_INTERLEAVE
+    }
+#else
     const int nst = st1 - st0;
     for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,6 +491,21 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
                         }
                     }
                 }
+                if (prune_tol > 0.f) {
+                    // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
+                    // query's final best from above, so the acceptance bound of this lane's best row of the tile (m0 / m1,
+                    // candidate or not) is already valid, and so is the one its partner lane (the other 16 rows of the
+                    // same query) derived.  A looser threshold is never wrong, so nothing else has to agree.  Without
+                    // this the thresholds stayed as loose as the last flush left them and one tile in five came here.
+                    const float vA = m0 >= 0 ? __int_as_float(m0) : -1024.f, vB = m1 >= 0 ? __int_as_float(m1) : -1024.f;
+                    float tA = 255.f - 2.f * (ceilf((256.f - vA) * 0.5f * prune_tol) - 1.f);
+                    float tB = 255.f - 2.f * (ceilf((256.f - vB) * 0.5f * prune_tol) - 1.f);
+                    tA = fmaxf(tA, __shfl_xor(tA, 32));
+                    tB = fmaxf(tB, __shfl_xor(tB, 32));
+                    thrA = fmaxf(thrA, tA); thrB = fmaxf(thrB, tB);
+                    thrAi = thrA >= 0.f ? __float_as_int(thrA) : INT_MIN;
+                    thrBi = thrB >= 0.f ? __float_as_int(thrB) : INT_MIN;
+                }
                 KM_T1(t_slow)
                 if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) {
                     KM_T0
@@ -352,6 +523,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
             signal(&s_filled[ns]);
         }
     }
+#endif
     flush();
 #ifdef KM_TIMING
     if (lane == 0) {
