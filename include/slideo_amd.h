@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 1
+#define SLIDEO_ABI_VERSION 2
 
 enum {
     SLIDEO_OK = 0,
@@ -78,6 +78,11 @@ typedef struct slideo_config {
     int32_t small_area;           /* 300*400 */
     /* MarkSimilarIter, mo/video_capture.rs:98 */
     float   changed_similarity;   /* 0.98f (changed <=> similarity < this) */
+    /* Extension with no reference counterpart (BASELINE.json north_star / configs[1] wording): 0 = off, the
+     * reference's tolerance vote above.  r > 0 replaces it by the ratio test on the two nearest neighbours:
+     * a query votes for its nearest row iff it has a second neighbour and (float)d1 < r * (float)d2 (f32,
+     * strict); needs knn_k >= 2. */
+    float   ratio_test;           /* 0.0f */
 } slideo_config;
 
 /* cv::KeyPoint as the reference consumes it (pt, size, angle, response,

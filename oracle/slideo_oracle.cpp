@@ -379,7 +379,8 @@ static bool config_supported(const slideo_config& c) {
     return c.nlevels >= 1 && c.nlevels <= 16 && c.nfeatures > 0 && c.patch_size != 31 &&
            c.patch_size >= 2 && c.edge_threshold >= desc_r + 3 && c.edge_threshold >= half &&
            c.edge_threshold >= 4 && c.scale_factor > 1.0f && c.fast_threshold >= 1 &&
-           c.fast_threshold < 255 && c.knn_k >= 1 && c.knn_k <= 64;
+           c.fast_threshold < 255 && c.knn_k >= 1 && c.knn_k <= 64 &&
+           c.ratio_test >= 0.f && !(c.ratio_test > 0.f && c.knn_k < 2);
 }
 
 struct Pyramid {
@@ -927,6 +928,16 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
     for (int q = 0; q < K; ++q) {
         if (idx[(size_t)q * k] < 0) continue;
         float best = (float)dist[(size_t)q * k];
+        if (c.ratio_test > 0.f) {
+            // extension (no reference counterpart; include/slideo_amd.h ratio_test): the ratio test on the two
+            // nearest rows replaces the tolerance vote
+            if (k >= 2 && idx[(size_t)q * k + 1] >= 0 && best < c.ratio_test * (float)dist[(size_t)q * k + 1]) {
+                int ti = idx[(size_t)q * k];
+                int pg = db.train_page[ti];
+                votes[pg].push_back({q, ti - db.page_ofs[pg]});
+            }
+            continue;
+        }
         float lim = best * c.vote_tolerance;
         for (int r = 0; r < k; ++r) {
             int ti = idx[(size_t)q * k + r];
@@ -1022,6 +1033,7 @@ void so_config_default(slideo_config* c) {
     c->min_similarity = 0.5f;                                      // mo/lib.rs:381
     c->small_area = 300 * 400;                                     // mo/image_utils.rs:11
     c->changed_similarity = 0.98f;                                 // mo/video_capture.rs:98
+    c->ratio_test = 0.0f;                                          // extension, off
 }
 
 int so_config_supported(const slideo_config* c) { return config_supported(*c) ? 1 : 0; }

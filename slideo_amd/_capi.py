@@ -24,7 +24,7 @@ class Config(C.Structure):
         ("ransac_threshold", C.c_double), ("ransac_max_iters", C.c_int32),
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
-        ("small_area", C.c_int32), ("changed_similarity", C.c_float),
+        ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
     ]
 
 

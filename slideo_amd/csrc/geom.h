@@ -173,6 +173,7 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (!(c.scale_factor > 1.0f)) { *why = "scale_factor must be > 1"; return false; }
     if (c.fast_threshold < 1 || c.fast_threshold > 254) { *why = "fast_threshold out of range"; return false; }
     if (c.knn_k < 1 || c.knn_k > 32) { *why = "knn_k must be 1..32"; return false; }
+    if (!(c.ratio_test >= 0.f) || (c.ratio_test > 0.f && c.knn_k < 2)) { *why = "ratio_test must be >= 0 and needs knn_k >= 2"; return false; }
     if (c.max_candidate_pages < 1 || c.max_candidate_pages > 64) { *why = "max_candidate_pages must be 1..64"; return false; }
     if (c.max_rated < 1 || c.max_rated > 16) { *why = "max_rated must be 1..16"; return false; }
     if (c.ransac_max_iters < 1 || c.ransac_max_iters > 5000) { *why = "ransac_max_iters must be 1..5000"; return false; }

@@ -47,6 +47,9 @@ constexpr int KM_QPB = KM_WAVES * 64;          // queries per block (two 32-quer
 constexpr int KM_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
 constexpr int KM_RING = 4;                     // LDS ring slots (super-tiles resident per block)
 constexpr int KM_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
+#ifndef KM_SLEEP
+#define KM_SLEEP 1
+#endif
 #ifndef KM_MFMA_PRIO_V
 #define KM_MFMA_PRIO_V 1
 #endif
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     auto wait_ge = [&](uint32_t* f, uint32_t target) {
         KM_T0
         while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(KM_SLEEP);
         asm volatile("" ::: "memory");
         KM_T1(t_bar)
     };

@@ -137,7 +137,7 @@ std::mutex g_err_mutex;
 VerifyParams make_vp(const slideo_config& c) {
     VerifyParams v{};
     v.k = c.knn_k; v.klist = KLIST; v.max_cand = c.max_candidate_pages; v.max_rated = c.max_rated;
-    v.tol = c.vote_tolerance; v.min_similarity = c.min_similarity;
+    v.tol = c.vote_tolerance; v.min_similarity = c.min_similarity; v.ratio = c.ratio_test;
     v.thr = c.ransac_threshold; v.conf = c.ransac_confidence; v.min_rating = c.min_rating;
     v.min_rating_ratio = c.min_rating_ratio; v.max_iters = c.ransac_max_iters; v.refine_iters = c.refine_iters;
     return v;
@@ -455,7 +455,8 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     if (qtot > 0) {
         // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
         // current best must still be kept, hence max(tol, 1)
-        const float prune = m->knn_exact_lists ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
+        // (the ratio test needs the exact two nearest rows: exact lists)
+        const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
         run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, prune);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
@@ -608,6 +609,7 @@ void slideo_config_default(slideo_config* c) {
     c->ransac_threshold = 3.0; c->ransac_max_iters = 2000; c->ransac_confidence = 0.99; c->refine_iters = 10;
     c->max_rated = 10; c->min_rating = 50.0; c->min_rating_ratio = 0.2;
     c->min_similarity = 0.5f; c->small_area = 300 * 400; c->changed_similarity = 0.98f;
+    c->ratio_test = 0.0f;
 }
 
 const char* slideo_last_error(const slideo_matcher* m) {

@@ -60,7 +60,7 @@ struct PairDesc {              // one (frame, survivor) unit of re-projection wo
 
 struct VerifyParams {
     int32_t k, klist, max_cand, max_rated;
-    float tol, min_similarity;
+    float tol, min_similarity, ratio;       // ratio > 0: ratio test instead of the tolerance vote
     double thr, conf, min_rating, min_rating_ratio;
     int32_t max_iters, refine_iters;
 };
@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
             uint32_t key[VOTE_KLIST];
 #pragma unroll
             for (int i = 0; i < VOTE_KLIST / 4; ++i) { const uint4 v = kq4[i]; key[4 * i] = v.x; key[4 * i + 1] = v.y; key[4 * i + 2] = v.z; key[4 * i + 3] = v.w; }
+            if (vp.ratio > 0.f) {                                            // ratio test on the two nearest rows
+                if (k >= 2 && key[0] != KNN_EMPTY && key[1] != KNN_EMPTY &&
+                    (float)(key[0] >> KNN_KEY_SHIFT) < vp.ratio * (float)(key[1] >> KNN_KEY_SHIFT))
+                    fn(q, key[0] & KNN_IDX_MASK);
+                continue;
+            }
             const float lim = (float)(key[0] >> KNN_KEY_SHIFT) * vp.tol;
 #pragma unroll
             for (int r = 0; r < VOTE_KLIST; ++r) {

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.EXPORTS) == names
-    assert L.slideo_abi_version() == 1
+    assert L.slideo_abi_version() == 2
 
 
 def test_config_struct_matches_oracle_layout(capi, oracle):

@@ -4,6 +4,8 @@ import hashlib
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 from PIL import Image
@@ -60,6 +62,24 @@ def test_synthetic_cfg0_pin(oracle, cfg0_data):
     v = db.match_frames(frames, threads=4)
     assert v["page_idx"].tolist() == e["page_idx"] == e["truth"]
     assert v["inliers"].tolist() == e["inliers"] and v["n_keypoints"].tolist() == e["n_keypoints"]
+
+
+def test_ratio_test_option_on_cfg0(oracle, cfg0_data):
+    """Extension (include/slideo_amd.h `ratio_test`): the ratio rule gives at most one vote per query, never more
+    votes than the reference's tolerance rule, and still finds the right pages on the synthetic set."""
+    pages, frames, truth, _ = cfg0_data
+    res = {}
+    for r in (0.0, 0.8):
+        db = oracle.PageDB(oracle.default_config(nfeatures=500, min_rating=12.0, ratio_test=r))
+        db.add_pages(pages, threads=4)
+        assert db.finalize() == 0
+        res[r] = [db.match_frame_trace(f) for f in frames]
+    for (v0, c0), (v1, c1) in zip(res[0.0], res[0.8]):
+        assert int(c1["n_votes"].sum()) <= int(c0["n_votes"].sum())
+        assert int(c1["n_votes"].sum()) <= int(v1["n_keypoints"])
+    got = np.array([int(v["page_idx"]) for v, _ in res[0.8]])
+    assert ((got == truth) | (got == -1)).all() and (got == truth).mean() >= 0.75     # fewer votes: a miss is "none"
+    assert oracle.lib().so_config_supported(C.byref(oracle.default_config(ratio_test=0.8, knn_k=1))) == 0
 
 
 @pytest.mark.gpu

@@ -595,3 +595,22 @@ def test_headline_shape_properties(capi, synth):
     assert (got == truth).mean() >= 0.97
     assert ((got >= 0) & (got != truth)).sum() <= 2                            # misses are "none", hardly ever another page
     m.close()
+
+
+@pytest.mark.parametrize("ratio", [0.7, 0.9])
+def test_ratio_test_mode_matches_oracle(capi, oracle, cfg0_data, ratio):
+    """The north-star's "ratio test" as an option (no reference counterpart): a query votes for its nearest row iff
+    d1 < ratio * d2.  Votes, inliers, transforms and verdicts against the CPU restatement of the same rule."""
+    pages, frames, truth, _ = cfg0_data
+    m, db = _build_both(capi, oracle, small_cfg(capi, ratio_test=ratio), small_cfg(oracle, ratio_test=ratio), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    # a vote per query at most, so fewer than under the tolerance rule
+    m2 = capi.Matcher(small_cfg(capi))
+    m2.add_pages(list(pages)); m2.finalize()
+    m2.match_frames(frames); m.match_frames(frames)
+    for i in range(len(frames)):
+        a, b = m.last_candidates(i), m2.last_candidates(i)
+        assert a["n_votes"].sum() <= b["n_votes"].sum()
+        assert a["n_votes"].sum() <= v["n_keypoints"][i]
+    m.close(); m2.close()
