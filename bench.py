@@ -53,8 +53,8 @@ LANEOPS_PER_PAIR = 16          # 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 per 256-bit 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
