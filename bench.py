@@ -268,9 +268,13 @@ def main():
         cv = db.match_frames(frames[:ns], threads=min(cores, ns))
         t_cpu = time.time() - t0
         agree = float((cv["page_idx"] == v["page_idx"][:ns]).mean())
+        t0 = time.time()
+        db.match_frames(frames[:2], threads=1)                      # also on one core
+        t_cpu1 = time.time() - t0
         out["cpu_baseline"] = {"value": round(ns / t_cpu, 3), "unit": "frames/s", "cores": int(min(cores, ns)),
                                "kind": "port", "sample": "%d of the %d benchmark frames, one frame per thread, page DB prebuilt (%.1f s on %d threads)" % (ns, B, t_cpu_db, cores),
-                               "seconds": round(t_cpu, 2), "verdict_agreement_with_gpu": agree}
+                               "seconds": round(t_cpu, 2), "verdict_agreement_with_gpu": agree,
+                               "single_thread": {"value": round(2 / t_cpu1, 4), "unit": "frames/s", "cores": 1, "sample": "2 frames"}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     m.close()
