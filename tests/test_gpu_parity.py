@@ -96,6 +96,23 @@ def test_knn_unaligned_sizes_and_complement(capi, oracle, mdef, knn_engine):
     assert gd.max() <= 256 or (gd == 65535).any()
 
 
+def test_knn_random_shapes(capi, oracle, mdef, knn_engine):
+    """Seeded sweep over (queries, train rows, k): ring lengths of 1, 2, 3, ... super-tiles, odd tile counts, partial last
+    tiles, several query blocks, duplicated rows (ties) and near-duplicates of queries (tight thresholds early)."""
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        nq = int(rng.integers(1, 1400)); nt = int(rng.integers(1, 2600)); k = int(rng.choice([1, 2, 7, 30, 32]))
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        for _ in range(min(nt, 40)):                       # ties and close rows
+            i, j = int(rng.integers(0, nt)), int(rng.integers(0, nq))
+            t[i] = q[j]
+            if rng.random() < 0.5: t[i, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        gi, gd = mdef.knn(q, t, k)
+        oi, od = oracle.knn_hamming(q, t, k)
+        assert np.array_equal(gd, od) and np.array_equal(gi, oi), (case, nq, nt, k)
+
+
 def test_knn_other_k(capi, oracle, mdef, knn_engine):
     rng = np.random.default_rng(5)
     q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
