@@ -18,6 +18,26 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def halo_range(n_frames, rank, world):
+    """Frames a rank must READ for the changed-frame test of its block: the block plus the one frame before it.
+
+    MarkSimilarIter (crates/matching-opencv/src/video_capture.rs:86-98) compares every sampled frame with the previous
+    sampled frame (the reference updates `last` on every sample, :97) and always keeps the first of the video (:92), so
+    a contiguous shard needs exactly a 1-frame halo at its start; rank 0 has none.  Returns (lo_read, lo, hi)."""
+    lo, hi = shard_range(n_frames, rank, world)
+    return (lo - 1 if lo > 0 and hi > lo else lo), lo, hi
+
+
+def changed_mask_of_shard(changed_mask_fn, frames_read, has_halo):
+    """`changed` flags of a shard given the frames of halo_range() and the single-process mask function
+    (`Matcher.changed_mask` on the GPU, the CPU restatement in the tests): the halo frame only provides the small image
+    the first real frame is compared with; its own flag (always "changed", it is first in the call) is dropped."""
+    if len(frames_read) == 0:
+        return np.zeros(0, bool)
+    changed = np.asarray(changed_mask_fn(frames_read)[0], bool)
+    return changed[1:] if has_halo else changed
+
+
 def all_gather_verdicts(verdicts, n_total, rank, world, device=None):
     """verdicts: structured array (_capi.VERDICT_DTYPE) of this rank's block.
     Returns the concatenation over ranks in frame order (length n_total) on every rank."""

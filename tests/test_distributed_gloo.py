@@ -30,6 +30,62 @@ def _worker(rank, world, port, n_frames, q):
     dist.destroy_process_group()
 
 
+def _mask_worker(rank, world, port, n_frames, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from slideo_amd import distributed as D, synth
+    import pyoracle as o
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _lecture_frames(synth, n_frames)
+    cfg = o.default_config()
+    rd, lo, hi = D.halo_range(n_frames, rank, world)
+    mine = D.changed_mask_of_shard(lambda f: o.changed_mask(f, cfg), frames[rd:hi], rd < lo)
+    cap = -(-n_frames // world)
+    buf = torch.zeros(cap, dtype=torch.uint8); buf[: hi - lo] = torch.from_numpy(mine.astype(np.uint8))
+    out = torch.empty(world * cap, dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, buf)
+    if rank == 0:
+        parts = [out[r * cap: r * cap + (D.shard_range(n_frames, r, world)[1] - D.shard_range(n_frames, r, world)[0])] for r in range(world)]
+        q.put(torch.cat(parts).numpy().astype(bool).tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _lecture_frames(synth, n):
+    """A sampled lecture: runs of the same page (later samples of a run differ by a little noise) — so that most frames
+    are unchanged and the flags at the shard seam depend on the halo."""
+    pages = synth.pages(3, 800, 450, threads=1)
+    base, _, _ = synth.frames(pages, 3, 640, 360, threads=1)
+    rng = np.random.default_rng(3)
+    out = []
+    for i in range(n):
+        f = base[(i // 3) % 3].astype(np.int16) + rng.integers(-1, 2, base[0].shape, dtype=np.int16)
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return np.stack(out)
+
+
+def test_world2_changed_mask_with_halo_equals_single_process(oracle, synth):
+    """video_capture.rs:86-98 over a sharded frame list: the 1-frame halo makes the seam flags equal the unsharded ones."""
+    import torch.multiprocessing as mp
+    from slideo_amd import distributed as D
+    n = 9
+    assert D.halo_range(n, 0, 2) == (0, 0, 5) and D.halo_range(n, 1, 2) == (4, 5, 9) and D.halo_range(1, 1, 2) == (1, 1, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_mask_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    single = oracle.changed_mask(_lecture_frames(synth, n), oracle.default_config())[0].astype(bool).tolist()
+    assert got == single
+    assert single[0] and not all(single) and single[5] is False          # the seam frame is unchanged: without the halo it would read "changed"
+
+
 def test_shard_range_partitions():
     from slideo_amd import distributed as D
     for n in (0, 1, 7, 8, 9, 216000):
