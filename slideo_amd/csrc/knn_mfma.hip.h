@@ -28,7 +28,7 @@
 // Block = 8 waves = 512 queries sharing the A tiles through LDS: super-tiles of 128 rows = 16 KB go through a
 // 4-slot ring filled by LDS-DMA and guarded by per-slot counters — no block barrier in the main loop.  Fast path
 // per tile and wave: 4 ds_read_b128 + 8 MFMA + 2 x 8 v_max3_i32 + 2 compares; the two accumulators of a wave run half
-// a tile apart so that each one's max tree is issued between the other's MFMAs (KM_SKEW).
+// a tile apart so that each one's max tree is issued between the other's MFMAs.
 #pragma once
 #include <limits.h>
 #include <hip/hip_runtime.h>
@@ -102,14 +102,7 @@ __global__ __launch_bounds__(256) void knn_expand_train_kernel(const uint32_t* _
 // prune_tol > 0 the threshold is additionally capped by the vote's acceptance bound (see the flush).
 constexpr int KM_FLUSH_AT = 16;
 constexpr int KM_FLUSH_BATCH = 4;
-#ifndef KM_SKEW
-#define KM_SKEW 1                                    // 1 = skewed main loop (see the kernel), 0 = the tile-synchronous loop before it
-#endif
-#if KM_SKEW
 constexpr int KM_PEND_CAP = 64;                      // >= KM_FLUSH_AT - 1 + 2 * 16 (flush test every second tile; a lane pushes <= 16 keys per tile and query)
-#else
-constexpr int KM_PEND_CAP = 32;                      // >= KM_FLUSH_AT - 1 + 16 (a lane pushes <= 16 keys per tile and query)
-#endif
 constexpr size_t KM_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64;
 
 // Pending buffers: every lane has a PRIVATE buffer per query tile in a global workspace (L2 resident; the
@@ -249,7 +242,6 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
     };
     if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
-#if KM_SKEW
     const int nst = st1 - st0;
     for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,142 +383,6 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
 #undef KM_TILE
 #undef KM_INTERLEAVE
     }
-#else
-    const int nst = st1 - st0;
-    for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int j = 0; j < KM_AHEAD && j < nst; ++j) signal(&s_filled[j]);
-    for (int j = 0; j < nst; ++j) {
-        const int st = st0 + j, slot = j % KM_RING;
-        const int jn = j + KM_AHEAD, ns = jn % KM_RING;
-        const bool more = jn < nst;
-        if (more) {                               // slot ns was last read for super-tile jn - KM_RING
-            wait_ge(&s_done[ns], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
-            stage(jn, ns);
-        }
-        wait_ge(&s_filled[slot], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
-        const uint4* L = lds[slot] + lane;
-        const int first_pad_tile = (nt - st * KM_ST_ROWS) >> 5;          // tiles from here on hold rows >= nt
-        // A fragments: the first two of a tile are fetched one tile ahead (right after the previous tile's MFMAs are
-        // issued, so their LDS latency hides under the epilogue), the other two behind the tile's first four MFMAs
-        uint4 f0 = L[0], f1 = L[64];
-#pragma unroll 1
-        for (int tile = 0; tile < KM_ST_ROWS / 32; ++tile) {
-            knn_v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
-            // the matrix pipe needs one issue slot in eight; at equal priority the SIMD's arbiter serves the oldest
-            // wave's VALU epilogue first and the pipe idles, so MFMAs are issued at raised priority
-            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
-            {
-                const uint4 f2 = L[tile * 256 + 128], f3 = L[tile * 256 + 192];
-                const knn_v8i v0 = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, 0, 0, 0, 0}, v1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w, 0, 0, 0, 0};
-                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, bq0[0], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, bq1[0], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, bq0[1], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, bq1[1], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                const knn_v8i v2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w, 0, 0, 0, 0}, v3 = {(int)f3.x, (int)f3.y, (int)f3.z, (int)f3.w, 0, 0, 0, 0};
-                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, bq0[2], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, bq1[2], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, bq0[3], a0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, bq1[3], a1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                const uint4* Ln = L + min(tile + 1, KM_ST_ROWS / 32 - 1) * 256;
-                f0 = Ln[0]; f1 = Ln[64];
-            }
-            __builtin_amdgcn_s_setprio(0);
-            // rows past the end of the train set (only in its last tile) can never be candidates
-            const int tile_row0 = st * KM_ST_ROWS + tile * 32;
-            if (tile >= first_pad_tile) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool pad = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nt;
-                    a0[r] = pad ? -1024.f : a0[r];
-                    a1[r] = pad ? -1024.f : a1[r];
-                }
-            }
-            // Fast path: does any of this lane's 2 x 16 dot products beat its query's threshold?  The maxima are taken
-            // on the raw bits with v_max3_i32 (f32 max would first canonicalise all 32 MFMA outputs): for thr >= 0 the
-            // integer order of the bit patterns decides "v > thr" exactly (a negative v has the sign bit set and
-            // compares below every thr >= 0; non-negative floats order like their bits), and a threshold < 0 (list not
-            // full yet, or tiny train sets) is kept as INT_MIN so that everything goes to the exact slow path.
-            int ia[16], ib[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float fa = a0[r], fb = a1[r];
-                ia[r] = __float_as_int(fa); ib[r] = __float_as_int(fb);
-            }
-            // maxima of register triples {3k, 3k+1, 3k+2} (v_max3_i32), k = 0..4, + register 15: 8 instructions per tile
-            int ta[5], tb[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                ta[k] = max(max(ia[3 * k], ia[3 * k + 1]), ia[3 * k + 2]);
-                tb[k] = max(max(ib[3 * k], ib[3 * k + 1]), ib[3 * k + 2]);
-            }
-            const int m0 = max(max(max(ia[15], ta[0]), ta[1]), max(max(ta[2], ta[3]), ta[4]));
-            const int m1 = max(max(max(ib[15], tb[0]), tb[1]), max(max(tb[2], tb[3]), tb[4]));
-            if (__builtin_amdgcn_ballot_w64(m0 > thrAi || m1 > thrBi) != 0ull) {
-                KM_T0
-#ifdef KM_TIMING
-                ++n_slow;
-#endif
-                // Slow path (about one iteration in five): usually ONE value of ONE lane qualifies, so each of the
-                // candidate tests below is a wave-uniform "nobody" branch that falls through.  (Rows of one tile may
-                // be offered in any order: the lists only change in a flush, which runs between tiles.)
-                const uint32_t row0 = (uint32_t)(tile_row0 + 4 * half);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const bool gate = k < 5 ? (ta[k < 5 ? k : 0] > thrAi || tb[k < 5 ? k : 0] > thrBi) : (ia[15] > thrAi || ib[15] > thrBi);
-                    if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
-#pragma unroll
-                    for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
-                        const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
-                        const float v0 = a0[r], v1 = a1[r];
-                        const bool h0 = v0 > thrA, h1 = v1 > thrB;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h0) != 0ull, 0)) {
-                            if (h0) {                                   // candidate for tile-0 query ql
-                                PA[cntA * 64 + lane] = ((uint32_t)(256 - (int)v0) << (KNN_KEY_SHIFT - 1)) | row;
-                                ++cntA;
-                            }
-                        }
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(h1) != 0ull, 0)) {
-                            if (h1) {                                   // candidate for tile-1 query ql
-                                PB[cntB * 64 + lane] = ((uint32_t)(256 - (int)v1) << (KNN_KEY_SHIFT - 1)) | row;
-                                ++cntB;
-                            }
-                        }
-                    }
-                }
-                if (prune_tol > 0.f) {
-                    // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
-                    // query's final best from above, so the acceptance bound of this lane's best row of the tile (m0 / m1,
-                    // candidate or not) is already valid, and so is the one its partner lane (the other 16 rows of the
-                    // same query) derived.  A looser threshold is never wrong, so nothing else has to agree.  Without
-                    // this the thresholds stayed as loose as the last flush left them and one tile in five came here.
-                    const float vA = m0 >= 0 ? __int_as_float(m0) : -1024.f, vB = m1 >= 0 ? __int_as_float(m1) : -1024.f;
-                    float tA = 255.f - 2.f * (ceilf((256.f - vA) * 0.5f * prune_tol) - 1.f);
-                    float tB = 255.f - 2.f * (ceilf((256.f - vB) * 0.5f * prune_tol) - 1.f);
-                    tA = fmaxf(tA, __shfl_xor(tA, 32));
-                    tB = fmaxf(tB, __shfl_xor(tB, 32));
-                    thrA = fmaxf(thrA, tA); thrB = fmaxf(thrB, tB);
-                    thrAi = thrA >= 0.f ? __float_as_int(thrA) : INT_MIN;
-                    thrBi = thrB >= 0.f ? __float_as_int(thrB) : INT_MIN;
-                }
-                KM_T1(t_slow)
-                if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) {
-                    KM_T0
-                    flush();
-                    KM_T1(t_flush)
-#ifdef KM_TIMING
-                    ++n_flush;
-#endif
-                }
-            }
-        }
-        signal(&s_done[slot]);
-        if (more) {                               // the DMA issued a whole iteration ago has landed long since
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            signal(&s_filled[ns]);
-        }
-    }
-#endif
     flush();
 #ifdef KM_TIMING
     if (lane == 0) {

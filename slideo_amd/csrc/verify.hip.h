@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
     uint32_t* runcnt = reinterpret_cast<uint32_t*>(smem + (size_t)npages * 4 + (((size_t)npages + 15) & ~(size_t)15));
     __shared__ unsigned long long red[4];
     __shared__ int32_t s_page[MAXC], s_count[MAXC], s_ofs[MAXC];
-    __shared__ int32_t s_ncand;
 
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q0 = qofs[f], n = qofs[f + 1] - q0;
@@ -145,7 +144,6 @@ __global__ __launch_bounds__(256) void vote_kernel(VerifyParams vp, const uint32
     if (tid == 0) {
         int o = 0;
         for (int i = 0; i < nc; ++i) { s_ofs[i] = o; o += s_count[i]; }
-        s_ncand = nc;
         fc.ncand = nc; fc.nsurv = 0;
         for (int i = 0; i < nc; ++i) { fc.page[i] = s_page[i]; fc.count[i] = s_count[i]; fc.ofs[i] = s_ofs[i]; }
     }
