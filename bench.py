@@ -211,7 +211,8 @@ def main():
                                "source": tj["source"], "note": tj["note"]}
                 except (OSError, KeyError, ValueError):
                     traffic = None
-            common = {"traffic": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
+            # `traffic` = HBM bytes per launch (a number, or null where it was not measured); the passes behind it in traffic_detail
+            common = {"traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
                       "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
                       "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream", "hbm_view": hbm_view}
             if args.knn == "mfma":

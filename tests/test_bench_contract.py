@@ -32,6 +32,7 @@ def test_single_gpu_line():
     for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or isinstance(rf["traffic"], (int, float))      # HBM bytes per launch; measured for the headline only
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["verdict_agreement_with_gpu"] == 1.0
 
