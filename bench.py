@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
-    ap.add_argument("--knn", default="mfma", choices=["mfma", "valu"], help="kNN engine (identical results)")
+    ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu"], help="kNN engine (identical results)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (<= the library's slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,11 +215,11 @@ def main():
             common = {"traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
                       "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
                       "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream", "hbm_view": hbm_view}
-            if args.knn == "mfma":
+            if args.knn != "valu":
                 # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
                 flops = 2.0 * 256 * pairs_per_launch
                 achieved = flops / avg_s / 1e12
-                out["roofline"] = dict({"kernel": "knn_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4)", "bound": "mfma",
+                out["roofline"] = dict({"kernel": "knn_mfma4_kernel / knn_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4; wave shape per launch)", "bound": "mfma",
                                         "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512}, **common)
             else:
@@ -230,7 +230,7 @@ def main():
                                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR}, **common)
             if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
                 a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
-                unit_work = (2.0 * 256 if args.knn == "mfma" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
+                unit_work = (2.0 * 256 if args.knn != "valu" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
                 out["roofline"]["one_batch_in_flight"] = {
                     "avg_launch_ms": round(a_s * 1e3, 4), "achieved": round(unit_work / a_s, 2),
                     "frac": round(unit_work / a_s / out["roofline"]["peak"], 4),

@@ -195,8 +195,11 @@ int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn
  *   (vote, ransac, rate, reproject, verdict)  3 whole sub-batch incl. copies.
  * launches_out[i] = number of timed intervals of stage i; for stage 1 each
  * interval is exactly one knn_hamming_kernel launch (+ its merge when split). */
-/* kNN engine: 0 = FP4 matrix-core kernel (default), 1 = integer-VALU popcount kernel.
- * Both are exact and return identical results; the switch exists for A/B measurement. */
+/* kNN engine: 0 = FP4 matrix cores, wave shape chosen per launch (default), 1 = integer-VALU popcount kernel,
+ * 2 = FP4 matrix cores forced to 2 waves per SIMD x 4 query tiles per wave (leaves half of every SIMD's registers
+ * and 96 KB of LDS per CU to the kernels of the other unit in flight; what 0 picks when the queries fill the chip),
+ * 3 = forced to 4 waves per SIMD x 2 query tiles per wave (what 0 picks for smaller query sets).
+ * All are exact and return identical results; the switch exists for A/B measurement. */
 int32_t     slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine);
 
 /* The matcher's kNN stage is fused with the acceptance rule of its only consumer, the tolerance vote

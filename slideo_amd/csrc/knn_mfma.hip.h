@@ -393,4 +393,264 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// knn_mfma4_kernel — the same algorithm with FOUR query tiles per wave and two waves per SIMD.
+//
+// A resident knn_mfma_kernel holds 4 waves x 115 VGPRs of every SIMD lane and 131 KB of the CU's LDS, so the kernels of
+// the other batch in flight (ORB, verify) mostly run in its tail.  Here a wave owns 128 queries (4 B tiles, 4
+// accumulators), a block of 8 waves 1024 queries, one block per CU: per SIMD two waves x ~190 VGPRs, per CU 64 KB of
+// LDS — room for two to three foreign waves per SIMD and 96 KB of LDS throughout the launch — and every A fragment read
+// from LDS feeds four MFMAs instead of two.  With only two waves per SIMD nobody else hides a wave's epilogue, so the
+// accumulators run skewed in two groups: while the 8 MFMAs of {a2, a3} are in the pipe the wave's VALU slots take the
+// max trees and threshold tests of {a0, a1}, and vice versa (see knn_mfma_kernel for the skew, the ring, the slow path
+// and the flush, which are the same).  Lane L owns the lists of wave-local queries L (tile L/32) and L + 64 (tile 2 + L/32).
+// Grid (ceil(nq / 1024), nseg), block 512.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int K4_NT = 4;
+constexpr int K4_QPW = 32 * K4_NT;                       // queries per wave
+constexpr int K4_QPB = KM_WAVES * K4_QPW;                // queries per block
+constexpr size_t K4_PEND_WORDS_PER_WAVE = (size_t)K4_NT * KM_PEND_CAP * 64;
+
+__global__ __launch_bounds__(KM_THREADS, 2) void knn_mfma4_kernel(const uint32_t* __restrict__ q, int nq,
+                                                                  const uint4* __restrict__ tx, int nt, int nt_pad,
+                                                                  int st_per_seg, uint32_t* __restrict__ out,
+                                                                  uint32_t* __restrict__ pend_ws, float prune_tol) {
+    __shared__ uint4 lds[KM_RING][KM_ST_U4];
+    __shared__ uint32_t s_filled[KM_RING], s_done[KM_RING];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, ql = lane & 31;
+    const int qbase = blockIdx.x * K4_QPB + wave * K4_QPW;
+    const int seg = blockIdx.y;
+    const int n_st = nt_pad / KM_ST_ROWS;
+    const int st0 = seg * st_per_seg, st1 = min(n_st, st0 + st_per_seg);
+    uint32_t* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KM_WAVES + wave) * K4_PEND_WORDS_PER_WAVE;
+    auto pend = [&](int i) -> uint32_t* { return P0 + (size_t)i * KM_PEND_CAP * 64; };
+
+    knn_v8i bq[K4_NT][4];
+    auto load_queries = [&]() {
+#pragma unroll
+        for (int i = 0; i < K4_NT; ++i) {
+            const uint32_t* qp = q + (size_t)min(qbase + 32 * i + ql, nq - 1) * 8;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t w = qp[2 * s + half];
+                bq[i][s] = knn_v8i{(int)fp4_expand8(w), (int)fp4_expand8(w >> 8), (int)fp4_expand8(w >> 16), (int)fp4_expand8(w >> 24), 0, 0, 0, 0};
+            }
+        }
+    };
+    load_queries();
+    // list p of this lane: wave-local query 64 p + lane, i.e. tile 2 p + half, column ql
+    auto list_of = [&](int p) -> uint4* { return reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qbase + 64 * p + lane, nq - 1)) * 32); };
+#pragma unroll
+    for (int p = 0; p < K4_NT / 2; ++p)
+        if (qbase + 64 * p + lane < nq) {
+            uint4* l = list_of(p);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
+        }
+    float thr[K4_NT]; int thri[K4_NT]; uint32_t cnt[K4_NT];
+#pragma unroll
+    for (int i = 0; i < K4_NT; ++i) { thr[i] = -1024.f; thri[i] = INT_MIN; cnt[i] = 0; }
+
+    auto flush = [&]() {
+#pragma unroll
+        for (int p = 0; p < K4_NT / 2; ++p) {
+            const int A = 2 * p, B = 2 * p + 1;
+            const uint32_t cA_lo = __shfl(cnt[A], ql), cA_hi = __shfl(cnt[A], ql + 32);
+            const uint32_t cB_lo = __shfl(cnt[B], ql), cB_hi = __shfl(cnt[B], ql + 32);
+            const uint32_t c_lo = half ? cB_lo : cA_lo, c_hi = half ? cB_hi : cA_hi;
+            const uint32_t* PP = (half ? pend(B) : pend(A)) + ql;
+            uint4* my_list = list_of(p);
+            const bool owner_valid = qbase + 64 * p + lane < nq;
+            uint32_t lst[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = my_list[i];
+                lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w;
+            }
+            for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KM_FLUSH_BATCH) {
+                uint32_t e[KM_FLUSH_BATCH];
+#pragma unroll
+                for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNN_EMPTY;
+#pragma unroll
+                for (int i = 0; i < KM_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+            }
+            for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KM_FLUSH_BATCH) {
+                uint32_t e[KM_FLUSH_BATCH];
+#pragma unroll
+                for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNN_EMPTY;
+#pragma unroll
+                for (int i = 0; i < KM_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+            }
+            if (owner_valid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
+            }
+            float t = 256.f - 2.f * (float)(lst[31] >> KNN_KEY_SHIFT);
+            if (prune_tol > 0.f) {
+                const float lim = (float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol;
+                t = fmaxf(t, 255.f - 2.f * (ceilf(lim) - 1.f));
+            }
+            cnt[A] = 0; cnt[B] = 0;
+            thr[A] = __shfl(t, ql);
+            thr[B] = __shfl(t, 32 + ql);
+            thri[A] = thr[A] >= 0.f ? __float_as_int(thr[A]) : INT_MIN;
+            thri[B] = thr[B] >= 0.f ? __float_as_int(thr[B]) : INT_MIN;
+        }
+    };
+    auto stage = [&](int jj, int sl) {
+        constexpr int PER_WAVE = KM_ST_U4 / KM_WAVES;
+        const uint4* src = tx + (size_t)(st0 + jj) * KM_ST_U4 + wave * PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE / 64; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
+                                             (__attribute__((address_space(3))) void*)&lds[sl][wave * PER_WAVE + 64 * i], 16, 0, 0);
+    };
+    auto signal = [&](uint32_t* f) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_ge = [&](uint32_t* f, uint32_t target) {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(KM_SLEEP);
+        asm volatile("" ::: "memory");
+    };
+    if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
+    __syncthreads();
+    const int nst = st1 - st0;
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) stage(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < KM_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    constexpr int TPS = KM_ST_ROWS / 32;
+    const int T = nst * TPS;
+    auto acquire = [&](int j) {
+        const int jp = j - 1 + KM_AHEAD, jn = j + KM_AHEAD;
+        if (j > 0 && jp < nst) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            signal(&s_filled[jp % KM_RING]);
+        }
+        if (jn < nst) {
+            wait_ge(&s_done[jn % KM_RING], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
+            stage(jn, jn % KM_RING);
+        }
+        wait_ge(&s_filled[j % KM_RING], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
+    };
+    auto frag = [&](int t, int s) -> uint4 { return lds[(t / TPS) % KM_RING][(t % TPS) * 256 + 64 * s + lane]; };
+    auto mfma = [&](knn_v16f acc, const uint4& f, const knn_v8i& b) {
+        const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    };
+    auto tree = [&](const knn_v16f& acc, int* tk) -> int {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            tk[k] = max(max(__float_as_int(acc[3 * k]), __float_as_int(acc[3 * k + 1])), __float_as_int(acc[3 * k + 2]));
+        return max(max(max(__float_as_int(acc[15]), tk[0]), tk[1]), max(max(tk[2], tk[3]), tk[4]));
+    };
+    auto candidates = [&](const knn_v16f& acc, const int* tk, int t, float& th, int& thi, uint32_t* P, uint32_t& c) {
+        const uint32_t row0 = (uint32_t)((st0 * TPS + t) * 32 + 4 * half);
+        float vbest = -1024.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool gate = k < 5 ? tk[k < 5 ? k : 0] > thi : __float_as_int(acc[15]) > thi;
+            if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
+#pragma unroll
+            for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
+                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2);
+                const float v = acc[r];
+                const bool h = v > th && row < (uint32_t)nt;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(h) != 0ull, 0)) {
+                    if (h) {
+                        P[c * 64 + lane] = ((uint32_t)(256 - (int)v) << (KNN_KEY_SHIFT - 1)) | row;
+                        ++c;
+                        vbest = fmaxf(vbest, v);
+                    }
+                }
+            }
+        }
+        if (prune_tol > 0.f) {
+            float tn = 255.f - 2.f * (ceilf((256.f - vbest) * 0.5f * prune_tol) - 1.f);
+            tn = fmaxf(tn, __shfl_xor(tn, 32));
+            th = fmaxf(th, tn);
+            thi = th >= 0.f ? __float_as_int(th) : INT_MIN;
+        }
+    };
+    if (T > 0) {
+        const knn_v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        knn_v16f a[K4_NT];
+#pragma unroll
+        for (int i = 0; i < K4_NT; ++i) a[i] = zero;
+        acquire(0);
+        uint4 x0 = frag(0, 0), x1 = frag(0, 1), x2 = frag(0, 2), x3 = frag(0, 3);
+        uint4 y0, y1, y2, y3;
+        // two accumulator chains through the four k-steps of one A tile: 8 MFMAs
+#define K4_MFMA8(G, f0, f1, f2, f3)                                                                                     \
+        a[G] = mfma(zero, f0, bq[G][0]); a[G + 1] = mfma(zero, f0, bq[G + 1][0]);                                      \
+        a[G] = mfma(a[G], f1, bq[G][1]); a[G + 1] = mfma(a[G + 1], f1, bq[G + 1][1]);                                  \
+        a[G] = mfma(a[G], f2, bq[G][2]); a[G + 1] = mfma(a[G + 1], f2, bq[G + 1][2]);                                  \
+        a[G] = mfma(a[G], f3, bq[G][3]); a[G + 1] = mfma(a[G + 1], f3, bq[G + 1][3]);
+        // one MFMA, then two instructions of the other group's max trees, eight times over
+#define K4_INTERLEAVE                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        // tests of group G (accumulators G, G+1) for tile t
+#define K4_TEST(G, t)                                                                                                   \
+        if (__builtin_amdgcn_ballot_w64(mA_ > thri[G] || mB_ > thri[G + 1]) != 0ull) {                                  \
+            if (__builtin_amdgcn_ballot_w64(mA_ > thri[G]) != 0ull) candidates(a[G], tkA_, (t), thr[G], thri[G], pend(G), cnt[G]); \
+            if (__builtin_amdgcn_ballot_w64(mB_ > thri[G + 1]) != 0ull) candidates(a[G + 1], tkB_, (t), thr[G + 1], thri[G + 1], pend(G + 1), cnt[G + 1]); \
+        }
+        // one tile: (c*) = F(t) live on entry, (n*) = F(t+1) on exit; group {0,1} already holds tile t
+#define K4_TILE(t, c0, c1, c2, c3, n0, n1, n2, n3)                                                                      \
+        {                                                                                                             \
+            const int tn_ = min((t) + 1, T - 1);                                                                      \
+            if (tn_ % TPS == 0 && (t) + 1 < T) acquire(tn_ / TPS);                                                    \
+            n0 = frag(tn_, 0); n1 = frag(tn_, 1);                                                                     \
+            int tkA_[5], tkB_[5];                                                                                     \
+            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            K4_MFMA8(2, c0, c1, c2, c3)                                                                               \
+            int mA_ = tree(a[0], tkA_), mB_ = tree(a[1], tkB_);                                                       \
+            K4_INTERLEAVE                                                                                             \
+            asm volatile("" : "+v"(a[2]), "+v"(a[3]));                                                                \
+            __builtin_amdgcn_s_setprio(0);                                                                            \
+            n2 = frag(tn_, 2); n3 = frag(tn_, 3);                                                                     \
+            K4_TEST(0, t)                                                                                             \
+            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            K4_MFMA8(0, n0, n1, n2, n3)                                                                               \
+            mA_ = tree(a[2], tkA_); mB_ = tree(a[3], tkB_);                                                           \
+            K4_INTERLEAVE                                                                                             \
+            asm volatile("" : "+v"(a[0]), "+v"(a[1]));                                                                \
+            __builtin_amdgcn_s_setprio(0);                                                                            \
+            K4_TEST(2, t)                                                                                             \
+            if (((t) + 1) % TPS == 0) signal(&s_done[((t) / TPS) % KM_RING]);                                         \
+        }
+        K4_MFMA8(0, x0, x1, x2, x3)
+#pragma unroll 1
+        for (int t = 0; t < T; t += 2) {
+            K4_TILE(t, x0, x1, x2, x3, y0, y1, y2, y3)
+            K4_TILE(t + 1, y0, y1, y2, y3, x0, x1, x2, x3)
+            bool need = false;
+#pragma unroll
+            for (int i = 0; i < K4_NT; ++i) need |= cnt[i] >= (uint32_t)KM_FLUSH_AT;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                flush();
+                load_queries();                                  // (rebuilt, not kept alive across the flush: see knn_mfma_kernel)
+                const int tr = min(t + 2, T - 1);
+                x0 = frag(tr, 0); x1 = frag(tr, 1); x2 = frag(tr, 2); x3 = frag(tr, 3);
+                K4_MFMA8(0, x0, x1, x2, x3)
+            }
+        }
+#undef K4_TILE
+#undef K4_TEST
+#undef K4_INTERLEAVE
+#undef K4_MFMA8
+    }
+    flush();
+}
+
 }  // namespace slideo

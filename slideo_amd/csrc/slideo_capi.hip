@@ -110,7 +110,8 @@ struct slideo_matcher {
     bool finalized = false;
     int64_t M = -1;
     DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
-    int knn_engine = 0;     // 0 = FP4 MFMA (default), 1 = integer VALU popcount
+    int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
+                            // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_mfma4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_mfma_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
 
     // workspaces
@@ -323,11 +324,27 @@ void expand_train(const uint32_t* t_dev, int nt, DevBuf& out, hipStream_t st) {
     check_launch("knn_expand_train_kernel");
 }
 
-struct KnnPlan { int qblocks, nseg, per_seg; };
+struct KnnPlan { int engine, qblocks, nseg, per_seg; };
+// The matrix-core engine has two wave shapes.  One block of 1024 queries per CU at 2 waves/SIMD (engine 2) keeps half of
+// every SIMD's registers and 96 KB of LDS per CU free for the other unit's ORB / verify kernels during the whole launch:
+// +8 % on the headline step (239 query blocks).  It needs enough queries to put a block on most CUs without splitting the
+// train set; below that (64 4K frames = 125 blocks: -6 %) the 512-query blocks of engine 3 fill the chip better.
+int knn_engine_for(const slideo_matcher* m, int nq) {
+    if (m->knn_engine != 0) return m->knn_engine;
+    return cdiv(std::max(nq, 1), K4_QPB) >= 192 ? 2 : 3;
+}
 KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
     KnnPlan p{};
     nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
-    if (m->knn_engine == 0 && nt > 0) {
+    p.engine = knn_engine_for(m, nq);
+    if (p.engine == 2 && nt > 0) {
+        // one block of 1024 queries per CU: split the train set when fewer query blocks than 3/4 of the CUs exist
+        p.qblocks = cdiv(nq, K4_QPB);
+        const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
+        int nseg = p.qblocks >= 192 ? 1 : std::min(std::max(256 / std::max(p.qblocks, 1), 1), n_st);
+        p.per_seg = cdiv(n_st, std::max(nseg, 1));
+        p.nseg = cdiv(n_st, p.per_seg);
+    } else if (p.engine == 3 && nt > 0) {
         p.qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
@@ -351,7 +368,8 @@ KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
 void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt) {
     const KnnPlan p = knn_plan(m, nq, nt);
     S.d_keys.reserve((size_t)p.nseg * std::max(nq, 1) * KLIST * 4);
-    if (m->knn_engine == 0) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
+    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
+    if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * K4_PEND_WORDS_PER_WAVE * 4);
 }
 
 // t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
@@ -364,7 +382,17 @@ void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const ui
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
     const KnnPlan p = knn_plan(m, nq, nt);
     knn_reserve(m, S, nq, nt);
-    if (m->knn_engine == 0 && nt > 0) {
+    if (p.engine == 2 && nt > 0) {
+        knn_mfma4_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
+                                                                         S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
+        check_launch("knn_mfma4_kernel");
+        if (p.nseg > 1) {
+            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
+            check_launch("knn_merge_kernel");
+        }
+        return;
+    }
+    if (p.engine == 3 && nt > 0) {
 #ifdef KM_TIMING
         static unsigned long long* dbg = nullptr;
         if (!dbg) HIP_CHECK(hipMalloc(&dbg, 64));
@@ -637,6 +665,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<slideo_matcher> mm(new slideo_matcher());
     mm->cfg = *cfg; mm->device = device;
+    if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
@@ -682,7 +711,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
 }
 
 int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
-    if (!m || engine < 0 || engine > 1) return SLIDEO_ERR_INVALID_ARG;
+    if (!m || engine < 0 || engine > 3) return SLIDEO_ERR_INVALID_ARG;
     m->knn_engine = engine;
     return SLIDEO_OK;
 }
@@ -1030,7 +1059,7 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
     DevBuf tapx;
-    if (m->knn_engine == 0 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
+    if (m->knn_engine != 1 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
     run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt, 0.f);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());

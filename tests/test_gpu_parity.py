@@ -29,7 +29,7 @@ def mdef(capi):
 # ---- kNN ---------------------------------------------------------------------------------
 # every kNN test runs on both engines: "mfma" (FP4 matrix cores, default) and "valu" (popcount)
 
-@pytest.fixture(params=["mfma", "valu"])
+@pytest.fixture(params=["mfma", "mfma2", "mfma4", "valu"])
 def knn_engine(request, mdef):
     mdef.set_knn_engine(request.param)
     yield request.param
@@ -298,8 +298,10 @@ def test_end_to_end_larger_deck_traces(capi, oracle, synth):
     frames, truth, _ = synth.frames(pages, 24, 640, 360)
     m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
     assert m.descriptor_count == db.descriptor_count > 20000
-    v = m.match_frames(frames)
-    _compare_traces(m, db, frames, v)
+    for engine in ("mfma4", "mfma2"):                          # both matrix-core wave shapes, fused vote filter on
+        m.set_knn_engine(engine)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)
     m.set_knn_exact_lists(True)
     v2 = m.match_frames(frames)
     assert np.array_equal(v, v2)
@@ -312,12 +314,13 @@ def test_knn_engines_give_identical_verdicts(capi, cfg0_data):
     m.add_pages(list(pages)); m.finalize()
     a = m.match_frames(frames)
     ca = [m.last_candidates(i) for i in range(len(frames))]
-    m.set_knn_engine("valu")
-    b = m.match_frames(frames)
-    cb = [m.last_candidates(i) for i in range(len(frames))]
-    assert np.array_equal(a, b)
-    for x, y in zip(ca, cb):
-        assert np.array_equal(x["n_votes"], y["n_votes"]) and np.array_equal(x["inliers"], y["inliers"])
+    for engine in ("valu", "mfma2", "mfma4"):                  # the fused vote filter runs in both matrix-core shapes
+        m.set_knn_engine(engine)
+        b = m.match_frames(frames)
+        cb = [m.last_candidates(i) for i in range(len(frames))]
+        assert np.array_equal(a, b), engine
+        for x, y in zip(ca, cb):
+            assert np.array_equal(x["n_votes"], y["n_votes"]) and np.array_equal(x["inliers"], y["inliers"]), engine
     m.close()
 
 
