@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--pages", type=int, default=0)
     ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu"], help="kNN engine (identical results)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (<= the library's slots)")
+    ap.add_argument("--inflight", type=int, default=0, help="batches in flight (default and maximum: the library's slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
@@ -109,6 +109,7 @@ def main():
     cfg = _capi.default_config(nfeatures=wl["nfeatures"])
     m = _capi.Matcher(cfg, device=local_rank)
     m.set_knn_engine(args.knn)
+    args.inflight = min(args.inflight or m.max_in_flight(), m.max_in_flight())
     t0 = time.time()
     CH = 50
     for i in range(0, P, CH):
@@ -185,7 +186,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
                    "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
-                   "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step; 2 batches in flight per GPU on 2 HIP streams" % world,
+                   "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step; %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
                    "accuracy_vs_synthetic_truth": round(acc, 4),
                    "mean_keypoints_per_frame": round(float(v["n_keypoints"].mean()), 1)},

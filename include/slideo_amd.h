@@ -161,11 +161,13 @@ int32_t     slideo_match_frames_bgr8_dev(slideo_matcher* m, int32_t n_frames,
                                          slideo_verdict* verdicts_out, void* hip_stream);
 
 /* Streaming form of the same call for callers that keep the GPU fed: submit a unit of frames (device
- * memory, must stay valid until collected), later collect its verdicts.  At most two units are in
- * flight; they run on two internal streams so that the ORB stage of one unit overlaps the matrix-core
- * bound kNN of the previous one (the reference gets the same effect from rayon's work stealing,
- * mo/lib.rs:174,213).  Tickets must be collected in submission order.  The synchronous entry points
- * above use the same machinery on two halves of their batch. */
+ * memory, must stay valid until collected), later collect its verdicts.  At most
+ * slideo_matcher_max_in_flight() units (4) are in flight; each runs on its own internal stream and workspace
+ * slot so that the ORB and verification stages of some units share the GPU with the matrix-core bound kNN of
+ * others (the reference gets the same effect from rayon's work stealing, mo/lib.rs:174,213).  Tickets must
+ * be collected in submission order.  The synchronous entry points above use the same machinery on two
+ * halves of their batch. */
+int32_t     slideo_matcher_max_in_flight(const slideo_matcher* m);
 int32_t     slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames,
                                            const uint8_t* frames_dev, int32_t width, int32_t height,
                                            int32_t stride_bytes, int64_t frame_stride_bytes,

@@ -39,7 +39,7 @@ CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers",
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p)
 
 EXPORTS = [
-    "slideo_abi_version", "slideo_config_default", "slideo_matcher_create", "slideo_matcher_destroy",
+    "slideo_abi_version", "slideo_matcher_max_in_flight", "slideo_config_default", "slideo_matcher_create", "slideo_matcher_destroy",
     "slideo_last_error", "slideo_matcher_add_pages_bgr8", "slideo_matcher_finalize_pages",
     "slideo_matcher_page_count", "slideo_matcher_descriptor_count", "slideo_matcher_get_page_features",
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
@@ -75,6 +75,7 @@ def lib():
         L.slideo_matcher_descriptor_count.restype = C.c_int64
         L.slideo_matcher_descriptor_count.argtypes = [C.c_void_p]
         L.slideo_matcher_page_count.argtypes = [C.c_void_p]
+        L.slideo_matcher_max_in_flight.argtypes = [C.c_void_p]
         L.slideo_matcher_destroy.argtypes = [C.c_void_p]
         L.slideo_matcher_destroy.restype = None
         _lib = L
@@ -189,8 +190,11 @@ class Matcher:
                                                        C.c_void_p(stream)))
         return out
 
+    def max_in_flight(self):
+        return int(lib().slideo_matcher_max_in_flight(self._h))
+
     def submit_dev(self, dev_ptr, n, w, h, stride=None, frame_stride=None, stream=0):
-        """Streaming form: returns a ticket; at most two units in flight; collect in order."""
+        """Streaming form: returns a ticket; at most max_in_flight() units in flight; collect in order."""
         stride = stride or w * 3
         frame_stride = frame_stride or stride * h
         t = C.c_int64()

@@ -407,6 +407,9 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_mfma_kernel(const uint32_t*
 // and the flush, which are the same).  Lane L owns the lists of wave-local queries L (tile L/32) and L + 64 (tile 2 + L/32).
 // Grid (ceil(nq / 1024), nseg), block 512.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef K4_PRIO
+#define K4_PRIO KM_MFMA_PRIO
+#endif
 constexpr int K4_NT = 4;
 constexpr int K4_QPW = 32 * K4_NT;                       // queries per wave
 constexpr int K4_QPB = KM_WAVES * K4_QPW;                // queries per block
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(KM_THREADS, 2) void knn_mfma4_kernel(const uint32_t
             if (tn_ % TPS == 0 && (t) + 1 < T) acquire(tn_ / TPS);                                                    \
             n0 = frag(tn_, 0); n1 = frag(tn_, 1);                                                                     \
             int tkA_[5], tkB_[5];                                                                                     \
-            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            __builtin_amdgcn_s_setprio(K4_PRIO);                                                                 \
             K4_MFMA8(2, c0, c1, c2, c3)                                                                               \
             int mA_ = tree(a[0], tkA_), mB_ = tree(a[1], tkB_);                                                       \
             K4_INTERLEAVE                                                                                             \
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(KM_THREADS, 2) void knn_mfma4_kernel(const uint32_t
             __builtin_amdgcn_s_setprio(0);                                                                            \
             n2 = frag(tn_, 2); n3 = frag(tn_, 3);                                                                     \
             K4_TEST(0, t)                                                                                             \
-            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);                                                                 \
+            __builtin_amdgcn_s_setprio(K4_PRIO);                                                                 \
             K4_MFMA8(0, n0, n1, n2, n3)                                                                               \
             mA_ = tree(a[2], tkA_); mB_ = tree(a[3], tkB_);                                                           \
             K4_INTERLEAVE                                                                                             \

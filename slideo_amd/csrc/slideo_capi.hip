@@ -27,7 +27,7 @@ using namespace slideo;
 namespace {
 
 #ifndef SLIDEO_NSLOTS
-#define SLIDEO_NSLOTS 2
+#define SLIDEO_NSLOTS 4
 #endif
 constexpr int NSLOTS = SLIDEO_NSLOTS;      // units in flight (each with its own workspace and HIP stream)
 constexpr int KLIST = 32;
@@ -92,7 +92,7 @@ struct slideo_matcher {
     std::string err;
     slideo_progress_fn progress = nullptr;
     void* progress_user = nullptr;
-    size_t ws_budget = (size_t)12 << 30;
+    size_t ws_budget = (size_t)48 << 30;      // all slots together (SLIDEO_WS_GB); 288 GB of HBM per GPU
 
     DevBuf d_tables, d_rng, d_ictab;
     int ic_shift = 0, ic_entries = 0;     // intensity-centroid weight table of describe_kernel (geom.h ic_weight_table)
@@ -191,7 +191,7 @@ void upload_area(slideo_matcher* m) {
 
 // max frames of size (w,h) per unit under the workspace budget (two slots share it)
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
-    size_t per = (size_t)g.frame_bytes * 2 + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
+    size_t per = (size_t)g.frame_bytes + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
     size_t fit = std::max<size_t>(1, (m->ws_budget / NSLOTS) / std::max<size_t>(per, 1));
     return (int)std::min<size_t>({(size_t)std::max(n, 1), fit, (size_t)4096});
 }
@@ -709,6 +709,8 @@ void slideo_matcher_destroy(slideo_matcher* m) {
     }
     delete m;
 }
+
+int32_t slideo_matcher_max_in_flight(const slideo_matcher* m) { return m ? NSLOTS : 0; }
 
 int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
     if (!m || engine < 0 || engine > 3) return SLIDEO_ERR_INVALID_ARG;

@@ -373,7 +373,10 @@ def test_streaming_submit_collect(capi, cfg0_data):
     fb = 640 * 360 * 3
     t1 = m.submit_dev(t.data_ptr(), 3, 640, 360)
     t2 = m.submit_dev(t.data_ptr() + 3 * fb, 5, 640, 360)
-    with pytest.raises(capi.SlideoError) as e:          # a third unit needs a free slot
+    slots = m.max_in_flight()
+    assert slots >= 2
+    extra = [m.submit_dev(t.data_ptr(), 1, 640, 360) for _ in range(slots - 2)]
+    with pytest.raises(capi.SlideoError) as e:          # one unit more than there are slots
         m.submit_dev(t.data_ptr(), 1, 640, 360)
     assert e.value.code == 4
     with pytest.raises(capi.SlideoError) as e:          # tickets are collected in order
@@ -383,13 +386,15 @@ def test_streaming_submit_collect(capi, cfg0_data):
         m.orb(frames[0])
     assert e.value.code == 4
     a = m.collect(t1); b = m.collect(t2)
+    for x in extra:
+        assert np.array_equal(m.collect(x), ref[:1])
     assert np.array_equal(np.concatenate([a, b]), ref)
     assert list(ref["page_idx"]) == list(truth)
-    # a long stream of units through the two slots
+    # a long stream of units through the slots
     tickets, outs = [], []
     for i in range(8):
         tickets.append(m.submit_dev(t.data_ptr() + i * fb, 1, 640, 360))
-        if len(tickets) == 2:
+        if len(tickets) == slots:
             outs.append(m.collect(tickets.pop(0)))
     while tickets:
         outs.append(m.collect(tickets.pop(0)))

@@ -22,7 +22,7 @@ bad = 0
 t0 = time.time()
 pending = []
 for r in range(reps):
-    if len(pending) == 2:
+    if len(pending) == m.max_in_flight():
         v = m.collect(pending.pop(0))
         bad += int(not np.array_equal(v, ref))
     pending.append(m.submit_dev(d.data_ptr(), B, 1920, 1080))
