@@ -591,7 +591,8 @@ def test_end_to_end_other_verify_parameters(capi, oracle, cfg0_data, over):
 
 
 # ---- size-independent properties at the headline shapes (no CPU oracle at this size) -----------------------------
-def test_headline_shape_properties(capi, synth):
+@pytest.mark.parametrize("engine", ["mfma2", "mfma4"])
+def test_headline_shape_properties(capi, synth, engine):
     """1080p frames against full-size pages with the reference's literal parameters (ORB-1000, k = 30, min rating 50):
     the verdicts must not depend on how frames are batched or ordered, repeat exactly, and assign the right page."""
     P, B = 120, 96
@@ -601,6 +602,7 @@ def test_headline_shape_properties(capi, synth):
     for i in range(0, P, 40):
         m.add_pages(list(pages[i:i + 40]))
     m.finalize()
+    m.set_knn_engine(engine)                                   # both matrix-core wave shapes at this scale (train set split in two)
     assert m.descriptor_count > 100000
     v = m.match_frames(frames)
     assert np.array_equal(v, m.match_frames(frames))                          # idempotent
