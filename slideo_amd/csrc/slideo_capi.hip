@@ -70,7 +70,7 @@ struct Slot {
 
     // Give this (idle) slot the capacities of `o`.  A slot used for the first time would otherwise grow its ~25 buffers
     // (hipFree + hipMalloc, device-wide stalls, tens of ms for the GB-sized ones) in the middle of a steady-state
-    // stream of batches; sizing both slots when the first one grows keeps every later unit allocation-free.
+    // stream of batches; sizing every idle slot when one grows keeps every later unit allocation-free.
     void match_capacity(const Slot& o) {
         DevBuf* mine[] = {&d_stage, &d_pyr, &d_blur, &d_cand, &d_hist, &d_candcount, &d_flags, &d_thr, &d_lvlofs, &d_kpcount, &d_qofs,
                           &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs};
@@ -189,7 +189,7 @@ void upload_area(slideo_matcher* m) {
     m->area_dirty = false;
 }
 
-// max frames of size (w,h) per unit under the workspace budget (two slots share it)
+// max frames of size (w,h) per unit under the workspace budget (the slots share it)
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
     size_t per = (size_t)g.frame_bytes + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
     size_t fit = std::max<size_t>(1, (m->ws_budget / NSLOTS) / std::max<size_t>(per, 1));
@@ -463,7 +463,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     S.timed = prof;
     if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
     orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride);
-    orb_wait_info(m, S);                  // the other slot's kNN / verify keep the GPU busy meanwhile
+    orb_wait_info(m, S);                  // the other units' kNN / verify keep the GPU busy meanwhile
     const uint32_t qtot = S.orb.qtot;
     // all workspace before the timed kNN interval
     knn_reserve(m, S, (int)qtot, (int)m->M);
@@ -557,7 +557,7 @@ void check_match_args(slideo_matcher* m, int n, const void* frames, const void* 
     if (frame_stride < (int64_t)h * stride) fail(SLIDEO_ERR_INVALID_ARG, "frame_stride smaller than one frame");
 }
 
-// Synchronous matching of n frames: cut into units and run them through the two slots as a pipeline.
+// Synchronous matching of n frames: cut into units and run them through the slots as a pipeline.
 void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_device, int w, int h, int stride,
                        int64_t frame_stride, slideo_verdict* out, hipStream_t user_stream) {
     check_match_args(m, n, frames, out, w, h, stride, frame_stride);
