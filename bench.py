@@ -12,7 +12,7 @@ the per-frame verdict records.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the exact
-Hamming kNN: knn_mfma_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
+Hamming kNN: knn_mfma4_kernel / knn_mfma_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
 library; `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
 bounded sample of the same workload on the host cores.
 """
@@ -133,8 +133,8 @@ def main():
         return v
 
     def run_steps(k, depth=None, local=False):
-        """k steps; a step = one batch of B frames through the whole hot path.  Two batches are kept in flight
-        (submit i+1 before collecting i) so that ORB of the next batch overlaps kNN / verify of the current one."""
+        """k steps; a step = one batch of B frames through the whole hot path.  `depth` batches are kept in flight
+        (submit i+depth-1 before collecting i) so that the ORB / verify stages of some batches share the GPU with the kNN of others."""
         v, pending = None, []
         depth = depth or (1 if args.no_overlap else max(1, args.inflight))
         done = (lambda x: x) if local else finish           # local: no collective (only this rank runs these steps)
