@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 2
+#define SLIDEO_ABI_VERSION 3
 
 enum {
     SLIDEO_OK = 0,
@@ -46,6 +46,59 @@ enum {
     SLIDEO_ERR_EMPTY_INDEX = 6,   /* no page produced a descriptor (reference: FLANN train on empty set throws, mo/flann.rs:45-47) */
     SLIDEO_ERR_CAPACITY = 7       /* caller-provided output buffer too small   */
 };
+
+/* OpenCV-semantics switches.  The arithmetic of the reference's hot path lives in OpenCV 4.5.2 C++
+ * (Cargo.lock:1723-1724, .github/workflows/ci.yml:18), whose source is neither under the reference
+ * repository nor in this image; every primitive whose exact rounding could only be RECALLED (SURVEY.md
+ * Appendix A, confidence M / L) is therefore restated in more than one form, selected here, shared by the
+ * kernels' host tables (csrc/geom.h) and by the CPU restatement (oracle/).  Value 0 is always the default
+ * = the best estimate of what a stock 4.5.2 build (SSE3 baseline, AVX2 dispatch, IPP on: ci/install-bionic.sh)
+ * runs for the reference's calls; DESIGN.md section 5 says why.  tools/pin_opencv.py dumps OpenCV's own
+ * outputs where cv2 4.5.2 exists, and tests/test_opencv_pin.py then names the matching value of each switch.
+ * The HIP library implements the values marked [hip]; others fail slideo_matcher_create with
+ * SLIDEO_ERR_UNSUPPORTED (the CPU restatement implements all of them). */
+typedef struct slideo_ocv_variants {
+    /* cvtColor(BGR2GRAY) inside ORB::detectAndCompute, mo/feature_extractor.rs:32-40 [OCV A.1]
+     *   0 [hip] Q15 coefficients 3735/19235/9798, (x + 2^14) >> 15   (4.x color_rgb.simd.hpp)
+     *   1 [hip] Q14 coefficients 1868/9617/4899,  (x + 2^13) >> 14   (2.4 / 3.x)                      */
+    int32_t gray;
+    /* GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) inside ORB, same call [OCV A.6].  ORB blurs a
+     * SUBMATRIX of its pyramid buffer, which GaussianBlur's fixed-point branch excludes
+     * (smooth.dispatch.cpp: `sdepth == CV_8U && ((borderType & BORDER_ISOLATED) || !src.isSubmatrix())`), so the
+     * call falls through to sepFilter2D with the CV_32F kernel:
+     *   0 [hip] sepFilter2D in f32 (4.2+: createBitExactKernel_32S rejects a kernel whose taps x 256 are not
+     *           integers): row pass k0*p0 then += k_i*p_i, column pass k3*c then += k_j*(r_+j + r_-j),
+     *           saturate_cast<uchar>(cvRound); products CONTRACTED to fma (the AVX2-dispatched filter.avx2.cpp
+     *           of a stock build is compiled with -mfma and GCC's default -ffp-contract=fast)
+     *   1 [hip] the same without contraction (hosts without AVX2, or baseline-only builds)
+     *   2 [hip] sepFilter2D in Q8 integers (before 4.2: taps cvRound(k * 256) = 18 34 49 55 49 34 18, sum 257),
+     *           (sum + 2^15) >> 16, saturated
+     *   3 [hip] GaussianBlur's bit-exact fixed-point path (what a non-submatrix source takes): error-diffused
+     *           taps 18 34 48 56 48 34 18 (sum 256), (sum + 2^15) >> 16                                */
+    int32_t blur;
+    /* resize(prev level, INTER_LINEAR_EXACT) inside ORB [OCV A.2]: rounding of the 8.8 coefficient
+     *   0 [hip] cvRound(frac * 256), ties to even (softdouble -> ufixedpoint16)
+     *   1 [hip] floor(frac * 256 + 0.5), ties up                                                      */
+    int32_t resize;
+    /* fastAtan2 in ORB's ICAngles [OCV A.5]: the odd degree-7 polynomial
+     *   0 [hip] plain f32 multiplies and adds (scalar baseline code, SSE3: no fma)
+     *   1 [hip] the Horner steps contracted to fma (a build whose BASELINE has FMA3)                  */
+    int32_t atan;
+    /* warpAffine(nearest, WARP_INVERSE_MAP), mo/lib.rs:339-347 [OCV A.10]
+     *   0 [hip] 10-bit fixed point: (saturate<int>(M0 x * 1024) + saturate<int>((M1 y + M2) * 1024) + 512) >> 10
+     *   1       cvRound of the f64 coordinate M0 x + M1 y + M2 (no fixed point; definitional cross-check) */
+    int32_t warp;
+    /* resize(INTER_AREA) tap construction, mo/image_utils.rs:17 [OCV A.11]
+     *   0 [hip] computeResizeAreaTab: f32 weights, edge taps dropped below 1e-3 of a source cell
+     *   1 [hip] exact box-overlap weights, no cut-off (definitional cross-check)                      */
+    int32_t area;
+    /* Levenberg-Marquardt step of estimateAffinePartial2D's refinement, mo/image_utils.rs:52 [OCV A.9]
+     *   0 [hip] damped normal equations by Gaussian elimination with partial pivoting
+     *   1       by Jacobi eigen-decomposition + back-substitution (cv::solve(DECOMP_EIG)); equal to f64 round-off */
+    int32_t lm;
+    /* cv::RNG multiplier (RANSAC sample schedule [OCV A.9], BRIEF pattern [OCV A.7]); any value [hip] */
+    uint32_t rng_mul;             /* 4164903690 */
+} slideo_ocv_variants;
 
 /* Every literal the reference hard-codes on the hot path, as one struct whose
  * defaults (slideo_config_default) equal those literals. */
@@ -83,6 +136,8 @@ typedef struct slideo_config {
      * a query votes for its nearest row iff it has a second neighbour and (float)d1 < r * (float)d2 (f32,
      * strict); needs knn_k >= 2. */
     float   ratio_test;           /* 0.0f */
+    /* which restatement of each OpenCV primitive to run (all 0 / 4164903690 by default) */
+    slideo_ocv_variants ocv;
 } slideo_config;
 
 /* cv::KeyPoint as the reference consumes it (pt, size, angle, response,

@@ -13,6 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 
+class OcvVariants(C.Structure):
+    """slideo_ocv_variants (include/slideo_amd.h): which restatement of each OpenCV primitive runs."""
+    _fields_ = [("gray", C.c_int32), ("blur", C.c_int32), ("resize", C.c_int32), ("atan", C.c_int32),
+                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32)]
+
+
 class Config(C.Structure):
     """Mirror of slideo_config (include/slideo_amd.h)."""
     _fields_ = [
@@ -23,6 +29,7 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
+        ("ocv", OcvVariants),
     ]
 
 
@@ -67,7 +74,10 @@ def default_config(**over):
     c = Config()
     lib().so_config_default(C.byref(c))
     for k, v in over.items():
-        setattr(c, k, v)
+        if k.startswith("ocv_"):            # ocv_blur=2 -> c.ocv.blur = 2 (slideo_ocv_variants)
+            setattr(c.ocv, k[4:], v)
+        else:
+            setattr(c, k, v)
     return c
 
 

@@ -59,9 +59,10 @@ static inline int cv_ceil(double v) { return (int)std::ceil(v); }
 // [OCV A.7] cv::RNG — 64-bit multiply-with-carry (core/include/opencv2/core.hpp).
 struct CvRng {
     uint64_t state;
-    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    uint64_t mul;      // CV_RNG_COEFF = 4164903690 (slideo_ocv_variants.rng_mul)
+    explicit CvRng(uint64_t s, uint32_t mul_ = 4164903690u) : state(s ? s : 0xffffffffULL), mul(mul_) {}
     uint32_t next() {
-        state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+        state = (uint64_t)(uint32_t)state * mul + (uint32_t)(state >> 32);
         return (uint32_t)state;
     }
     int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a)) + a; }
@@ -90,14 +91,17 @@ static inline int reflect101(int p, int n) {
 // [OCV A.1] BGR -> gray, imgproc/src/color_rgb.simd.hpp RGB2Gray<uchar>
 //   gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
 // ---------------------------------------------------------------------------
-static void gray_bgr8(const uint8_t* bgr, int w, int h, int stride, Img8& out) {
+// ocv.gray: 0 = the Q15 coefficients above (4.x), 1 = Q14 1868/9617/4899 (2.4 / 3.x)
+static void gray_bgr8(const uint8_t* bgr, int w, int h, int stride, Img8& out, int variant = 0) {
     out = Img8(w, h);
+    const int cb = variant == 1 ? 1868 : 3735, cg = variant == 1 ? 9617 : 19235, cr = variant == 1 ? 4899 : 9798;
+    const int sh = variant == 1 ? 14 : 15;
     for (int y = 0; y < h; ++y) {
         const uint8_t* s = bgr + (size_t)y * stride;
         uint8_t* d = out.row(y);
         for (int x = 0; x < w; ++x) {
             int b = s[3 * x], g = s[3 * x + 1], r = s[3 * x + 2];
-            d[x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+            d[x] = (uint8_t)((b * cb + g * cg + r * cr + (1 << (sh - 1))) >> sh);
         }
     }
 }
@@ -109,7 +113,8 @@ static void gray_bgr8(const uint8_t* bgr, int w, int h, int stride, Img8& out) {
 // ---------------------------------------------------------------------------
 struct LinCoef { int ofs; int c0, c1; };  // value = c0*src[ofs] + c1*src[ofs+1]; weights sum to 256
 
-static void linear_exact_coeffs(int ssize, int dsize, std::vector<LinCoef>& out) {
+// ocv.resize: 0 = cvRound (ties to even), 1 = floor(x + 0.5) (ties up)
+static void linear_exact_coeffs(int ssize, int dsize, std::vector<LinCoef>& out, int variant = 0) {
     out.resize(dsize);
     double inv_scale = (double)dsize / (double)ssize;
     double scale = 1.0 / inv_scale;
@@ -120,7 +125,7 @@ static void linear_exact_coeffs(int ssize, int dsize, std::vector<LinCoef>& out)
         if (i >= 0 && ssize > 1) {
             if (i < ssize - 1) {
                 c.ofs = i;
-                c.c1 = cv_round((f - (double)i) * 256.0);
+                c.c1 = variant == 1 ? cv_floor((f - (double)i) * 256.0 + 0.5) : cv_round((f - (double)i) * 256.0);
                 c.c0 = 256 - c.c1;
             } else {
                 c.ofs = ssize - 1; c.c0 = 256; c.c1 = 0;   // right/bottom replicate
@@ -132,11 +137,11 @@ static void linear_exact_coeffs(int ssize, int dsize, std::vector<LinCoef>& out)
     }
 }
 
-static void resize_linear_exact(const Img8& src, int dw, int dh, Img8& dst) {
+static void resize_linear_exact(const Img8& src, int dw, int dh, Img8& dst, int variant = 0) {
     dst = Img8(dw, dh);
     std::vector<LinCoef> cx, cy;
-    linear_exact_coeffs(src.w, dw, cx);
-    linear_exact_coeffs(src.h, dh, cy);
+    linear_exact_coeffs(src.w, dw, cx, variant);
+    linear_exact_coeffs(src.h, dh, cy, variant);
     std::vector<uint32_t> r0(dw), r1(dw);
     for (int y = 0; y < dh; ++y) {
         const LinCoef& yc = cy[y];
@@ -203,9 +208,9 @@ static void umax_table(int half_patch, std::vector<int>& umax) {
 }
 
 // [OCV A.7] BRIEF pattern for patchSize != 31, orb.cpp makeRandomPattern
-static void brief_pattern(int patch_size, int npoints, std::vector<int32_t>& xy) {
+static void brief_pattern(int patch_size, int npoints, std::vector<int32_t>& xy, uint32_t rng_mul = 4164903690u) {
     xy.resize((size_t)npoints * 2);
-    CvRng rng(0x34985739);
+    CvRng rng(0x34985739, rng_mul);
     for (int i = 0; i < npoints; ++i) {
         xy[2 * i] = rng.uniform(-patch_size / 2, patch_size / 2 + 1);
         xy[2 * i + 1] = rng.uniform(-patch_size / 2, patch_size / 2 + 1);

@@ -15,6 +15,12 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "STATE", 5: "UNSUPPO
              6: "EMPTY_INDEX", 7: "CAPACITY"}
 
 
+class OcvVariants(C.Structure):
+    """slideo_ocv_variants (include/slideo_amd.h): which restatement of each OpenCV primitive runs."""
+    _fields_ = [("gray", C.c_int32), ("blur", C.c_int32), ("resize", C.c_int32), ("atan", C.c_int32),
+                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32)]
+
+
 class Config(C.Structure):
     """slideo_config (include/slideo_amd.h); defaults = the reference's literals."""
     _fields_ = [
@@ -25,6 +31,7 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
+        ("ocv", OcvVariants),
     ]
 
 
@@ -86,9 +93,10 @@ def default_config(**over):
     c = Config()
     lib().slideo_config_default(C.byref(c))
     for k, v in over.items():
-        if not hasattr(c, k):
+        tgt, name = (c.ocv, k[4:]) if k.startswith("ocv_") else (c, k)     # ocv_blur=2 -> c.ocv.blur = 2
+        if not hasattr(tgt, name):
             raise AttributeError(k)
-        setattr(c, k, v)
+        setattr(tgt, name, v)
     return c
 
 
