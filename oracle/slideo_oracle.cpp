@@ -300,11 +300,68 @@ static void gauss_kernel_fixed(int n, double sigma, std::vector<int>& k) {
     k[n2] = (int)(256 - 2 * acc);    // centre = remainder, kernel sums to exactly 256
 }
 
-static void gaussian_blur7(const Img8& src, Img8& dst) {
-    std::vector<int> k;
-    gauss_kernel_fixed(7, 2.0, k);
+// taps of ocv.blur 2: createSeparableLinearFilter before 4.2, kernel.convertTo(CV_32S, 256) = cvRound(k * 256)
+static void gauss_kernel_q8_rounded(int n, double sigma, std::vector<int>& k) {
+    std::vector<double> kd(n);
+    double scale2x = -0.5 / (sigma * sigma), sum = 0;
+    for (int i = 0; i < n; ++i) { double x = i - (n - 1) * 0.5; kd[i] = std::exp(scale2x * x * x); sum += kd[i]; }
+    k.assign(n, 0);
+    for (int i = 0; i < n; ++i) k[i] = cv_round((double)(float)(kd[i] * (1.0 / sum)) * 256.0);
+}
+
+// f32 taps of ocv.blur 0 / 1: getGaussianKernel(n, sigma, CV_32F) = (float) of the f64 (softdouble) kernel, built as
+// getGaussianKernelBitExact does: the n/2 outer values, sum = 2 * their sum + 1, each value times 1/sum
+static void gauss_kernel_f32(int n, double sigma, std::vector<float>& k) {
+    const int n2 = (n - 1) / 2;
+    std::vector<double> v(n2 + 1);
+    const double scale2x = -0.125 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; ++i, x += 2) { v[i] = std::exp((double)(x * x) * scale2x); sum += v[i]; }
+    sum *= 2.0; sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    k.assign(n, 0.f);
+    for (int i = 0; i < n2; ++i) { const double t = v[i] * mul1; k[i] = (float)t; k[n - 1 - i] = (float)t; }
+    k[n2] = (float)(1.0 * mul1);
+}
+
+static inline float mad_f32(float a, float b, float c, bool fma) { return fma ? std::fmaf(a, b, c) : a * b + c; }
+
+// ocv.blur (include/slideo_amd.h): 0 = sepFilter2D f32 with contracted products, 1 = f32 without, 2 = sepFilter2D Q8
+// (rounded taps, saturating), 3 = GaussianBlur's bit-exact fixed-point path (error-diffused taps)
+static void gaussian_blur7(const Img8& src, Img8& dst, int variant = 0) {
     int w = src.w, h = src.h;
     dst = Img8(w, h);
+    if (variant == 0 || variant == 1) {
+        // filter.simd.hpp RowFilter<uchar, float, RowNoVec>: s = k0 * p0; s += k_i * p_i (i = 1..6);
+        // SymmColumnFilter<Cast<float, uchar>, ColumnNoVec>: s = k3 * c (+ delta 0); s += k_(3+j) * (r_(+j) + r_(-j)); cvRound, saturate
+        const bool fma = variant == 0;
+        std::vector<float> k;
+        gauss_kernel_f32(7, 2.0, k);
+        std::vector<float> tmp((size_t)w * h);
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* s = src.row(y);
+            float* t = tmp.data() + (size_t)y * w;
+            for (int x = 0; x < w; ++x) {
+                float a = k[0] * (float)s[reflect101(x - 3, w)];
+                for (int i = 1; i < 7; ++i) a = mad_f32(k[i], (float)s[reflect101(x + i - 3, w)], a, fma);
+                t[x] = a;
+            }
+        }
+        for (int y = 0; y < h; ++y) {
+            uint8_t* d = dst.row(y);
+            const float* r[7];
+            for (int i = 0; i < 7; ++i) r[i] = tmp.data() + (size_t)reflect101(y + i - 3, h) * w;
+            for (int x = 0; x < w; ++x) {
+                float a = mad_f32(k[3], r[3][x], 0.f, fma);
+                for (int j = 1; j <= 3; ++j) a = mad_f32(k[3 + j], r[3 + j][x] + r[3 - j][x], a, fma);
+                int iv = (int)std::lrintf(a);
+                d[x] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+            }
+        }
+        return;
+    }
+    std::vector<int> k;
+    if (variant == 2) gauss_kernel_q8_rounded(7, 2.0, k); else gauss_kernel_fixed(7, 2.0, k);
     std::vector<uint32_t> tmp((size_t)w * h);
     for (int y = 0; y < h; ++y) {
         const uint8_t* s = src.row(y);
@@ -322,7 +379,8 @@ static void gaussian_blur7(const Img8& src, Img8& dst) {
         for (int x = 0; x < w; ++x) {
             uint32_t a = 0;
             for (int i = 0; i < 7; ++i) a += (uint32_t)k[i] * r[i][x];
-            d[x] = (uint8_t)((a + (1u << 15)) >> 16);
+            a = (a + (1u << 15)) >> 16;
+            d[x] = (uint8_t)(a > 255u ? 255u : a);          // (only the 257-sum taps of variant 2 can exceed 255)
         }
     }
 }
@@ -330,19 +388,23 @@ static void gaussian_blur7(const Img8& src, Img8& dst) {
 // ---------------------------------------------------------------------------
 // [OCV A.5] fastAtan2, core/src/mathfuncs_core.simd.hpp atan_f32 (all f32)
 // ---------------------------------------------------------------------------
-static float fast_atan2(float y, float x) {
+// ocv.atan: 0 = plain multiplies and adds, 1 = the Horner steps contracted to fma
+static float fast_atan2(float y, float x, int variant = 0) {
     const float s = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
                 p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const bool fma = variant == 1;
     float ax = std::fabs(x), ay = std::fabs(y), a, c, c2;
     if (ax >= ay) {
         c = ay / (ax + (float)DBL_EPSILON);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = mad_f32(mad_f32(mad_f32(p7, c2, p5, fma), c2, p3, fma), c2, p1, fma) * c;
     } else {
         c = ax / (ay + (float)DBL_EPSILON);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        // (with contraction GCC folds the final multiply into the subtraction: 90 - P*c = fma(-P, c, 90))
+        const float P = mad_f32(mad_f32(mad_f32(p7, c2, p5, fma), c2, p3, fma), c2, p1, fma);
+        a = fma ? std::fmaf(-P, c, 90.f) : 90.f - P * c;
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
@@ -350,7 +412,7 @@ static float fast_atan2(float y, float x) {
 }
 
 // [OCV A.5] intensity-centroid angle, orb.cpp ICAngles (unblurred level image)
-static float ic_angle(const Img8& im, int cx, int cy, const std::vector<int>& umax, int half) {
+static float ic_angle(const Img8& im, int cx, int cy, const std::vector<int>& umax, int half, int atan_variant = 0) {
     int m01 = 0, m10 = 0;
     const uint8_t* c = im.row(cy) + cx;
     int step = im.w;
@@ -364,7 +426,7 @@ static float ic_angle(const Img8& im, int cx, int cy, const std::vector<int>& um
         }
         m01 += v * vsum;
     }
-    return fast_atan2((float)m01, (float)m10);
+    return fast_atan2((float)m01, (float)m10, atan_variant);
 }
 
 // ---------------------------------------------------------------------------
@@ -385,7 +447,10 @@ static bool config_supported(const slideo_config& c) {
            c.patch_size >= 2 && c.edge_threshold >= desc_r + 3 && c.edge_threshold >= half &&
            c.edge_threshold >= 4 && c.scale_factor > 1.0f && c.fast_threshold >= 1 &&
            c.fast_threshold < 255 && c.knn_k >= 1 && c.knn_k <= 64 &&
-           c.ratio_test >= 0.f && !(c.ratio_test > 0.f && c.knn_k < 2);
+           c.ratio_test >= 0.f && !(c.ratio_test > 0.f && c.knn_k < 2) &&
+           c.ocv.gray >= 0 && c.ocv.gray <= 1 && c.ocv.blur >= 0 && c.ocv.blur <= 3 && c.ocv.resize >= 0 && c.ocv.resize <= 1 &&
+           c.ocv.atan >= 0 && c.ocv.atan <= 1 && c.ocv.warp >= 0 && c.ocv.warp <= 1 && c.ocv.area >= 0 && c.ocv.area <= 1 &&
+           c.ocv.lm >= 0 && c.ocv.lm <= 1;
 }
 
 struct Pyramid {
@@ -399,15 +464,15 @@ static void build_pyramid(const uint8_t* bgr, int w, int h, int stride, const sl
     std::vector<int> ws, hs;
     pyramid_sizes(w, h, c, ws, hs, p.scale);
     p.level.resize(c.nlevels);
-    gray_bgr8(bgr, w, h, stride, p.level[0]);
+    gray_bgr8(bgr, w, h, stride, p.level[0], c.ocv.gray);
     for (int l = 1; l < c.nlevels; ++l) {
         if (ws[l] < 1 || hs[l] < 1) { p.level[l] = Img8(0, 0); continue; }
-        resize_linear_exact(p.level[l - 1], ws[l], hs[l], p.level[l]);  // progressive
+        resize_linear_exact(p.level[l - 1], ws[l], hs[l], p.level[l], c.ocv.resize);  // progressive
     }
     if (with_blur) {
         p.blurred.resize(c.nlevels);
         for (int l = 0; l < c.nlevels; ++l)
-            if (p.level[l].w > 0) gaussian_blur7(p.level[l], p.blurred[l]);
+            if (p.level[l].w > 0) gaussian_blur7(p.level[l], p.blurred[l], c.ocv.blur);
     }
 }
 
@@ -421,7 +486,7 @@ static void orb_detect_describe(const uint8_t* bgr, int w, int h, int stride,
     const int half = c.patch_size / 2;
     umax_table(half, umax);
     std::vector<int32_t> pat;
-    brief_pattern(c.patch_size, 512, pat);
+    brief_pattern(c.patch_size, 512, pat, c.ocv.rng_mul);
     const int edge = c.edge_threshold;
 
     for (int l = 0; l < c.nlevels; ++l) {
@@ -463,7 +528,7 @@ static void orb_detect_describe(const uint8_t* bgr, int w, int h, int stride,
             k.octave = l;
             k.size = (float)c.patch_size * sf;
             k.response = (float)r.score;
-            k.angle = ic_angle(im, r.x, r.y, umax, half);
+            k.angle = ic_angle(im, r.x, r.y, umax, half, c.ocv.atan);
             k.x = (float)r.x * sf;
             k.y = (float)r.y * sf;
             // descriptor on the blurred level, orb.cpp computeOrbDescriptors
@@ -593,6 +658,88 @@ static bool solve4(const double Ain[16], const double bin[4], double x[4]) {
     return true;
 }
 
+// ocv.lm 1: cv::solve(A, b, DECOMP_EIG) — core/src/lapack.cpp JacobiImpl_ (largest off-diagonal pivot, n*n*30 sweeps at most,
+// eigenvalues sorted descending) followed by SVBkSb: x = sum_i (e_i . b) / w_i * e_i over the w_i above 2 eps * sum(w).
+static void jacobi_eig4(double A[16], double W[4], double V[16]) {
+    const int n = 4;
+    const double eps = DBL_EPSILON;
+    int indR[4], indC[4];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    double mv = 0;
+    int i, k, m;
+    for (k = 0; k < n; ++k) {
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) {
+            for (m = k + 1, mv = std::fabs(A[n * k + m]), i = k + 2; i < n; ++i) { double v = std::fabs(A[n * k + i]); if (mv < v) mv = v, m = i; }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = std::fabs(A[k]), i = 1; i < k; ++i) { double v = std::fabs(A[n * i + k]); if (mv < v) mv = v, m = i; }
+            indC[k] = m;
+        }
+    }
+    for (int iters = 0; iters < n * n * 30; ++iters) {
+        for (k = 0, mv = std::fabs(A[indR[0]]), i = 1; i < n - 1; ++i) { double v = std::fabs(A[n * i + indR[i]]); if (mv < v) mv = v, k = i; }
+        int l = indR[k];
+        for (i = 1; i < n; ++i) { double v = std::fabs(A[n * indC[i] + i]); if (mv < v) mv = v, k = indC[i], l = i; }
+        double p = A[n * k + l];
+        if (std::fabs(p) <= eps) break;
+        double y = (W[l] - W[k]) * 0.5;
+        double t = std::fabs(y) + std::hypot(p, y);
+        double sn = std::hypot(p, t);
+        double c = t / sn;
+        sn = p / sn; t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+        A[n * k + l] = 0;
+        W[k] -= t; W[l] += t;
+        double a0, b0;
+#define SO_ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * sn, v1 = a0 * sn + b0 * c
+        for (i = 0; i < k; ++i) SO_ROT(A[n * i + k], A[n * i + l]);
+        for (i = k + 1; i < l; ++i) SO_ROT(A[n * k + i], A[n * i + l]);
+        for (i = l + 1; i < n; ++i) SO_ROT(A[n * k + i], A[n * l + i]);
+        for (i = 0; i < n; ++i) SO_ROT(V[n * k + i], V[n * l + i]);
+#undef SO_ROT
+        for (int j = 0; j < 2; ++j) {
+            int idx = j == 0 ? k : l;
+            if (idx < n - 1) {
+                for (m = idx + 1, mv = std::fabs(A[n * idx + m]), i = idx + 2; i < n; ++i) { double v = std::fabs(A[n * idx + i]); if (mv < v) mv = v, m = i; }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                for (m = 0, mv = std::fabs(A[idx]), i = 1; i < idx; ++i) { double v = std::fabs(A[n * i + idx]); if (mv < v) mv = v, m = i; }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (k = 0; k < n - 1; ++k) {
+        m = k;
+        for (i = k + 1; i < n; ++i) if (W[m] < W[i]) m = i;
+        if (k != m) { std::swap(W[m], W[k]); for (i = 0; i < n; ++i) std::swap(V[n * m + i], V[n * k + i]); }
+    }
+}
+
+static bool solve4_eig(const double Ain[16], const double bin[4], double x[4]) {
+    double A[16], W[4], V[16];
+    std::memcpy(A, Ain, sizeof(A));
+    jacobi_eig4(A, W, V);
+    double thr = 0;
+    for (int i = 0; i < 4; ++i) thr += W[i];
+    thr *= DBL_EPSILON * 2;
+    x[0] = x[1] = x[2] = x[3] = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (std::fabs(W[i]) <= thr) continue;
+        double sdot = 0;
+        for (int j = 0; j < 4; ++j) sdot += V[4 * i + j] * bin[j];
+        sdot *= 1 / W[i];
+        for (int j = 0; j < 4; ++j) x[j] = x[j] + sdot * V[4 * i + j];
+    }
+    return true;
+}
+
+static bool solve4_v(const double A[16], const double b[4], double x[4], int lm_variant) {
+    return lm_variant == 1 ? solve4_eig(A, b, x) : solve4(A, b, x);
+}
+
 // residuals + (optionally) J^T J and J^T r for h = (a, b, tx, ty); returns |r|^2
 static double lm_eval(const P2f* src, const P2f* dst, int n, const double h[4], double* A,
                       double* v, double* rinf) {
@@ -618,7 +765,7 @@ static double lm_eval(const P2f* src, const P2f* dst, int n, const double h[4], 
 }
 
 // [OCV] calib3d/src/levmarq.cpp LMSolverImpl::run, 4 parameters, maxIters iterations
-static void lm_refine(const P2f* src, const P2f* dst, int n, double h[4], int max_iters) {
+static void lm_refine(const P2f* src, const P2f* dst, int n, double h[4], int max_iters, int lm_variant = 0) {
     const double eps = (double)FLT_EPSILON;
     double x[4] = {h[0], h[1], h[2], h[3]}, xd[4], A[16], v[4], D[4], d[4], Ap[16], rinf = 0;
     double S = lm_eval(src, dst, n, x, A, v, &rinf);
@@ -629,7 +776,7 @@ static void lm_refine(const P2f* src, const P2f* dst, int n, double h[4], int ma
     for (;;) {
         std::memcpy(Ap, A, sizeof(A));
         for (int i = 0; i < 4; ++i) Ap[i * 4 + i] += lambda * D[i];
-        if (!solve4(Ap, v, d)) { std::fill(d, d + 4, 0.0); }
+        if (!solve4_v(Ap, v, d, lm_variant)) { std::fill(d, d + 4, 0.0); }
         for (int i = 0; i < 4; ++i) xd[i] = x[i] - d[i];
         double Sd = lm_eval(src, dst, n, xd, nullptr, nullptr, nullptr);
         // temp_d = -A d + 2 v ; dS = d . temp_d
@@ -654,7 +801,7 @@ static void lm_refine(const P2f* src, const P2f* dst, int n, double h[4], int ma
                 for (int i = 0; i < 4; ++i) {
                     double e[4] = {0, 0, 0, 0}, col[4];
                     e[i] = 1;
-                    if (solve4(A, e, col)) maxval = std::max(maxval, std::fabs(col[i]));
+                    if (solve4_v(A, e, col, lm_variant)) maxval = std::max(maxval, std::fabs(col[i]));
                 }
                 lambda = lc = 1. / maxval;
                 nu *= 0.5;
@@ -691,7 +838,7 @@ static bool estimate_affine_partial(const P2f* from, const P2f* to, int count,
     } else {
         const float thr2 = (float)(c.ransac_threshold * c.ransac_threshold);
         int niters = std::max(c.ransac_max_iters, 1), max_good = 0, iter;
-        CvRng rng((uint64_t)-1);   // fresh per call
+        CvRng rng((uint64_t)-1, c.ocv.rng_mul);   // fresh per call
         std::vector<uint8_t> cur(count);
         double Mi[6];
         for (iter = 0; iter < niters; ++iter) {
@@ -717,7 +864,7 @@ static bool estimate_affine_partial(const P2f* from, const P2f* to, int count,
         for (int i = 0; i < count; ++i) if (mask[i]) { s.push_back(from[i]); d.push_back(to[i]); }
         if (!s.empty()) {
             double h[4] = {M[0], M[3], M[2], M[5]};
-            lm_refine(s.data(), d.data(), (int)s.size(), h, c.refine_iters);
+            lm_refine(s.data(), d.data(), (int)s.size(), h, c.refine_iters, c.ocv.lm);
             M[0] = M[4] = h[0]; M[1] = -h[1]; M[2] = h[2]; M[3] = h[1]; M[5] = h[3];
         }
     }
@@ -737,7 +884,12 @@ static inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 3
 
 struct WarpSampler {  // source coordinate of destination pixel (x, y)
     double M[6];
+    int variant = 0;      // ocv.warp: 0 = imgwarp.cpp's 10-bit fixed point, 1 = cvRound of the f64 coordinate
     inline void src_xy(int x, int y, int& sx, int& sy) const {
+        if (variant == 1) {
+            sx = sat_short(sat_int(M[0] * x + M[1] * y + M[2])); sy = sat_short(sat_int(M[3] * x + M[4] * y + M[5]));
+            return;
+        }
         const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
         int adelta = sat_int(M[0] * x * AB_SCALE), bdelta = sat_int(M[3] * x * AB_SCALE);
         int X0 = sat_int((M[1] * y + M[2]) * AB_SCALE) + round_delta;
@@ -750,9 +902,10 @@ struct WarpSampler {  // source coordinate of destination pixel (x, y)
 };
 
 static void warp_affine_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride, const double M[6],
-                                uint8_t* dst, int dw, int dh) {
+                                uint8_t* dst, int dw, int dh, int variant = 0) {
     WarpSampler ws;
     std::memcpy(ws.M, M, sizeof(ws.M));
+    ws.variant = variant;
     for (int y = 0; y < dh; ++y) {
         uint8_t* d = dst + (size_t)y * dw * 3;
         for (int x = 0; x < dw; ++x) {
@@ -775,8 +928,21 @@ static void warp_affine_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride,
 // ---------------------------------------------------------------------------
 struct AreaTap { int si, di; float alpha; };
 
-static void area_tab(int ssize, int dsize, double scale, std::vector<AreaTap>& tab) {
+// ocv.area: 0 = computeResizeAreaTab as below, 1 = exact box-overlap weights (no 1e-3 cut-off, weights normalised by the
+// clipped cell width) — a definitional cross-check
+static void area_tab(int ssize, int dsize, double scale, std::vector<AreaTap>& tab, int variant = 0) {
     tab.clear();
+    if (variant == 1) {
+        for (int dx = 0; dx < dsize; ++dx) {
+            double a = dx * scale, b = std::min(a + scale, (double)ssize);
+            double cell = b - a;
+            for (int sx = cv_floor(a); sx < ssize && (double)sx < b; ++sx) {
+                double ov = std::min(b, sx + 1.0) - std::max(a, (double)sx);
+                if (ov > 0) tab.push_back({sx, dx, (float)(ov / cell)});
+            }
+        }
+        return;
+    }
     for (int dx = 0; dx < dsize; ++dx) {
         double fsx1 = dx * scale, fsx2 = fsx1 + scale;
         double cell = std::min(scale, ssize - fsx1);
@@ -798,7 +964,7 @@ static inline uint8_t sat_u8_f(float v) {
 // Generic over a pixel fetcher so the same arithmetic serves plain images and
 // the fused warp -> area path used by tests of the fused GPU kernel.
 template <class Fetch>
-static bool resize_area_generic(int sw, int sh, int dw, int dh, uint8_t* dst, Fetch fetch) {
+static bool resize_area_generic(int sw, int sh, int dw, int dh, uint8_t* dst, Fetch fetch, int area_variant = 0) {
     if (dw <= 0 || dh <= 0 || dw > sw || dh > sh) return false;   // shrink only
     double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
     double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
@@ -831,8 +997,8 @@ static bool resize_area_generic(int sw, int sh, int dw, int dh, uint8_t* dst, Fe
         return true;
     }
     std::vector<AreaTap> xt, yt;
-    area_tab(sw, dw, scale_x, xt);
-    area_tab(sh, dh, scale_y, yt);
+    area_tab(sw, dw, scale_x, xt, area_variant);
+    area_tab(sh, dh, scale_y, yt, area_variant);
     // group taps by destination index
     std::vector<int> xs(dw + 1, 0), ys(dh + 1, 0);
     for (const AreaTap& t : xt) xs[t.di + 1]++;
@@ -869,13 +1035,13 @@ static void small_size(int w, int h, int small_area, int& sw, int& sh) {
 }
 
 static bool small_image(const uint8_t* bgr, int w, int h, int stride, int small_area,
-                        std::vector<uint8_t>& out, int& sw, int& sh) {
+                        std::vector<uint8_t>& out, int& sw, int& sh, int area_variant = 0) {
     small_size(w, h, small_area, sw, sh);
     out.assign((size_t)std::max(sw, 0) * std::max(sh, 0) * 3, 0);
     return resize_area_generic(w, h, sw, sh, out.data(), [&](int x, int y, uint8_t* p) {
         const uint8_t* s = bgr + (size_t)y * stride + 3 * x;
         p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
-    });
+    }, area_variant);
 }
 
 // mo/image_utils.rs:22-27 compute_similarity  ([OCV A.12] norm L2: integer sum, f64 sqrt)
@@ -987,7 +1153,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
     for (Rated& r : surv) {                                    // mo/lib.rs:335-351
         const Page& pg = db.pages[r.page];
         std::vector<uint8_t> proj_small((size_t)pg.sw * pg.sh * 3);
-        WarpSampler ws; std::memcpy(ws.M, r.M, sizeof(ws.M));
+        WarpSampler ws; std::memcpy(ws.M, r.M, sizeof(ws.M)); ws.variant = c.ocv.warp;
         // warp to the slide's size, then to_small_image of that (fused; identical arithmetic)
         int sw, sh; small_size(pg.w, pg.h, c.small_area, sw, sh);
         bool ok = resize_area_generic(pg.w, pg.h, sw, sh, proj_small.data(), [&](int x, int y, uint8_t* p) {
@@ -996,7 +1162,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
                 const uint8_t* s = bgr + (size_t)sy * stride + 3 * sx;
                 p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
             } else p[0] = p[1] = p[2] = 0;
-        });
+        }, c.ocv.area);
         r.sim = ok ? similarity_bgr8(proj_small.data(), pg.small.data(), pg.sw, pg.sh) : 0.f;
         r.survived = true;
     }
@@ -1039,6 +1205,8 @@ void so_config_default(slideo_config* c) {
     c->small_area = 300 * 400;                                     // mo/image_utils.rs:11
     c->changed_similarity = 0.98f;                                 // mo/video_capture.rs:98
     c->ratio_test = 0.0f;                                          // extension, off
+    std::memset(&c->ocv, 0, sizeof(c->ocv));                       // every OpenCV-variant switch at its default (0)
+    c->ocv.rng_mul = 4164903690u;                                  // CV_RNG_COEFF
 }
 
 int so_config_supported(const slideo_config* c) { return config_supported(*c) ? 1 : 0; }
@@ -1087,9 +1255,37 @@ void so_fast_nms_map(const uint8_t* img, int w, int h, int thr, uint8_t* out) {
 }
 void so_gaussian_blur7(const uint8_t* img, int w, int h, uint8_t* out) {
     Img8 s(w, h), d; std::memcpy(s.d.data(), img, s.d.size());
-    gaussian_blur7(s, d); std::memcpy(out, d.d.data(), d.d.size());
+    gaussian_blur7(s, d, 3); std::memcpy(out, d.d.data(), d.d.size());    // (GaussianBlur's bit-exact fixed-point path = ocv.blur 3)
 }
 float so_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+// the same primitives with an explicit slideo_ocv_variants value (tests/test_oracle_variants.py, tests/test_opencv_pin.py)
+float so_fast_atan2_v(float y, float x, int variant) { return fast_atan2(y, x, variant); }
+void so_gray_bgr8_v(const uint8_t* bgr, int w, int h, int stride, uint8_t* out, int variant) {
+    Img8 g; gray_bgr8(bgr, w, h, stride, g, variant); std::memcpy(out, g.d.data(), g.d.size());
+}
+void so_resize_linear_exact_v(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int variant) {
+    Img8 s(sw, sh), d; std::memcpy(s.d.data(), src, s.d.size());
+    resize_linear_exact(s, dw, dh, d, variant); std::memcpy(dst, d.d.data(), d.d.size());
+}
+void so_gaussian_blur7_v(const uint8_t* img, int w, int h, uint8_t* out, int variant) {
+    Img8 s(w, h), d; std::memcpy(s.d.data(), img, s.d.size());
+    gaussian_blur7(s, d, variant); std::memcpy(out, d.d.data(), d.d.size());
+}
+// integer taps of blur variants 2 / 3, f32 taps of variants 0 / 1
+void so_gauss_taps_q8(int variant, int32_t* out7) {
+    std::vector<int> k; if (variant == 2) gauss_kernel_q8_rounded(7, 2.0, k); else gauss_kernel_fixed(7, 2.0, k);
+    for (int i = 0; i < 7; ++i) out7[i] = k[i];
+}
+void so_gauss_taps_f32(float* out7) { std::vector<float> k; gauss_kernel_f32(7, 2.0, k); for (int i = 0; i < 7; ++i) out7[i] = k[i]; }
+void so_warp_affine_nn_bgr8_v(const uint8_t* src, int sw, int sh, int sstride, const double* M6, uint8_t* dst, int dw, int dh, int variant) {
+    warp_affine_nn_bgr8(src, sw, sh, sstride, M6, dst, dw, dh, variant);
+}
+int so_resize_area_bgr8_v(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int variant) {
+    return resize_area_generic(sw, sh, dw, dh, dst, [&](int x, int y, uint8_t* p) {
+        const uint8_t* s = src + (size_t)y * sstride + 3 * x; p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
+    }, variant) ? 0 : 5;
+}
+int so_solve4(const double* A16, const double* b4, double* x4, int lm_variant) { return solve4_v(A16, b4, x4, lm_variant) ? 1 : 0; }
 
 int so_pyramid_level(const uint8_t* bgr, int w, int h, int stride, const slideo_config* c, int level,
                      int blurred, uint8_t* out, int64_t cap, int32_t* lw, int32_t* lh) {
@@ -1184,7 +1380,7 @@ int so_changed_mask_bgr8(const uint8_t* frames, int n, int w, int h, int stride,
         last.assign(prev_small, prev_small + (size_t)sw * sh * 3); have = true;
     }
     for (int i = 0; i < n; ++i) {
-        if (!small_image(frames + (size_t)i * frame_stride, w, h, stride, c->small_area, cur, sw, sh)) return 5;
+        if (!small_image(frames + (size_t)i * frame_stride, w, h, stride, c->small_area, cur, sw, sh, c->ocv.area)) return 5;
         float s = have ? similarity_bgr8(last.data(), cur.data(), sw, sh) : 0.0f;
         changed[i] = s < c->changed_similarity;
         if (sims) sims[i] = s;
@@ -1204,7 +1400,7 @@ int so_pagedb_add_page(so_pagedb* db, const uint8_t* bgr, int w, int h, int stri
     if (db->finalized) return 4;
     Page p; p.w = w; p.h = h;
     orb_detect_describe(bgr, w, h, stride, db->cfg, p.orb);
-    if (!small_image(bgr, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh)) return 5;
+    if (!small_image(bgr, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh, db->cfg.ocv.area)) return 5;
     db->pages.push_back(std::move(p));
     return 0;
 }
@@ -1221,7 +1417,7 @@ int so_pagedb_add_pages(so_pagedb* db, const uint8_t* pages, int n, int w, int h
             p.w = w; p.h = h;
             const uint8_t* img = pages + (size_t)i * page_stride;
             orb_detect_describe(img, w, h, stride, db->cfg, p.orb);
-            if (!small_image(img, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh)) rc[t] = 5;
+            if (!small_image(img, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh, db->cfg.ocv.area)) rc[t] = 5;
         }
     };
     std::vector<std::thread> th;

@@ -109,25 +109,41 @@ inline void ic_weight_table(int half, const int* umax, std::vector<uint32_t>& ta
 
 // [OCV A.7] cv::RNG (64-bit multiply-with-carry)
 struct CvRng {
-    uint64_t state;
-    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    uint64_t state, mul;            // mul = CV_RNG_COEFF (slideo_ocv_variants.rng_mul, 4164903690)
+    explicit CvRng(uint64_t s, uint32_t mul_ = 4164903690u) : state(s ? s : 0xffffffffULL), mul(mul_) {}
     uint32_t next() {
-        state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+        state = (uint64_t)(uint32_t)state * mul + (uint32_t)(state >> 32);
         return (uint32_t)state;
     }
     int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a)) + a; }
 };
 
 // [OCV A.7] makeRandomPattern(patchSize, 512)
-inline void brief_pattern(int patch_size, int8_t* xy /* 1024 */) {
-    CvRng rng(0x34985739);
+inline void brief_pattern(int patch_size, int8_t* xy /* 1024 */, uint32_t rng_mul = 4164903690u) {
+    CvRng rng(0x34985739, rng_mul);
     for (int i = 0; i < 512; ++i) {
         xy[2 * i] = (int8_t)rng.uniform(-patch_size / 2, patch_size / 2 + 1);
         xy[2 * i + 1] = (int8_t)rng.uniform(-patch_size / 2, patch_size / 2 + 1);
     }
 }
 
-// [OCV A.6] 7-tap sigma-2 fixed-point Gaussian (getGaussianKernelFixedPoint_ED)
+// [OCV A.6] the 7-tap sigma-2 Gaussian of ORB's blur, one form per slideo_ocv_variants.blur value:
+//   0 / 1  f32 taps of getGaussianKernel(7, 2, CV_32F) (sepFilter2D in f32; gauss7_f32)
+//   2      Q8 taps cvRound(k * 256) of sepFilter2D's integer path before OpenCV 4.2: 18 34 49 55 49 34 18 (sum 257)
+//   3      error-diffused Q8 taps of GaussianBlur's bit-exact fixed-point path: 18 34 48 56 48 34 18 (sum 256)
+inline void gauss7_f32(float* k) {
+    double v[3], sum = 0;
+    for (int i = 0, x = -6; i < 3; ++i, x += 2) { v[i] = std::exp((double)(x * x) * (-0.125 / 4.0)); sum += v[i]; }
+    sum *= 2.0; sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    for (int i = 0; i < 3; ++i) { k[i] = (float)(v[i] * mul1); k[6 - i] = k[i]; }
+    k[3] = (float)(1.0 * mul1);
+}
+inline void gauss7_q8_rounded(int* k) {
+    float kf[7];
+    gauss7_f32(kf);
+    for (int i = 0; i < 7; ++i) k[i] = (int)std::lrint((double)kf[i] * 256.0);
+}
 inline void gauss7_fixed(int* k) {
     double kd[7], sum = 0;
     for (int i = 0; i < 7; ++i) { double x = i - 3.0; kd[i] = std::exp(-0.5 / 4.0 * x * x); sum += kd[i]; }
@@ -145,14 +161,15 @@ inline void gauss7_fixed(int* k) {
 
 // [OCV A.2] INTER_LINEAR_EXACT per-axis coefficients: entry = ofs | c1 << 16
 // (value = (256 - c1) * src[ofs] + c1 * src[min(ofs+1, n-1)])
-inline void linear_exact_table(int ssize, int dsize, std::vector<uint32_t>& out) {
+// round_variant = slideo_ocv_variants.resize: 0 = cvRound (ties to even), 1 = floor(x + 0.5)
+inline void linear_exact_table(int ssize, int dsize, std::vector<uint32_t>& out, int round_variant = 0) {
     double inv_scale = (double)dsize / (double)ssize, scale = 1.0 / inv_scale;
     for (int d = 0; d < dsize; ++d) {
         double f = scale * ((double)d + 0.5) - 0.5;
         int i = (int)std::floor(f);
         uint32_t ofs, c1;
         if (i >= 0 && ssize > 1) {
-            if (i < ssize - 1) { ofs = (uint32_t)i; c1 = (uint32_t)cv_round_d((f - (double)i) * 256.0); }
+            if (i < ssize - 1) { ofs = (uint32_t)i; c1 = round_variant == 1 ? (uint32_t)std::floor((f - (double)i) * 256.0 + 0.5) : (uint32_t)cv_round_d((f - (double)i) * 256.0); }
             else { ofs = (uint32_t)(ssize - 1); c1 = 0; }
         } else { ofs = 0; c1 = 0; }
         out.push_back(ofs | (c1 << 16));
@@ -178,6 +195,15 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (c.max_rated < 1 || c.max_rated > 16) { *why = "max_rated must be 1..16"; return false; }
     if (c.ransac_max_iters < 1 || c.ransac_max_iters > 5000) { *why = "ransac_max_iters must be 1..5000"; return false; }
     if (c.small_area < 64) { *why = "small_area too small"; return false; }
+    // OpenCV-variant switches: the values this library implements ([hip] in slideo_amd.h)
+    const slideo_ocv_variants& o = c.ocv;
+    if (o.gray < 0 || o.gray > 1) { *why = "ocv.gray must be 0 or 1"; return false; }
+    if (o.blur < 0 || o.blur > 3) { *why = "ocv.blur must be 0..3"; return false; }
+    if (o.resize < 0 || o.resize > 1) { *why = "ocv.resize must be 0 or 1"; return false; }
+    if (o.atan < 0 || o.atan > 1) { *why = "ocv.atan must be 0 or 1"; return false; }
+    if (o.area < 0 || o.area > 1) { *why = "ocv.area must be 0 or 1"; return false; }
+    if (o.warp != 0) { *why = "ocv.warp: only 0 (10-bit fixed point) is implemented on the GPU; the CPU restatement has 1"; return false; }
+    if (o.lm != 0) { *why = "ocv.lm: only 0 (Gaussian elimination) is implemented on the GPU; the CPU restatement has 1"; return false; }
     return true;
 }
 
@@ -218,14 +244,14 @@ inline void build_pyr_geom(int w, int h, const slideo_config& c, PyrGeom& g, std
             // x tables: 16-byte aligned, padded to a multiple of 4 entries with copies of the last entry
             // (resize_kernel reads them 4 entries at a time)
             while (lin_tab.size() % 4) lin_tab.push_back(0);
-            L.xtab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].w, L.w, lin_tab);
+            L.xtab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].w, L.w, lin_tab, c.ocv.resize);
             while (lin_tab.size() % 4) lin_tab.push_back(lin_tab.back());
             L.xctab_ofs = (int32_t)lin_tab.size();
             for (size_t i = (size_t)L.xtab_ofs, e = lin_tab.size(); i < e; ++i) {
                 uint32_t c1 = lin_tab[i] >> 16;
                 lin_tab.push_back((256u - c1) | (c1 << 16));
             }
-            L.ytab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].h, L.h, lin_tab);
+            L.ytab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].h, L.h, lin_tab, c.ocv.resize);
         }
     }
     g.frame_bytes = ofs; g.fast_tiles = ftile; g.blur_tiles = btile; g.cand_per_frame = cand;
@@ -245,11 +271,21 @@ struct AreaGeom {        // one per distinct (source size -> small size) class
     int32_t max_xtaps, max_ytaps;
 };
 
-inline void area_taps(int ssize, int dsize, double scale, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int& max_taps) {
+// variant = slideo_ocv_variants.area: 0 = computeResizeAreaTab, 1 = exact box-overlap weights (no 1e-3 cut-off)
+inline void area_taps(int ssize, int dsize, double scale, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int& max_taps, int variant = 0) {
     max_taps = 0;
     for (int dx = 0; dx < dsize; ++dx) {
         idx.push_back((int32_t)taps.size());
         size_t before = taps.size();
+        if (variant == 1) {
+            const double a = dx * scale, b = std::min(a + scale, (double)ssize), cellw = b - a;
+            for (int sx = (int)std::floor(a); sx < ssize && (double)sx < b; ++sx) {
+                const double ov = std::min(b, sx + 1.0) - std::max(a, (double)sx);
+                if (ov > 0) taps.push_back({sx, (float)(ov / cellw)});
+            }
+            max_taps = std::max(max_taps, (int)(taps.size() - before));
+            continue;
+        }
         double fsx1 = dx * scale, fsx2 = fsx1 + scale;
         double cell = std::min(scale, ssize - fsx1);
         int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
@@ -271,7 +307,7 @@ inline void small_size(int w, int h, int small_area, int& sw, int& sh) {
 }
 
 // Returns false when the resize is not a shrink (INTER_AREA would fall back to bilinear).
-inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vector<AreaTap>& taps, std::vector<int32_t>& idx) {
+inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int variant = 0) {
     a = AreaGeom();
     a.sw = w; a.sh = h;
     small_size(w, h, small_area, a.dw, a.dh);
@@ -282,12 +318,12 @@ inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vect
     a.fast_scale = 1.f / (float)(a.iscale_x * a.iscale_y);
     a.xidx_ofs = (int32_t)idx.size(); a.xtap_ofs = (int32_t)taps.size();
     {
-        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(w, a.dw, scale_x, t, i, a.max_xtaps);
+        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(w, a.dw, scale_x, t, i, a.max_xtaps, variant);
         taps.insert(taps.end(), t.begin(), t.end()); idx.insert(idx.end(), i.begin(), i.end());
     }
     a.yidx_ofs = (int32_t)idx.size(); a.ytap_ofs = (int32_t)taps.size();
     {
-        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(h, a.dh, scale_y, t, i, a.max_ytaps);
+        std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(h, a.dh, scale_y, t, i, a.max_ytaps, variant);
         taps.insert(taps.end(), t.begin(), t.end()); idx.insert(idx.end(), i.begin(), i.end());
     }
     return true;

@@ -32,21 +32,22 @@ namespace slideo {
 
 struct OrbTables {             // device-resident constants (per matcher)
     int32_t umax[68];
-    int32_t gk[8];             // 7-tap kernel, sums to 256
+    int32_t gk[8];             // 7-tap Q8 kernel of slideo_ocv_variants.blur 2 (sum 257) / 3 (sum 256); geom.h
+    float gkf[8];              // 7-tap f32 kernel of blur 0 / 1
     int8_t pattern[1024];      // 512 (x,y)
 };
+
+struct GrayCoef { uint32_t cb, cg, cr, shift; };      // slideo_ocv_variants.gray: Q15 3735/19235/9798 or Q14 1868/9617/4899
 
 // ---------------------------------------------------------------------------
 // [OCV A.1] gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
 // grid (ceil(w/4/256), h, B)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
-    return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
-}
-
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride,
                                                    int stride, uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
-                                                   int w, int h, int pitch, int aligned4) {
+                                                   int w, int h, int pitch, int aligned4, GrayCoef gc) {
+    const uint32_t half = 1u << (gc.shift - 1);
+    auto gray_of = [&](uint32_t b, uint32_t g, uint32_t r) { return (b * gc.cb + g * gc.cg + r * gc.cr + half) >> gc.shift; };
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -514,8 +515,84 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
             const uint32_t a1 = dot2_u16(vb, k45, dot2_u16(va, k23, dot2_u16(lb, k01, dot2_u16(rA, k6_, 1u << 15))));
             const uint32_t a2 = dot2_u16(rA, k56, dot2_u16(vb, k34, dot2_u16(va, k12, dot2_u16(lb, k_0, 1u << 15))));
             const uint32_t a3 = dot2_u16(rA, k45, dot2_u16(vb, k23, dot2_u16(va, k01, dot2_u16(rB, k6_, 1u << 15))));
-            // result byte = bits 16..23 of each sum
-            const uint32_t o = __builtin_amdgcn_perm(__builtin_amdgcn_perm(a3, a2, 0x0c0c0602u), __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), 0x05040100u);
+            // result byte = bits 16..23 of each sum (clamped: the taps of blur variant 2 sum to 257, so a sum can pass 255 << 16)
+            const uint32_t o = __builtin_amdgcn_perm(__builtin_amdgcn_perm(min(a3, 0xFFFFFFu), min(a2, 0xFFFFFFu), 0x0c0c0602u),
+                                                     __builtin_amdgcn_perm(min(a1, 0xFFFFFFu), min(a0, 0xFFFFFFu), 0x0c0c0602u), 0x05040100u);
+            const int gy = y0 + i;
+            if (inner && gy < L.h && xs < L.w) {
+                uint8_t* d = out + (int64_t)gy * L.pitch + xs;
+                if (xs + 3 < L.w) *reinterpret_cast<uint32_t*>(d) = o;
+                else for (int c = 0; c < 4 && xs + c < L.w; ++c) d[c] = (uint8_t)(o >> (8 * c));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [OCV A.6], slideo_ocv_variants.blur 0 / 1: the blur ORB actually gets for a pyramid level (a SUBMATRIX, so GaussianBlur
+// falls through to sepFilter2D with the CV_32F kernel): f32 row pass  s = k0 p0; s += k_i p_i (i = 1..6), f32 column pass
+// s = k3 c; s += k_(3+j) (r_(+j) + r_(-j)) (j = 1..3), saturate_cast<uchar>(cvRound(s)).  FMA = products contracted as a
+// stock build's AVX2-dispatched filter code has them (variant 0), or separate multiplies and adds (variant 1).
+// Same strip geometry as blur_kernel: a lane streams one aligned dword (4 pixels) per source row, gets its neighbours'
+// dwords by wave shuffle for the 7-tap row pass, and keeps the last 7 row-filtered rows (4 floats each) in a register ring.
+// grid (blur_tiles, B), block 256.
+// ---------------------------------------------------------------------------
+template <bool FMA>
+__global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+                                                       uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab) {
+    const int f = blockIdx.y;
+    const int l = level_of_tile(g, blockIdx.x, true);
+    const LevelGeom L = g.lv[l];
+    const int tile = blockIdx.x - L.btile0;
+    const int ty = tile / L.btx, tx = tile - ty * L.btx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tx * BLUR_TW;
+    const int y0 = ty * BLUR_TH + wave * BLUR_RH;
+    if (y0 >= L.h) return;
+    const int xs = x0 - 4 + 4 * lane;
+    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    uint8_t* out = blur + (int64_t)f * g.frame_bytes + L.ofs;
+    float k[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) k[i] = tab->gkf[i];
+    auto mad = [](float a, float b, float c) { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
+    auto load = [&](int y) { return blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs); };
+    // row pass of one source row: the lane's 4 outputs from pixels xs-3 .. xs+6
+    auto rowpass = [&](uint32_t d, float (&o)[4]) {
+        const uint32_t lf = __shfl_up(d, 1), rt = __shfl_down(d, 1);
+        float p[10];
+        p[0] = (float)((lf >> 8) & 255u); p[1] = (float)((lf >> 16) & 255u); p[2] = (float)(lf >> 24);
+        p[3] = (float)(d & 255u); p[4] = (float)((d >> 8) & 255u); p[5] = (float)((d >> 16) & 255u); p[6] = (float)(d >> 24);
+        p[7] = (float)(rt & 255u); p[8] = (float)((rt >> 8) & 255u); p[9] = (float)((rt >> 16) & 255u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = k[0] * p[j];
+#pragma unroll
+            for (int i = 1; i < 7; ++i) a = mad(k[i], p[j + i], a);
+            o[j] = a;
+        }
+    };
+    float ring[7][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rowpass(load(y0 - 3 + j), ring[j]);
+    const bool inner = lane >= 1 && lane <= 62;
+    uint32_t dn0 = load(y0 + 3), dn1 = load(y0 + 4), dn2 = load(y0 + 5);
+    for (int gI = 0; gI < BLUR_RH / 7; ++gI) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) {
+            const int i = gI * 7 + ph;                              // output row y0 + i; rows y0+i-3+j sit in ring[(ph+j)%7]
+            rowpass(dn0, ring[(ph + 6) % 7]);
+            dn0 = dn1; dn1 = dn2;
+            dn2 = load(min(y0 + i + 6, y0 + BLUR_RH + 2));
+            uint32_t o = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = mad(k[3], ring[(ph + 3) % 7][c], 0.f);
+#pragma unroll
+                for (int j = 1; j <= 3; ++j) a = mad(k[3 + j], ring[(ph + 3 + j) % 7][c] + ring[(ph + 3 - j) % 7][c], a);
+                const uint32_t v = min((uint32_t)(int)rintf(a), 255u);      // a >= 0: cvRound, then saturate
+                o |= v << (8 * c);
+            }
             const int gy = y0 + i;
             if (inner && gy < L.h && xs < L.w) {
                 uint8_t* d = out + (int64_t)gy * L.pitch + xs;
@@ -661,7 +738,9 @@ __global__ __launch_bounds__(1024) void sort_kernel(const uint32_t* __restrict__
 // [OCV A.5] fastAtan2 (f32) ; [OCV A.5] ICAngles ; [OCV A.7] rotated BRIEF-256
 // One wave per keypoint, 4 keypoints per block.  grid ceil(Qtot/4).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float fast_atan2f_cv(float y, float x) {
+// fma = slideo_ocv_variants.atan 1: the Horner steps (and the final 90 - P c) contracted, as a compiler does when the
+// scalar code is built for a baseline with FMA3
+__device__ __forceinline__ float fast_atan2f_cv(float y, float x, bool fma) {
     const float s = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
                 p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
@@ -669,11 +748,13 @@ __device__ __forceinline__ float fast_atan2f_cv(float y, float x) {
     if (ax >= ay) {
         c = ay / (ax + (float)DBL_EPSILON);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = fma ? __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1) * c
+                : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     } else {
         c = ax / (ay + (float)DBL_EPSILON);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = fma ? __builtin_fmaf(-__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1), c, 90.f)
+                : 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
@@ -706,7 +787,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
                                                        const uint32_t* __restrict__ qofs, int nframes,
                                                        const uint64_t* __restrict__ items, uint32_t qtot, DescWin dw,
                                                        const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
-                                                       slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc) {
+                                                       slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int atan_fma) {
     extern __shared__ __attribute__((aligned(16))) uint32_t desc_lds[];
     const int wave = threadIdx.x >> 6;
     const uint32_t gi = blockIdx.x * 4 + wave;
@@ -769,7 +850,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
-    const float angle = fast_atan2f_cv((float)m01, (float)m10);
+    const float angle = fast_atan2f_cv((float)m01, (float)m10, atan_fma != 0);
     const float ang = angle * (float)(3.14159265358979323846 / 180.f);
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
 
@@ -793,7 +874,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
             hsum = __builtin_amdgcn_udot4((uint32_t)(v8 >> 32), k456, hsum, false);
             acc += __umul24(hsum, gr[r]);                             // hsum <= 255 * 256
         }
-        return acc >> 16;
+        return min(acc >> 16, 255u);                                 // (the taps of blur variant 2 sum to 257)
     };
     uint64_t bits[4];
 #pragma unroll
@@ -808,6 +889,90 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
         const uint32_t t1 = blurred((int)rintf(x1), (int)rintf(y1));
         bits[w] = __builtin_amdgcn_ballot_w64(t0 < t1);
     }
+    if (lane < 4) reinterpret_cast<uint64_t*>(desc + (size_t)gi * 32)[lane] = bits[lane];
+    if (lane == 0) {
+        slideo_keypoint k;
+        k.x = kx; k.y = ky; k.size = (float)g.patch_size * sf; k.angle = angle;
+        k.response = (float)score; k.octave = l;
+        kp[gi] = k;
+    }
+}
+
+// slideo_ocv_variants.blur 0 / 1 (f32 blur): the float sums cannot be evaluated per sample in integer arithmetic, so
+// blur_f32_kernel materialises the blurred pyramid and this kernel reads it: the intensity centroid over the disc from the
+// UNBLURRED level (dword gathers straight from global memory / L2: one disc row is 16 dwords), then the 512 samples as
+// single bytes of the BLURRED level.  One wave per keypoint, 4 keypoints per block, no LDS.  grid ceil(Qtot / 4).
+__global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                               const OrbTables* __restrict__ tab, const uint32_t* __restrict__ qofs, int nframes,
+                                                               const uint64_t* __restrict__ items, uint32_t qtot,
+                                                               const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
+                                                               slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int atan_fma) {
+    const int wave = threadIdx.x >> 6;
+    const uint32_t gi = blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63;
+    if (gi >= qtot) return;
+    int lo = 0, hi = nframes;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
+    const int f = lo;
+    const uint64_t it = items[gi];
+    const int score = (int)(it & 255), px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
+    const LevelGeom L = g.lv[l];
+    const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
+    const uint8_t* bimg = blur + (int64_t)f * g.frame_bytes + L.ofs;
+    const int half = g.half_patch;
+    const float sf = L.scale;
+    const float kx = (float)px * sf, ky = (float)py * sf;
+    const float inv = 1.f / sf;
+    const int cx = (int)rintf(kx * inv), cy = (int)rintf(ky * inv);
+
+    int m10, m01 = 0;
+    {
+        const uint8_t* ic0 = img + (int64_t)(py - half) * L.pitch + (px - half);      // pixel (u, v) = (-half, -half)
+        const int ncm = (1 << ic_shift) - 1;
+        uint32_t accU = 0, accS = 0;
+        constexpr int ICB = 8;                                       // loads in flight per lane
+        for (int e0 = lane; e0 < ic_entries; e0 += 64 * ICB) {
+            uint32_t d[ICB]; uint2 wgt[ICB]; int rows[ICB];
+#pragma unroll
+            for (int u = 0; u < ICB; ++u) {
+                const int e = min(e0 + 64 * u, ic_entries - 1);      // (table entries past the disc carry weight 0; the clamp keeps `d` a plain array)
+                rows[u] = e >> ic_shift;
+                // rows past the disc (zero-weight pad entries) re-read the disc's last row instead of running off it
+                __builtin_memcpy(&d[u], ic0 + (int64_t)min(rows[u], 2 * half) * L.pitch + 4 * (e & ncm), 4);
+                wgt[u] = ic_tab[e];
+                if (e0 + 64 * u >= ic_entries) wgt[u] = make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < ICB; ++u) {
+                const uint32_t srow = __builtin_amdgcn_udot4(d[u], wgt[u].y, 0u, false);
+                accU = __builtin_amdgcn_udot4(d[u], wgt[u].x, accU, false);
+                accS += srow;
+                m01 += (rows[u] - half) * (int)srow;
+            }
+        }
+        m10 = (int)accU - half * (int)accS;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    const float angle = fast_atan2f_cv((float)m01, (float)m10, atan_fma != 0);
+    const float ang = angle * (float)(3.14159265358979323846 / 180.f);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+
+    const uint8_t* bc = bimg + (int64_t)cy * L.pitch + cx;
+    uint32_t t0[4], t1[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t pw = reinterpret_cast<const uint32_t*>(tab->pattern)[lane + 64 * w];
+        const float p0x = (float)(int8_t)(pw & 255), p0y = (float)(int8_t)((pw >> 8) & 255);
+        const float p1x = (float)(int8_t)((pw >> 16) & 255), p1y = (float)(int8_t)(pw >> 24);
+        const float x0 = p0x * a - p0y * b, y0 = p0x * b + p0y * a;
+        const float x1 = p1x * a - p1y * b, y1 = p1x * b + p1y * a;
+        t0[w] = bc[(int64_t)(int)rintf(y0) * L.pitch + (int)rintf(x0)];
+        t1[w] = bc[(int64_t)(int)rintf(y1) * L.pitch + (int)rintf(x1)];
+    }
+    uint64_t bits[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bits[w] = __builtin_amdgcn_ballot_w64(t0[w] < t1[w]);
     if (lane < 4) reinterpret_cast<uint64_t*>(desc + (size_t)gi * 32)[lane] = bits[lane];
     if (lane == 0) {
         slideo_keypoint k;

@@ -169,7 +169,7 @@ int area_class_for(slideo_matcher* m, int w, int h) {
     for (size_t i = 0; i < m->area_geoms.size(); ++i)
         if (m->area_geoms[i].sw == w && m->area_geoms[i].sh == h) return (int)i;
     AreaGeom a;
-    if (!build_area_geom(w, h, m->cfg.small_area, a, m->area_taps, m->area_idx))
+    if (!build_area_geom(w, h, m->cfg.small_area, a, m->area_taps, m->area_idx, m->cfg.ocv.area))
         fail(SLIDEO_ERR_UNSUPPORTED, "image %dx%d has area below small_area=%d: to_small_image would upscale (INTER_AREA falls back to bilinear in OpenCV), not implemented",
              w, h, m->cfg.small_area);
     m->area_geoms.push_back(a);
@@ -189,9 +189,11 @@ void upload_area(slideo_matcher* m) {
     m->area_dirty = false;
 }
 
+bool blur_is_f32(const slideo_matcher* m) { return m->cfg.ocv.blur <= 1; }
+
 // max frames of size (w,h) per unit under the workspace budget (the slots share it)
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
-    size_t per = (size_t)g.frame_bytes + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
+    size_t per = (size_t)g.frame_bytes * (blur_is_f32(m) ? 2 : 1) + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
     size_t fit = std::max<size_t>(1, (m->ws_budget / NSLOTS) / std::max<size_t>(per, 1));
     return (int)std::min<size_t>({(size_t)std::max(n, 1), fit, (size_t)4096});
 }
@@ -203,9 +205,12 @@ void require_idle(slideo_matcher* m) {
 // ---- ORB over `n` equally sized frames already on the device, in three steps -------------
 // stage 1: gray, pyramid, FAST+NMS, blur, retainBest thresholds, per-frame offsets; copies {Qtot, max, flags} to pinned memory
 // `with_blur`: also materialise the blurred pyramid (only the pyramid tap wants it; describe_kernel blurs at its samples)
+// the f32 blur of ocv.blur 0 / 1 cannot be evaluated per BRIEF sample in integer arithmetic: those variants always
+// materialise the blurred pyramid (blur_f32_kernel) and describe from it (describe_blurred_kernel)
 void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
                 bool with_blur = false) {
     hipStream_t st = S.st;
+    with_blur = with_blur || blur_is_f32(m);
     GeomEntry& ge = geom_for(m, w, h);
     const PyrGeom& g = ge.g;
     const int L = g.nlevels;
@@ -229,8 +234,9 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
     const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
     {
         dim3 grid(cdiv(cdiv(w, 4), 256), h, n);
+        const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
         gray_kernel<<<grid, 256, 0, st>>>(frames_dev, frame_stride, stride, S.d_pyr.as<uint8_t>(), g.frame_bytes, w, h,
-                                          g.lv[0].pitch, aligned4);
+                                          g.lv[0].pitch, aligned4, gc);
         check_launch("gray_kernel");
     }
     for (int l = 1; l < L; ++l) {
@@ -249,8 +255,13 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         check_launch("fast_kernel");
     }
     if (with_blur && g.blur_tiles > 0) {
-        blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
-        check_launch("blur_kernel");
+        if (m->cfg.ocv.blur == 0)
+            blur_f32_kernel<true><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+        else if (m->cfg.ocv.blur == 1)
+            blur_f32_kernel<false><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+        else
+            blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+        check_launch("blur kernel");
     }
     threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, S.d_thr.as<uint32_t>(), S.d_lvlofs.as<uint32_t>(),
                                            S.d_kpcount.as<uint32_t>(), flags);
@@ -292,11 +303,19 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
     while ((uint32_t)np2 < maxc) np2 <<= 1;
     sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(S.d_qofs.as<uint32_t>(), S.d_items.as<uint64_t>(), np2);
     check_launch("sort_kernel");
+    if (blur_is_f32(m)) {
+        describe_blurred_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
+                                                                    S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot,
+                                                                    m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
+                                                                    S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(), m->cfg.ocv.atan);
+        check_launch("describe_blurred_kernel");
+        return;
+    }
     const DescWin dw = describe_window(g.half_patch);
     describe_kernel<<<cdiv((int)qtot, 4), 256, (size_t)dw.dwords * 16, st>>>(g, S.d_pyr.as<uint8_t>(), m->d_tables.as<OrbTables>(),
                                                                              S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot, dw,
                                                                              m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
-                                                                             S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>());
+                                                                             S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(), m->cfg.ocv.atan);
     check_launch("describe_kernel");
 }
 
@@ -638,6 +657,8 @@ void slideo_config_default(slideo_config* c) {
     c->max_rated = 10; c->min_rating = 50.0; c->min_rating_ratio = 0.2;
     c->min_similarity = 0.5f; c->small_area = 300 * 400; c->changed_similarity = 0.98f;
     c->ratio_test = 0.0f;
+    std::memset(&c->ocv, 0, sizeof(c->ocv));         // every OpenCV-variant switch at its default
+    c->ocv.rng_mul = 4164903690u;                    // CV_RNG_COEFF
 }
 
 const char* slideo_last_error(const slideo_matcher* m) {
@@ -675,8 +696,9 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     mm->stream = mm->slots[0].st;
     OrbTables t{};
     umax_table(cfg->patch_size / 2, t.umax);
-    gauss7_fixed(t.gk);
-    brief_pattern(cfg->patch_size, t.pattern);
+    if (cfg->ocv.blur == 2) gauss7_q8_rounded(t.gk); else gauss7_fixed(t.gk);
+    gauss7_f32(t.gkf);
+    brief_pattern(cfg->patch_size, t.pattern, cfg->ocv.rng_mul);
     mm->d_tables.reserve(sizeof(OrbTables));
     HIP_CHECK(hipMemcpy(mm->d_tables.p, &t, sizeof(t), hipMemcpyHostToDevice));
     {
@@ -687,7 +709,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         HIP_CHECK(hipMemcpy(mm->d_ictab.p, ict.data(), ict.size() * 4, hipMemcpyHostToDevice));
     }
     std::vector<uint32_t> rng(RNG_TABLE);
-    CvRng r((uint64_t)-1);
+    CvRng r((uint64_t)-1, cfg->ocv.rng_mul);
     for (auto& v : rng) v = r.next();
     mm->d_rng.reserve(rng.size() * 4);
     HIP_CHECK(hipMemcpy(mm->d_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
@@ -813,6 +835,8 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     int64_t M = 0, small_bytes = 0;
     for (const HostPage& p : m->pages) { M += (int64_t)p.kp.size(); small_bytes += (int64_t)p.small_img.size(); }
     if (M >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "%lld descriptors exceed 2^23", (long long)M);
+    // (the matcher stays open for more pages: the reference's FLANN train on an empty set throws, mo/flann.rs:45-47)
+    if (M == 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
     std::vector<uint8_t> train((size_t)M * 32);
     std::vector<int32_t> tpage((size_t)M);
     std::vector<float2> xy((size_t)M);
@@ -848,7 +872,6 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     upload_area(m);
     m->M = M;
     m->finalized = true;
-    if (M == 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
     API_CATCH(m)
 }
 

@@ -59,11 +59,18 @@ def all_gather_verdicts(verdicts, n_total, rank, world, device=None):
     return np.ascontiguousarray(np.concatenate(parts)).view(verdicts.dtype).reshape(-1)
 
 
-def timeline(verdicts, times_s, frame_idx, total_time_s, total_frames):
+def timeline(verdicts, times_s, frame_idx, total_time_s, total_frames, changed=None):
     """lib.rs:185-189 + 229-244 on gathered verdicts: end-of-video sentinel, stable sort by time,
-    drop consecutive equal pages.  Returns a list of (time_s, frame_idx, page_idx or -1)."""
+    drop consecutive equal pages.  Returns a list of (time_s, frame_idx, page_idx or -1).
+
+    The reference pushes a Matching only for CHANGED frames (lib.rs:205-208): pass the gathered `changed` flags when
+    `verdicts` covers every sampled frame (an unchanged frame's record is not a verdict and would break the
+    consecutive-duplicate removal); None = the verdicts are already those of the changed frames only."""
     rows = [(float(total_time_s), int(total_frames), -1)]
-    rows += [(float(t), int(i), int(p)) for t, i, p in zip(times_s, frame_idx, verdicts["page_idx"])]
+    keep = np.ones(len(verdicts), bool) if changed is None else np.asarray(changed, bool)
+    if len(keep) != len(verdicts):
+        raise ValueError("`changed` must have one flag per verdict")
+    rows += [(float(t), int(i), int(p)) for t, i, p, k in zip(times_s, frame_idx, verdicts["page_idx"], keep) if k]
     rows.sort(key=lambda r: r[0])
     out, last = [], None
     for r in rows:

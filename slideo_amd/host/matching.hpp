@@ -238,7 +238,7 @@ public:
             meta.clear(); frames.clear();
         };
         for (uint64_t idx = 0; idx < video.n_frames; ++idx) {                                      // VideoCaptureIter, video_capture.rs:42-57
-            if (!(step <= 0 || std::fmod((double)idx, step) < 1.0)) continue;
+            if (step <= 0 || !(std::fmod((double)idx, step) < 1.0)) continue;   // step 0 (fps < 0.2): `idx % 0.0` is NaN in the reference, nothing is retrieved (video_capture.rs:53)
             frames.resize(frames.size() + fb);
             video.read(idx, frames.data() + frames.size() - fb);
             meta.push_back({(double)idx / video.fps, (size_t)idx});

@@ -92,8 +92,10 @@ def sampled_frames(video, interval_s=5.0):
     """VideoCaptureIter (video_capture.rs:42-57): grab every frame, retrieve when
     frame_idx % floor(fps * interval) < 1; yields (frame, time_s, frame_idx)."""
     step = float(np.floor(video.fps * interval_s))
+    if step <= 0:            # fps < 1 / interval: the reference's `frame_idx % 0.0` is NaN and `NaN < 1.0` is false — no frame is ever retrieved
+        return
     for idx in range(int(video.n_frames)):
-        if step <= 0 or (idx % step) < 1.0:
+        if (idx % step) < 1.0:
             yield video.read(idx), idx / video.fps, idx
 
 

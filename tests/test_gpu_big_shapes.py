@@ -1,0 +1,214 @@
+"""The BASELINE.json configurations at their real shapes, HIP path vs the CPU restatement (VERDICT r01 "next round" item 1).
+
+  headline     1080p x 256 frames in ONE unit vs a 500-page deck (M ~ 517 k train rows): the launch shape bench.py times —
+               239 kNN blocks, one train segment; both wave shapes, fused vote filter on and off; decision traces of a
+               frame sample against the oracle, properties on all 256 frames
+  configs[1]   exactly B = 256 frames vs P = 100 pages, ORB-1000: traces on a 16-frame sample, properties on all
+  configs[4]   4K frames, ORB-2000 (the reference's literals), 100 pages of 2001 x 1125: every frame's trace end to end
+  configs[3]   the app's flow (changed-frame mask -> match -> sentinel / sort / dedup) over a 1000-page deck, frames sharded
+               over TWO ranks that both run the HIP library on one GPU (gloo, 1-frame halo): timeline == one process == truth
+The oracle is test infrastructure (oracle/); it only checks here.
+"""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCPU = os.cpu_count() or 1
+
+
+def _oracle_traces(db, frames, idx):
+    with ThreadPoolExecutor(max_workers=min(len(idx), max(1, NCPU // 2))) as ex:      # ctypes calls release the GIL
+        return dict(zip(idx, ex.map(lambda i: db.match_frame_trace(frames[i]), idx)))
+
+
+def _compare_trace(gv, gc, ov, oc, tag):
+    assert gv["n_keypoints"] == ov["n_keypoints"], tag
+    assert list(gc["page_idx"]) == list(oc["page_idx"]), tag
+    assert list(gc["n_votes"]) == list(oc["n_votes"]), tag
+    assert list(gc["inliers"]) == list(oc["inliers"]), tag
+    assert list(gc["survived"]) == list(oc["survived"]), tag
+    for a, b in zip(gc, oc):
+        if b["inliers"] > 0:
+            scale = np.array([1, 1, 1e3, 1, 1, 1e3])
+            assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale), tag
+        assert abs(a["similarity"] - b["similarity"]) <= 1e-4, tag
+    assert gv["page_idx"] == ov["page_idx"] and gv["inliers"] == ov["inliers"], tag
+    assert abs(gv["similarity"] - ov["similarity"]) <= 1e-4, tag
+
+
+def _one_unit(m, d_frames, n, w, h):
+    """all n frames as ONE unit (the shape bench.py submits), traces of every frame kept"""
+    import torch
+    t = m.submit_dev(d_frames.data_ptr(), n, w, h, stream=torch.cuda.current_stream().cuda_stream)
+    v = m.collect(t)
+    return v, [m.last_candidates(i) for i in range(n)]
+
+
+def _sample(truth, k):
+    """k spread frame indices that include "no slide" frames when the batch has any"""
+    n = len(truth)
+    idx = sorted(set(int(x) for x in np.linspace(0, n - 1, k)))
+    none = [int(i) for i in np.nonzero(truth < 0)[0][:2]]
+    return sorted(set(idx + none))
+
+
+@pytest.fixture(scope="module")
+def deck500(synth):
+    return synth.pages(500, threads=min(64, NCPU))
+
+
+def test_headline_shape_traces_vs_oracle(capi, oracle, synth, deck500):
+    import torch
+    pages = deck500
+    B, fw, fh = 256, 1920, 1080
+    frames, truth, _ = synth.frames(pages, B, fw, fh, threads=min(64, NCPU))
+    db = oracle.PageDB(oracle.default_config(nfeatures=1000))
+    db.add_pages(pages, threads=NCPU)
+    assert db.finalize() == 0
+    m = capi.Matcher(capi.default_config(nfeatures=1000))
+    for i in range(0, 500, 50):
+        m.add_pages(list(pages[i:i + 50]))
+    m.finalize()
+    assert m.descriptor_count == db.descriptor_count > 450000
+    for p in (0, 137, 499):
+        gk, gd = m.page_features(p)
+        ok, od = db.page_features(p)
+        assert np.array_equal(gd, od) and np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["angle"], ok["angle"])
+    idx = _sample(truth, 10)
+    otr = _oracle_traces(db, frames, idx)
+    d_frames = torch.from_numpy(frames).cuda()
+    ref_v = ref_c = None
+    for engine in ("mfma4", "mfma2"):
+        for exact in (False, True):
+            m.set_knn_engine(engine)
+            m.set_knn_exact_lists(exact)
+            v, cands = _one_unit(m, d_frames, B, fw, fh)
+            for i in idx:
+                _compare_trace(v[i], cands[i], otr[i][0], otr[i][1], "engine %s exact_lists %s frame %d" % (engine, exact, i))
+            if ref_v is None:
+                ref_v, ref_c = v, cands
+            else:                                     # every engine / list mode: identical decisions on ALL 256 frames
+                assert np.array_equal(v, ref_v)
+                for a, b in zip(cands, ref_c):
+                    assert np.array_equal(a["page_idx"], b["page_idx"]) and np.array_equal(a["n_votes"], b["n_votes"])
+                    assert np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["similarity"], b["similarity"])
+    assert (ref_v["page_idx"] == truth).mean() >= 0.97
+    assert ((ref_v["page_idx"] == truth) | (ref_v["page_idx"] == -1)).all()       # a miss is "none", never a wrong page
+    assert 850 < ref_v["n_keypoints"].mean() < 1100
+    m.close()
+
+
+def test_configs1_exact_shape(capi, oracle, synth):
+    """BASELINE configs[1]: 1920x1080 frame batch = 256 vs 100 pages, ORB-1000."""
+    import torch
+    B, P, fw, fh = 256, 100, 1920, 1080
+    pages = synth.pages(P, threads=min(64, NCPU))
+    frames, truth, _ = synth.frames(pages, B, fw, fh, threads=min(64, NCPU))
+    db = oracle.PageDB(oracle.default_config(nfeatures=1000))
+    db.add_pages(pages, threads=NCPU)
+    assert db.finalize() == 0
+    m = capi.Matcher(capi.default_config(nfeatures=1000))
+    m.add_pages(list(pages[:50])); m.add_pages(list(pages[50:]))
+    m.finalize()
+    assert m.descriptor_count == db.descriptor_count
+    idx = _sample(truth, 16)
+    otr = _oracle_traces(db, frames, idx)
+    v, cands = _one_unit(m, torch.from_numpy(frames).cuda(), B, fw, fh)
+    for i in idx:
+        _compare_trace(v[i], cands[i], otr[i][0], otr[i][1], "frame %d" % i)
+    assert (v["page_idx"] == truth).mean() >= 0.97 and ((v["page_idx"] == truth) | (v["page_idx"] == -1)).all()
+    # the host-frame entry point cuts the batch into two units: same verdicts
+    assert np.array_equal(m.match_frames(frames), v)
+    m.close()
+
+
+def test_configs4_shape_4k_orb2000_end_to_end(capi, oracle, synth):
+    """BASELINE configs[4] shape: 3840x2160 frames, ORB-2000 = the reference's literals throughout, multi-scale pyramid,
+    RANSAC verification, verdicts; 100 pages.  Every frame's decision trace against the oracle."""
+    P, B, fw, fh = 100, 6, 3840, 2160
+    pages = synth.pages(P, threads=min(64, NCPU))
+    frames, truth, _ = synth.frames(pages, B, fw, fh, first=40, threads=min(64, NCPU))
+    db = oracle.PageDB(oracle.default_config())
+    db.add_pages(pages, threads=NCPU)
+    assert db.finalize() == 0
+    m = capi.Matcher(capi.default_config())
+    m.add_pages(list(pages[:50])); m.add_pages(list(pages[50:]))
+    m.finalize()
+    assert m.descriptor_count == db.descriptor_count > 150000
+    otr = _oracle_traces(db, frames, list(range(B)))
+    v = m.match_frames(frames)
+    for i in range(B):
+        _compare_trace(v[i], m.last_candidates(i), otr[i][0], otr[i][1], "frame %d" % i)
+    assert ((v["page_idx"] == truth) | (v["page_idx"] == -1)).all() and (v["page_idx"] == truth).sum() >= B - 2
+    assert v["n_keypoints"].min() > 1500
+    m.close()
+
+
+# ---- configs[3] shape: the lecture flow, two ranks on one GPU --------------------------------------------------------------
+
+LECT_PAGES, LECT_SAMPLES = 1000, 96          # 1000-page deck; 8 minutes of lecture sampled every 5 s
+
+
+def _lecture_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lecture_timeline as LT
+    from slideo_amd import synth, distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pages = synth.pages(LECT_PAGES, threads=min(32, NCPU // 2))
+    visits = LT.make_visits(LECT_SAMPLES, LECT_PAGES)
+    m = LT.build_matcher(pages)                                         # page DB replicated on every rank; BOTH ranks drive the HIP library
+    changed, page_of, _, _ = LT.run_shard(m, pages, visits, LECT_SAMPLES, rank, world, batch=32)
+    lo, hi = D.shard_range(LECT_SAMPLES, rank, world)
+    cap = -(-LECT_SAMPLES // world)
+    buf = torch.full((cap, 2), -3, dtype=torch.int32)
+    buf[: hi - lo, 0] = torch.from_numpy(changed.astype(np.int32)); buf[: hi - lo, 1] = torch.from_numpy(page_of)
+    out = torch.empty((world * cap, 2), dtype=torch.int32)
+    dist.all_gather_into_tensor(out, buf)                               # the one collective of the path
+    if rank == 0:
+        parts = [out[r * cap: r * cap + (D.shard_range(LECT_SAMPLES, r, world)[1] - D.shard_range(LECT_SAMPLES, r, world)[0])] for r in range(world)]
+        q.put(torch.cat(parts).numpy().tolist())
+    dist.barrier()
+    m.close()
+    dist.destroy_process_group()
+
+
+def test_configs3_shape_lecture_two_ranks_one_gpu(capi, synth):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lecture_timeline as LT
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_lecture_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    # meanwhile: the same lecture in ONE process (this one), same GPU
+    pages = synth.pages(LECT_PAGES, threads=min(32, NCPU // 2))
+    visits = LT.make_visits(LECT_SAMPLES, LECT_PAGES)
+    m = LT.build_matcher(pages)
+    assert m.page_count == LECT_PAGES and m.descriptor_count > 900000
+    changed1, page1, _, _ = LT.run_shard(m, pages, visits, LECT_SAMPLES, 0, 1, batch=32)
+    m.close()
+    got = np.array(q.get(timeout=900), np.int32)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert np.array_equal(got[:, 0].astype(bool), changed1), "changed flags: two ranks with halo vs one process"
+    assert np.array_equal(got[:, 1], page1), "per-sample verdicts: two ranks vs one process"
+    imgs = [LT.Page(i + 1) for i in range(LECT_PAGES)]
+    tl2 = LT.timeline_from_samples(got[:, 1], LECT_SAMPLES, imgs)
+    tl1 = LT.timeline_from_samples(page1, LECT_SAMPLES, imgs)
+    tt = LT.truth_timeline(visits, LECT_SAMPLES, imgs)
+    k = LT.timeline_key
+    assert list(map(k, tl2)) == list(map(k, tl1))
+    want, have = set(map(k, tt)), set(map(k, tl2))
+    assert len(want - have) <= max(1, len(want) // 20) and len(have - want) <= max(1, len(want) // 20), (sorted(want - have), sorted(have - want))
+    assert 0.02 < changed1.mean() < 0.5                                   # the mask removes most sampled frames

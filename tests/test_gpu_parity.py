@@ -427,6 +427,11 @@ def test_state_and_error_behaviour(capi, cfg0_data):
     with pytest.raises(capi.SlideoError) as e:
         m.finalize()
     assert e.value.code == 6                                          # SLIDEO_ERR_EMPTY_INDEX
+    # the matcher is not stuck after an empty finalize: more pages can be added and finalize succeeds
+    m.add_pages(list(pages))
+    m.finalize()
+    assert m.page_count == 5 and m.descriptor_count > 0
+    assert m.match_frames(frames[:2])["page_idx"].tolist() == [p + 1 if p >= 0 else -1 for p in cfg0_data[2][:2].tolist()]
     m.close()
     m = capi.Matcher(small_cfg(capi))
     with pytest.raises(capi.SlideoError) as e:
