@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
-    ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu"], help="kNN engine (identical results)")
+    ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu", "tile4", "tile2"], help="kNN engine (identical results)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
     ap.add_argument("--inflight", type=int, default=0, help="batches in flight (default and maximum: the library's slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

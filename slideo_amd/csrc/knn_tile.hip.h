@@ -1,0 +1,384 @@
+// knn_tile.hip.h — exact Hamming k-NN on the CDNA4 matrix cores, {0,1} x {0,1} FP4 operands.
+//
+// Same contract as knn.hip.h (keys = distance << 23 | train_row, the k smallest, ties to the lower row) and the same
+// skeleton as the first matrix-core engine (LDS ring filled by LDS-DMA and guarded by per-slot counters, several 32-query
+// B tiles per wave held in registers, skewed accumulator groups, pushed candidates + batched flushes into lists that live in
+// the output buffer, vote-acceptance bound fused into the threshold), ONE template over the wave shape:
+//   NT = 4 query tiles per wave, 2 waves per SIMD, 1024-query blocks, one per CU  (leaves half of every SIMD's registers
+//          and the rest of the LDS to the kernels of the other units in flight; the shape for full batches)
+//   NT = 2 query tiles per wave, 4 waves per SIMD, 512-query blocks, two per CU    (fills the chip from fewer queries)
+//
+// What changed against that engine is the operand alphabet.  There every descriptor bit b was 1 - 2b in {+1, -1} and
+// <q', t'> = 256 - 2 Hamming.  The chip clocks to its power budget, and what the FP4 multiplier array burns depends on the
+// VALUES it is fed: with 16 v_mfma_scale_f32_32x32x64_f8f6f4 + 32 VALU per wave-iteration (tools/mfma_operand_power.hip,
+// profiles/r02_mfma_operand_power.txt) the chip sustains 7.3 PFLOP/s on +-1 x +-1 operands, 7.3 on {0,1} x +-1, 8.4 on
+// {0,1} x {0,1} (three of four products are zero) and 8.75 on all-zero operands.  So both operands are the raw bits,
+// b -> b in {0, 1} (FP4 e2m1: 0x0 / 0x2), the contraction is dot = popcount(q & t), and
+//       Hamming(q, t) = |q| + |t| - 2 dot.
+// |q| is a per-lane constant.  |t| varies per row, which would cost one VALU per accumulator register in the fast path —
+// so the train rows are laid out in ascending |t| order (a stable counting sort when the set is prepared; keys carry the
+// caller's row through a permutation staged next to the tile), and a tile of 32 rows has (nearly) one norm: with
+// B = the largest distance a query still accepts, a row qualifies iff d <= B  <=>  dot - |t|/2 > h,  h = (|q| - B - 1) / 2,
+// and for a whole tile  max(dot) > h + nmin/2  is necessary (nmin = the tile's smallest norm, a scalar) — one v_add per
+// query tile and train tile, then the same v_max3 ladder on the raw bit patterns as before (dot >= 0, so the integer
+// order of the patterns is the float order, and a negative threshold compares below everything, which is what it means).
+// The exact per-row test, the norms and the original row numbers are touched in the slow path only (LDS, staged with
+// the tile).  Because norm order is not row order a later row can have a LOWER original index than a list's k-th entry:
+// the acceptance test is non-strict (d <= k-th distance) and the sorted insert decides.
+#pragma once
+#include <limits.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "knn.hip.h"
+
+namespace slideo {
+
+typedef int knn_v8i __attribute__((ext_vector_type(8)));
+typedef float knn_v16f __attribute__((ext_vector_type(16)));
+
+constexpr int KT_WAVES = 8;                    // waves per block
+constexpr int KT_THREADS = KT_WAVES * 64;
+constexpr int KT_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
+constexpr int KT_RING = 4;                     // LDS ring slots (super-tiles resident per block)
+constexpr int KT_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
+constexpr int KT_MFMA_PRIO = 1;                // wave priority while its MFMAs are issued (0 elsewhere)
+constexpr int KT_ST_U4 = KT_ST_ROWS * 128 / 16;  // uint4 per super-tile of operand (1024)
+constexpr int KT_SIDE_U32 = 2 * KT_ST_ROWS;    // per super-tile: 128 f32 norms, then 128 i32 original rows
+constexpr int KT_FLUSH_AT = 16;
+constexpr int KT_FLUSH_BATCH = 4;
+constexpr int KT_TPS = KT_ST_ROWS / 32;        // tiles per super-tile
+constexpr int KT_PEND_CAP = 80;                // >= KT_FLUSH_AT - 1 + KT_TPS * 16 (flush test once per super-tile; a lane pushes <= 16 keys per tile and query)
+constexpr float KT_PAD_NORM = 1024.f;          // norm of the pad rows: no distance bound (<= 512) admits them
+
+template <int NT> constexpr int knn_qpb() { return KT_WAVES * 32 * NT; }                         // queries per block
+template <int NT> constexpr size_t knn_pend_words_per_wave() { return (size_t)NT * KT_PEND_CAP * 64; }
+
+// 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if set, 0x0 (0.0) if clear; bit i -> nibble i.
+__host__ __device__ __forceinline__ uint32_t fp4_bits8(uint32_t byte) {
+    uint32_t y = byte & 0xFFu;
+    y = (y | (y << 12)) & 0x000F000Fu;
+    y = (y | (y << 6)) & 0x03030303u;
+    y = (y | (y << 3)) & 0x11111111u;
+    return y << 1;
+}
+
+// train [nt][8] u32 (packed) -> FP4 {0,1}, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]: MFMA k-step s of a wave
+// needs chunk 2s + (lane >> 5) of row (lane & 31) == byte s*1024 + lane*16 of the tile, one linear KB per k-step), IN NORM
+// ORDER: sorted row i is the caller's row perm[i]; padded with all-zero rows to a multiple of KT_ST_ROWS.  One thread per
+// (sorted row, chunk).
+__global__ __launch_bounds__(256) void knn_tile_expand_kernel(const uint32_t* __restrict__ t, int nt, int nt_pad,
+                                                               const int32_t* __restrict__ perm, uint4* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt_pad * 8) return;
+    const int row = i >> 3, c = i & 7;
+    const uint32_t w = row < nt ? t[(size_t)perm[row] * 8 + c] : 0u;
+    out[(size_t)(row >> 5) * 256 + c * 32 + (row & 31)] = make_uint4(fp4_bits8(w), fp4_bits8(w >> 8), fp4_bits8(w >> 16), fp4_bits8(w >> 24));
+}
+
+// q: [nq][8] u32 packed; tx: expanded train; side: [n_st][KT_SIDE_U32] (f32 norms | original rows, pad rows KT_PAD_NORM / -1);
+// nminh: [n_st] float4 = half the smallest norm of each of the super-tile's 4 tiles.
+// prune_tol: 0 = exact k-NN lists; > 0 = lists are exact only for the neighbours with d < best * prune_tol (the vote's rule).
+// Grid (ceil(nq / knn_qpb<NT>()), nseg), block 512.  Segment s covers super-tiles [s * st_per_seg, ...).  out: [seg][nq][32] keys.
+template <int NT>
+__global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(const uint32_t* __restrict__ q, int nq,
+                                                                               const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
+                                                                               const float4* __restrict__ nminh, int nt_pad, int st_per_seg,
+                                                                               uint32_t* __restrict__ out, uint32_t* __restrict__ pend_ws,
+                                                                               float prune_tol) {
+    static_assert(NT == 2 || NT == 4, "two accumulator groups of NT / 2");
+    constexpr int G = NT / 2;                                          // accumulators per skew group
+    __shared__ uint4 lds[KT_RING][KT_ST_U4];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_side[KT_RING][KT_SIDE_U32];
+    __shared__ uint32_t s_filled[KT_RING], s_done[KT_RING];           // waves that wrote / finished reading each slot (monotonic)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, ql = lane & 31;
+    const int qbase = blockIdx.x * knn_qpb<NT>() + wave * 32 * NT;
+    const int seg = blockIdx.y;
+    const int n_st = nt_pad / KT_ST_ROWS;
+    const int st0 = seg * st_per_seg, st1 = min(n_st, st0 + st_per_seg);
+    const int nst = st1 - st0;
+    uint32_t* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KT_WAVES + wave) * knn_pend_words_per_wave<NT>();
+    auto pend = [&](int i) -> uint32_t* { return P0 + (size_t)i * KT_PEND_CAP * 64; };
+
+    // B operands: lane l holds, of query (l & 31) of each tile, the 32 bits of packed dword 2s + (l >> 5) for k-step s
+    knn_v8i bq[NT][4];
+    float nqf[NT];                                                     // |q| of this lane's query of each tile
+    auto load_queries = [&]() {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const uint32_t* qp = q + (size_t)min(qbase + 32 * i + ql, nq - 1) * 8;
+            int pc = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t w = qp[2 * s + half];
+                pc += __popc(w);
+                bq[i][s] = knn_v8i{(int)fp4_bits8(w), (int)fp4_bits8(w >> 8), (int)fp4_bits8(w >> 16), (int)fp4_bits8(w >> 24), 0, 0, 0, 0};
+            }
+            nqf[i] = (float)(pc + __shfl_xor(pc, 32));
+        }
+    };
+    load_queries();
+    // list p of this lane: wave-local query 64 p + lane, i.e. tile 2 p + half, column ql
+    auto list_of = [&](int p) -> uint4* { return reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qbase + 64 * p + lane, nq - 1)) * 32); };
+#pragma unroll
+    for (int p = 0; p < G; ++p)
+        if (qbase + 64 * p + lane < nq) {
+            uint4* l = list_of(p);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
+        }
+    // h = (|q| - B - 1) / 2 with B = the largest distance the query still accepts (512 = anything); a row qualifies iff
+    // dot - |t| / 2 > h
+    float h[NT]; uint32_t cnt[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { h[i] = (nqf[i] - 513.f) * 0.5f; cnt[i] = 0; }
+
+    // owners drain the pending buffers of their two source lanes into their sorted lists (which live in `out`)
+    auto flush = [&]() {
+#pragma unroll
+        for (int p = 0; p < G; ++p) {
+            const int A = 2 * p, B = 2 * p + 1;
+            const uint32_t cA_lo = __shfl(cnt[A], ql), cA_hi = __shfl(cnt[A], ql + 32);
+            const uint32_t cB_lo = __shfl(cnt[B], ql), cB_hi = __shfl(cnt[B], ql + 32);
+            const uint32_t c_lo = half ? cB_lo : cA_lo, c_hi = half ? cB_hi : cA_hi;
+            const uint32_t* PP = (half ? pend(B) : pend(A)) + ql;
+            uint4* my_list = list_of(p);
+            const bool owner_valid = qbase + 64 * p + lane < nq;
+            uint32_t lst[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = my_list[i];
+                lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w;
+            }
+            // pending keys are fetched KT_FLUSH_BATCH at a time (their L2 latency is paid once per batch); a slot past a
+            // lane's count reads as KNN_EMPTY, whose insertion is a no-op
+            for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KT_FLUSH_BATCH) {
+                uint32_t e[KT_FLUSH_BATCH];
+#pragma unroll
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNN_EMPTY;
+#pragma unroll
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+            }
+            for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KT_FLUSH_BATCH) {
+                uint32_t e[KT_FLUSH_BATCH];
+#pragma unroll
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNN_EMPTY;
+#pragma unroll
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+            }
+            if (owner_valid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
+            }
+            // new bound of the query this lane OWNS: the k-th distance (inclusive: see the header), and with prune_tol the
+            // vote's acceptance bound — a neighbour counts iff (float)d < (float)best * tol (f32, strict), best only
+            // decreases, so d <= ceil(best * tol) - 1 is necessary for ever counting
+            float bnd = lst[31] == KNN_EMPTY ? 512.f : (float)(lst[31] >> KNN_KEY_SHIFT);
+            if (prune_tol > 0.f) bnd = fminf(bnd, ceilf((float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol) - 1.f);     // (empty list: 511 * tol, no bound)
+            cnt[A] = 0; cnt[B] = 0;
+            h[A] = (nqf[A] - __shfl(bnd, ql) - 1.f) * 0.5f;
+            h[B] = (nqf[B] - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
+        }
+    };
+
+    // ---- LDS ring (no block barrier in the main loop) --------------------------------------------------------------
+    //   s_filled[slot] += 1 by each wave once its share of a super-tile has landed (consume when == 8 * use#)
+    //   s_done[slot]   += 1 by each wave once it has finished reading the slot     (overwrite when == 8 * use#)
+    // this wave's share of a super-tile: 2 KB of operand (two 1-KiB LDS-DMA instructions) and, waves 0..3, 256 B of the
+    // side array; lane i of a DMA instruction lands at the wave-uniform LDS base + (its width) * i
+    auto stage = [&](int jj, int sl) {
+        constexpr int PER_WAVE = KT_ST_U4 / KT_WAVES;                  // uint4 per wave and super-tile
+        static_assert(PER_WAVE % 64 == 0, "whole wave-instructions");
+        const uint4* src = tx + (size_t)(st0 + jj) * KT_ST_U4 + wave * PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE / 64; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
+                                             (__attribute__((address_space(3))) void*)&lds[sl][wave * PER_WAVE + 64 * i], 16, 0, 0);
+        if (wave < KT_SIDE_U32 / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(side + (size_t)(st0 + jj) * KT_SIDE_U32 + wave * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)&lds_side[sl][wave * 64], 4, 0, 0);
+    };
+    auto signal = [&](uint32_t* f) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_ge = [&](uint32_t* f, uint32_t target) {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    if (tid < KT_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
+    __syncthreads();
+    for (int j = 0; j < KT_AHEAD && j < nst; ++j) stage(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < KT_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    auto acquire = [&](int j) {                                        // group A is about to read super-tile j
+        const int jp = j - 1 + KT_AHEAD, jn = j + KT_AHEAD;
+        if (j > 0 && jp < nst) {                                       // publish this wave's share staged at acquire(j - 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            signal(&s_filled[jp % KT_RING]);
+        }
+        if (jn < nst) {                                                // the slot was last read for super-tile jn - KT_RING
+            wait_ge(&s_done[jn % KT_RING], (uint32_t)KT_WAVES * (uint32_t)(jn / KT_RING));
+            stage(jn, jn % KT_RING);
+        }
+        wait_ge(&s_filled[j % KT_RING], (uint32_t)KT_WAVES * (uint32_t)(j / KT_RING + 1));
+    };
+    auto mfma = [&](knn_v16f acc, const uint4& f, const knn_v8i& b) {
+        const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    };
+    // maxima of the raw bit patterns: triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
+    auto tree = [&](const knn_v16f& acc, int* tk) -> int {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            tk[k] = max(max(__float_as_int(acc[3 * k]), __float_as_int(acc[3 * k + 1])), __float_as_int(acc[3 * k + 2]));
+        return max(max(max(__float_as_int(acc[15]), tk[0]), tk[1]), max(max(tk[2], tk[3]), tk[4]));
+    };
+    // Slow path (about one tile in twenty): exact per-row test with the rows' own norms; usually ONE value of ONE lane
+    // qualifies, so every test is a wave-uniform "nobody" branch that falls through.  Register r of a lane is row
+    // (r & 3) + 8 (r >> 2) + 4 half of the tile.
+    auto candidates = [&](const knn_v16f& acc, const int* tk, int thri, const uint32_t* sd, int tt, float& hh, float nq_i, uint32_t* P, uint32_t& c) {
+        float dbest = 1024.f;
+        // the norms of this lane's 16 rows: four aligned 16-byte LDS reads in flight at once (row by row, every test waited
+        // for its own LDS round trip)
+        // (NT = 2 has no registers to spare at 4 waves per SIMD and reads them one by one)
+        constexpr bool BATCH_NORMS = NT == 4;
+        float nrm16[BATCH_NORMS ? 16 : 1];
+        if constexpr (BATCH_NORMS) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 n4 = *reinterpret_cast<const uint4*>(sd + tt * 32 + 8 * g + 4 * half);
+                nrm16[4 * g] = __uint_as_float(n4.x); nrm16[4 * g + 1] = __uint_as_float(n4.y);
+                nrm16[4 * g + 2] = __uint_as_float(n4.z); nrm16[4 * g + 3] = __uint_as_float(n4.w);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool gate = k < 5 ? tk[k < 5 ? k : 0] > thri : __float_as_int(acc[15]) > thri;
+            if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
+#pragma unroll
+            for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
+                const int ro = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;           // row within the super-tile
+                const float nrm = BATCH_NORMS ? nrm16[BATCH_NORMS ? r : 0] : __uint_as_float(sd[ro]);
+                const float v = acc[r];
+                const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;                  // exact: halves of small integers
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
+                    if (hit) {
+                        const float d = nq_i + nrm - 2.f * v;
+                        P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | sd[KT_ST_ROWS + ro];
+                        ++c;
+                        dbest = fminf(dbest, d);
+                    }
+                }
+            }
+        }
+        if (prune_tol > 0.f) {
+            // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
+            // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
+            // valid, and so is the one its partner lane (the other 16 rows of the same query) derived.
+            float bn = ceilf(dbest * prune_tol) - 1.f;
+            bn = fminf(bn, __shfl_xor(bn, 32));
+            hh = fmaxf(hh, (nq_i - bn - 1.f) * 0.5f);
+        }
+    };
+
+    if (nst > 0) {
+        const knn_v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        knn_v16f a[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) a[i] = zero;
+        // G accumulator chains through the four k-steps of one A tile
+#define KT_MFMAS(GB, f0, f1, f2, f3)                                                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) a[GB + g_] = mfma(zero, f0, bq[GB + g_][0]);                 \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) a[GB + g_] = mfma(a[GB + g_], f1, bq[GB + g_][1]);           \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) a[GB + g_] = mfma(a[GB + g_], f2, bq[GB + g_][2]);           \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) a[GB + g_] = mfma(a[GB + g_], f3, bq[GB + g_][3]);
+        // one MFMA, then two instructions of the other group's max trees, 4 G times over
+#define KT_INTERLEAVE                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4 * G; ++i_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+        // trees + thresholds of group GB for the tile whose half norm is nmh_; then the tests
+#define KT_TREES(GB, nmh_)                                                                                             \
+        int tk_[G][5], mx_[G], ti_[G];                                                                                \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) { mx_[g_] = tree(a[GB + g_], tk_[g_]); ti_[g_] = __float_as_int(h[GB + g_] + (nmh_)); }
+#define KT_TEST(GB, sd_, tt_)                                                                                          \
+        {                                                                                                             \
+            bool any_ = false;                                                                                        \
+            _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) any_ |= mx_[g_] > ti_[g_];                               \
+            if (__builtin_amdgcn_ballot_w64(any_) != 0ull) {                                                          \
+                _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_)                                                      \
+                    if (__builtin_amdgcn_ballot_w64(mx_[g_] > ti_[g_]) != 0ull)                                       \
+                        candidates(a[GB + g_], tk_[g_], ti_[g_], sd_, tt_, h[GB + g_], nqf[GB + g_], pend(GB + g_), cnt[GB + g_]); \
+            }                                                                                                         \
+        }
+        // One tile (tt = its index in the super-tile, compile time): (c*) = F(t) are live on entry, (n*) = F(t + 1) on exit;
+        // group A (accumulators 0 .. G-1) already holds tile t.  Lc / Ln: this lane's fragment pointers into the slot of the
+        // current / the next tile's super-tile; sdc: side array of the current slot.
+#define KT_TILE(tt, c0, c1, c2, c3, n0, n1, n2, n3)                                                                    \
+        {                                                                                                             \
+            const uint4* Lx_ = (tt) == KT_TPS - 1 ? Ln : Lc + ((tt) + 1) * 256;                                       \
+            n0 = Lx_[0]; n1 = Lx_[64];                                                                                \
+            const float nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                     \
+            {                                                                                                         \
+                __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);                                                             \
+                KT_MFMAS(G, c0, c1, c2, c3)                                                                            \
+                KT_TREES(0, nmh_)                                                                                     \
+                KT_INTERLEAVE                                                                                         \
+                _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) asm volatile("" : "+v"(a[G + g_]));   /* keeps the MFMAs above the branch below */ \
+                __builtin_amdgcn_s_setprio(0);                                                                        \
+                n2 = Lx_[128]; n3 = Lx_[192];                                                                         \
+                KT_TEST(0, sdc, tt)                                                                                   \
+            }                                                                                                         \
+            {                                                                                                         \
+                __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);                                                             \
+                KT_MFMAS(0, n0, n1, n2, n3)                                                                            \
+                KT_TREES(G, nmh_)                                                                                     \
+                KT_INTERLEAVE                                                                                         \
+                _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) asm volatile("" : "+v"(a[g_]));                      \
+                __builtin_amdgcn_s_setprio(0);                                                                        \
+                KT_TEST(G, sdc, tt)                                                                                   \
+            }                                                                                                         \
+        }
+        acquire(0);
+        const uint4* Lc = lds[0] + lane;
+        uint4 x0 = Lc[0], x1 = Lc[64], x2 = Lc[128], x3 = Lc[192];                                 // F(t)
+        uint4 y0, y1, y2, y3;                                                                      // F(t + 1)
+        KT_MFMAS(0, x0, x1, x2, x3)
+#pragma unroll 1
+        for (int j = 0; j < nst; ++j) {
+            const int slot = j % KT_RING;
+            Lc = lds[slot] + lane;
+            const uint32_t* sdc = lds_side[slot];
+            const float4 nm4 = nminh[st0 + j];                         // (wave-uniform address: scalar loads)
+            // the tile after the segment's last is the last one again: recomputed into group A, never tested
+            const uint4* Ln = j + 1 < nst ? lds[(j + 1) % KT_RING] + lane : Lc + (KT_TPS - 1) * 256;
+            KT_TILE(0, x0, x1, x2, x3, y0, y1, y2, y3)
+            KT_TILE(1, y0, y1, y2, y3, x0, x1, x2, x3)
+            KT_TILE(2, x0, x1, x2, x3, y0, y1, y2, y3)
+            if (j + 1 < nst) acquire(j + 1);                           // group A enters the next super-tile in tile 3
+            KT_TILE(3, y0, y1, y2, y3, x0, x1, x2, x3)
+            signal(&s_done[slot]);
+            bool need = false;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) need |= cnt[i] >= (uint32_t)KT_FLUSH_AT;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                flush();
+                // everything the loop carries is rebuilt after the (rare) flush instead of kept alive across it: the flush
+                // needs 32 registers for the list, and values live across it would be spilled on every path
+                load_queries();
+                x0 = Ln[0]; x1 = Ln[64]; x2 = Ln[128]; x3 = Ln[192];
+                KT_MFMAS(0, x0, x1, x2, x3)
+            }
+        }
+#undef KT_TILE
+#undef KT_TEST
+#undef KT_TREES
+#undef KT_INTERLEAVE
+#undef KT_MFMAS
+    }
+    flush();
+}
+
+}  // namespace slideo

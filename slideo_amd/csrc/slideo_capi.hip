@@ -17,6 +17,7 @@
 #include "geom.h"
 #include "knn.hip.h"
 #include "knn_mfma.hip.h"
+#include "knn_tile.hip.h"
 #include "knn_l2.hip.h"
 #include "orb.hip.h"
 #include "slideo_amd.h"
@@ -110,6 +111,7 @@ struct slideo_matcher {
     bool finalized = false;
     int64_t M = -1;
     DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
+    DevBuf d_trainb, d_train_side, d_train_nminh, d_train_perm;   // {0,1} FP4 operand in norm order + its side arrays (knn_tile.hip.h)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_mfma4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_mfma_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
@@ -343,6 +345,42 @@ void expand_train(const uint32_t* t_dev, int nt, DevBuf& out, hipStream_t st) {
     check_launch("knn_expand_train_kernel");
 }
 
+// Operand of the {0,1} x {0,1} engine (knn_tile.hip.h): rows in ascending popcount order (stable counting sort on the host:
+// nt x 32 bytes of popcounts), expanded to tile-major FP4 on the device, plus per super-tile the rows' norms and original
+// indices and per tile half its smallest norm.  `t_host`: the packed rows in host memory.
+struct TrainBits { DevBuf *tx, *side, *nminh, *perm; };
+void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, TrainBits o, hipStream_t st) {
+    const int nt_pad = knn_pad_rows(nt), n_st = nt_pad / KT_ST_ROWS;
+    std::vector<uint16_t> norm((size_t)std::max(nt, 1));
+    uint32_t hist[258] = {0};
+    for (int i = 0; i < nt; ++i) {
+        uint64_t w[4];
+        std::memcpy(w, t_host + (size_t)i * 32, 32);
+        const int n = __builtin_popcountll(w[0]) + __builtin_popcountll(w[1]) + __builtin_popcountll(w[2]) + __builtin_popcountll(w[3]);
+        norm[i] = (uint16_t)n; hist[n + 1]++;
+    }
+    for (int i = 0; i < 257; ++i) hist[i + 1] += hist[i];
+    std::vector<int32_t> perm((size_t)nt_pad, -1);
+    for (int i = 0; i < nt; ++i) perm[hist[norm[i]]++] = i;             // stable: ties keep row order
+    std::vector<uint32_t> side((size_t)n_st * KT_SIDE_U32);
+    std::vector<float> nminh((size_t)n_st * 4);
+    for (int r = 0; r < nt_pad; ++r) {
+        const float nf = r < nt ? (float)norm[perm[r]] : KT_PAD_NORM;
+        uint32_t bits; std::memcpy(&bits, &nf, 4);
+        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + (r % KT_ST_ROWS)] = bits;
+        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + KT_ST_ROWS + (r % KT_ST_ROWS)] = (uint32_t)perm[r];
+        if (r % 32 == 0) nminh[r / 32] = 0.5f * nf;                      // ascending order: a tile's first row has its smallest norm
+    }
+    o.tx->reserve((size_t)nt_pad * 128); o.side->reserve(side.size() * 4 + 16); o.nminh->reserve(nminh.size() * 4 + 16);
+    o.perm->reserve(perm.size() * 4 + 16);
+    HIP_CHECK(hipMemcpyAsync(o.perm->p, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(o.side->p, side.data(), side.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(o.nminh->p, nminh.data(), nminh.size() * 4, hipMemcpyHostToDevice, st));
+    knn_tile_expand_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(t_dev, nt, nt_pad, o.perm->as<int32_t>(), o.tx->as<uint4>());
+    check_launch("knn_tile_expand_kernel");
+    HIP_CHECK(hipStreamSynchronize(st));                                 // the host vectors die here
+}
+
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // The matrix-core engine has two wave shapes.  One block of 1024 queries per CU at 2 waves/SIMD (engine 2) keeps half of
 // every SIMD's registers and 96 KB of LDS per CU free for the other unit's ORB / verify kernels during the whole launch:
@@ -356,14 +394,14 @@ KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
     KnnPlan p{};
     nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
     p.engine = knn_engine_for(m, nq);
-    if (p.engine == 2 && nt > 0) {
+    if ((p.engine == 2 || p.engine == 4) && nt > 0) {
         // one block of 1024 queries per CU: split the train set when fewer query blocks than 3/4 of the CUs exist
         p.qblocks = cdiv(nq, K4_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
         int nseg = p.qblocks >= 192 ? 1 : std::min(std::max(256 / std::max(p.qblocks, 1), 1), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
-    } else if (p.engine == 3 && nt > 0) {
+    } else if ((p.engine == 3 || p.engine == 5) && nt > 0) {
         p.qblocks = cdiv(nq, KM_QPB);
         const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
@@ -389,18 +427,43 @@ void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt) {
     S.d_keys.reserve((size_t)p.nseg * std::max(nq, 1) * KLIST * 4);
     if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
     if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * K4_PEND_WORDS_PER_WAVE * 4);
+    if (p.engine == 4) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<4>() * 4);
+    if (p.engine == 5) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<2>() * 4);
 }
 
 // t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
 // prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (MFMA engine; the VALU
 // engine always returns full lists)
-void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const uint32_t* t_dev, const uint4* tx_dev, int nt,
-             float prune_tol) {
+struct TrainOps {             // device operands of one train set, per engine
+    const uint32_t* t;        // packed [nt][8] (VALU engine)
+    const uint4* tx;          // +-1 FP4 expansion (first matrix-core engine)
+    const uint4* txb;         // {0,1} FP4 expansion in norm order + side arrays (knn_tile.hip.h)
+    const uint32_t* side;
+    const float4* nminh;
+};
+
+void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const TrainOps& T, int nt, float prune_tol) {
     if (nq <= 0) return;
     hipStream_t st = S.st;
+    const uint32_t* t_dev = T.t;
+    const uint4* tx_dev = T.tx;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
     const KnnPlan p = knn_plan(m, nq, nt);
     knn_reserve(m, S, nq, nt);
+    if ((p.engine == 4 || p.engine == 5) && nt > 0) {
+        if (p.engine == 4)
+            knn_tile_kernel<4><<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
+        else
+            knn_tile_kernel<2><<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
+        check_launch("knn_tile_kernel");
+        if (p.nseg > 1) {
+            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
+            check_launch("knn_merge_kernel");
+        }
+        return;
+    }
     if (p.engine == 2 && nt > 0) {
         knn_mfma4_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
                                                                          S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
@@ -504,7 +567,9 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         // current best must still be kept, hence max(tol, 1)
         // (the ratio test needs the exact two nearest rows: exact lists)
         const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), (int)m->M, prune);
+        const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(),
+                         m->d_train_nminh.as<float4>()};
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, T, (int)m->M, prune);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
@@ -686,7 +751,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<slideo_matcher> mm(new slideo_matcher());
     mm->cfg = *cfg; mm->device = device;
-    if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
+    if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 5) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
@@ -735,7 +800,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
 int32_t slideo_matcher_max_in_flight(const slideo_matcher* m) { return m ? NSLOTS : 0; }
 
 int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
-    if (!m || engine < 0 || engine > 3) return SLIDEO_ERR_INVALID_ARG;
+    if (!m || engine < 0 || engine > 5) return SLIDEO_ERR_INVALID_ARG;
     m->knn_engine = engine;
     return SLIDEO_OK;
 }
@@ -863,6 +928,7 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
         expand_train(m->d_train.as<uint32_t>(), (int)M, m->d_trainx, m->stream);
+        prepare_train_bits(train.data(), m->d_train.as<uint32_t>(), (int)M, TrainBits{&m->d_trainb, &m->d_train_side, &m->d_train_nminh, &m->d_train_perm}, m->stream);
         HIP_CHECK(hipStreamSynchronize(m->stream));
     }
     if (P > 0) {
@@ -1083,9 +1149,11 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64));
     HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    DevBuf tapx;
-    if (m->knn_engine != 1 && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
-    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), nt, 0.f);
+    DevBuf tapx, tapb, tap_side, tap_nminh, tap_perm;
+    const int eng = knn_engine_for(m, nq);
+    if ((eng == 2 || eng == 3) && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
+    if ((eng == 4 || eng == 5) && nt > 0) prepare_train_bits(t, m->d_tapt.as<uint32_t>(), nt, TrainBits{&tapb, &tap_side, &tap_nminh, &tap_perm}, st);
+    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, TrainOps{m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), tapb.as<uint4>(), tap_side.as<uint32_t>(), tap_nminh.as<float4>()}, nt, 0.f);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");
