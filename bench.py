@@ -12,7 +12,7 @@ the per-frame verdict records.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the exact
-Hamming kNN: knn_mfma4_kernel / knn_mfma_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
+Hamming kNN: knn_tile4_kernel / knn_tile2_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
 library; `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
 bounded sample of the same workload on the host cores.
 """
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--pages", type=int, default=0)
-    ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu", "tile4", "tile2"], help="kNN engine (identical results)")
+    ap.add_argument("--knn", default="mfma", choices=["mfma", "mfma2", "mfma4", "valu"], help="kNN engine (identical results)")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight (for per-kernel profiling)")
     ap.add_argument("--inflight", type=int, default=0, help="batches in flight (default and maximum: the library's slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,7 +220,7 @@ def main():
                 # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
                 flops = 2.0 * 256 * pairs_per_launch
                 achieved = flops / avg_s / 1e12
-                out["roofline"] = dict({"kernel": "knn_mfma4_kernel / knn_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4; wave shape per launch)", "bound": "mfma",
+                out["roofline"] = dict({"kernel": "knn_tile4_kernel / knn_tile2_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4; wave shape per launch)", "bound": "mfma",
                                         "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512}, **common)
             else:

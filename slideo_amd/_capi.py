@@ -238,7 +238,7 @@ class Matcher:
     def set_knn_engine(self, engine):
         """'mfma' (default: FP4 matrix cores, wave shape chosen per launch), 'mfma4' / 'mfma2' (the two shapes forced:
         2 waves/SIMD x 4 query tiles, 4 waves/SIMD x 2 query tiles) or 'valu' (integer popcount); identical results."""
-        self._check(lib().slideo_matcher_set_knn_engine(self._h, {"mfma": 0, "valu": 1, "mfma4": 2, "mfma2": 3, "tile4": 4, "tile2": 5}[engine]))
+        self._check(lib().slideo_matcher_set_knn_engine(self._h, {"mfma": 0, "valu": 1, "mfma4": 2, "mfma2": 3}[engine]))
 
     def set_knn_exact_lists(self, on=True):
         """Keep full exact k-NN lists in the matcher (default: only what the 5 % vote can use); same results."""

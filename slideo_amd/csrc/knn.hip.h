@@ -108,8 +108,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_hamming_kernel(
 }
 
 // Merge nseg sorted lists per query into the first one (in place into seg 0).
+// nq_dev != null: the query count lives on the device (grid sized by capacity), `nq` is ignored
 template <int KLIST>
-__global__ __launch_bounds__(KNN_BLOCK) void knn_merge_kernel(uint32_t* __restrict__ lists, int nq, int nseg) {
+__global__ __launch_bounds__(KNN_BLOCK) void knn_merge_kernel(uint32_t* __restrict__ lists, int nq, int nseg, const uint32_t* __restrict__ nq_dev = nullptr) {
+    if (nq_dev) nq = (int)*nq_dev;
     const int qi = blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (qi >= nq) return;
     uint32_t lst[KLIST];

@@ -6,7 +6,7 @@
 // With every component centred, x' = x - 128 in [-128, 127] (one XOR 0x80 per byte),
 //     |q - t|^2 = |q'|^2 + |t'|^2 - 2 <q', t'>
 // and <q', t'> is exact in v_mfma_i32_32x32x32_i8: 4 instructions per 32 x 32 tile of pairs, like the Hamming
-// engine (knn_mfma.hip.h), whose structure this kernel shares: tile-major train operand (a 128-byte row is 8 chunks of
+// engine (knn_tile.hip.h), whose structure this kernel shares: tile-major train operand (a 128-byte row is 8 chunks of
 // 16 B, exactly the FP4 layout), 512-query blocks, two 32-query B tiles per wave, LDS ring filled by LDS-DMA and
 // guarded by per-slot counters, per-lane thresholds, pushed candidates and batched flushes.  Differences:
 //   * the score of a pair is s = 2 <q',t'> - |t'|^2 (larger is nearer; d^2 = |q'|^2 - s).  The train rows are laid out in
@@ -20,7 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "knn_mfma.hip.h"
+#include "knn_tile.hip.h"
 
 namespace slideo {
 
@@ -28,9 +28,10 @@ typedef int knl_v4i __attribute__((ext_vector_type(4)));
 typedef int knl_v16i __attribute__((ext_vector_type(16)));
 
 constexpr unsigned long long KNL_EMPTY = ~0ull;
+constexpr int KNL_QPB = KT_WAVES * 64;            // queries per block (two 32-query B tiles per wave)
 constexpr int KNL_PAD_NORM = 1 << 30;
 constexpr int KNL_THR_OPEN = -(1 << 30) + (1 << 24);
-constexpr size_t KNL_PEND_WORDS_PER_WAVE = (size_t)2 * KM_PEND_CAP * 64 * 2;      // u64 keys
+constexpr size_t KNL_PEND_WORDS_PER_WAVE = (size_t)2 * KT_PEND_CAP * 64 * 2;      // u64 keys
 
 // |t'|^2 of every train row (centred components), one thread per row
 __global__ __launch_bounds__(256) void knl_norms_kernel(const uint8_t* __restrict__ t, int nt, int32_t* __restrict__ norm) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void knl_norms_kernel(const uint8_t* __restric
 }
 
 // train [nt][128] u8 -> centred i8, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]) IN NORM ORDER: sorted row i
-// is the caller's row perm[i] (ascending |t'|^2, ties by row), padded to a multiple of KM_ST_ROWS rows;
+// is the caller's row perm[i] (ascending |t'|^2, ties by row), padded to a multiple of KT_ST_ROWS rows;
 // neg_norm[i] = -|t'|^2 (pad rows: -2^30, perm -1).  One thread per (sorted row, chunk).
 __global__ __launch_bounds__(256) void knl_expand_train_kernel(const uint8_t* __restrict__ t, int nt, int nt_pad,
                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ norm,
@@ -85,21 +86,21 @@ __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsign
 // flush spill (still exact, 26.4 ms).
 // Grid ceil(nq / 512), block 512.
 template <int KL>
-__global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq,
+__global__ __launch_bounds__(KT_THREADS, 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq,
                                                                const uint4* __restrict__ tx, const int32_t* __restrict__ tnn,
                                                                const int32_t* __restrict__ perm, int nt_pad,
                                                                unsigned long long* __restrict__ out,
                                                                unsigned long long* __restrict__ pend_ws) {
-    __shared__ uint4 lds[KM_RING][KM_ST_U4];
-    __shared__ __attribute__((aligned(16))) int32_t lds_nn[KM_RING][KM_ST_ROWS];
-    __shared__ uint32_t s_filled[KM_RING], s_done[KM_RING];
+    __shared__ uint4 lds[KT_RING][KT_ST_U4];
+    __shared__ __attribute__((aligned(16))) int32_t lds_nn[KT_RING][KT_ST_ROWS];
+    __shared__ uint32_t s_filled[KT_RING], s_done[KT_RING];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, ql = lane & 31;
-    const int qbase = blockIdx.x * KM_QPB + wave * 64;
+    const int qbase = blockIdx.x * KNL_QPB + wave * 64;
     const int qi = qbase + lane;                                    // the query whose list this lane owns
-    const int nst = nt_pad / KM_ST_ROWS;
-    unsigned long long* const PA = pend_ws + ((size_t)blockIdx.x * KM_WAVES + wave) * (KNL_PEND_WORDS_PER_WAVE / 2);
-    unsigned long long* const PB = PA + (size_t)KM_PEND_CAP * 64;
+    const int nst = nt_pad / KT_ST_ROWS;
+    unsigned long long* const PA = pend_ws + ((size_t)blockIdx.x * KT_WAVES + wave) * (KNL_PEND_WORDS_PER_WAVE / 2);
+    unsigned long long* const PB = PA + (size_t)KT_PEND_CAP * 64;
 
     // B operands: lane l holds, of query (l & 31) of each tile, the 16 components [32 s + 16 (l >> 5), +16) of k-step s
     knl_v4i bq0[4], bq1[4];
@@ -147,19 +148,19 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
             const uint4 v = my_list[i];
             lst[2 * i] = ((unsigned long long)v.y << 32) | v.x; lst[2 * i + 1] = ((unsigned long long)v.w << 32) | v.z;
         }
-        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KM_FLUSH_BATCH) {
-            unsigned long long e[KM_FLUSH_BATCH];
+        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KT_FLUSH_BATCH) {
+            unsigned long long e[KT_FLUSH_BATCH];
 #pragma unroll
-            for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNL_EMPTY;
+            for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNL_EMPTY;
 #pragma unroll
-            for (int i = 0; i < KM_FLUSH_BATCH; ++i) knl_insert<KL>(lst, e[i]);
+            for (int i = 0; i < KT_FLUSH_BATCH; ++i) knl_insert<KL>(lst, e[i]);
         }
-        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KM_FLUSH_BATCH) {
-            unsigned long long e[KM_FLUSH_BATCH];
+        for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KT_FLUSH_BATCH) {
+            unsigned long long e[KT_FLUSH_BATCH];
 #pragma unroll
-            for (int i = 0; i < KM_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNL_EMPTY;
+            for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNL_EMPTY;
 #pragma unroll
-            for (int i = 0; i < KM_FLUSH_BATCH; ++i) knl_insert<KL>(lst, e[i]);
+            for (int i = 0; i < KT_FLUSH_BATCH; ++i) knl_insert<KL>(lst, e[i]);
         }
         if (owner_valid) {
 #pragma unroll
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
     };
 
     auto stage = [&](int jj, int sl) {
-        constexpr int PER_WAVE = KM_ST_U4 / KM_WAVES;
-        const uint4* src = tx + (size_t)jj * KM_ST_U4 + wave * PER_WAVE + lane;
+        constexpr int PER_WAVE = KT_ST_U4 / KT_WAVES;
+        const uint4* src = tx + (size_t)jj * KT_ST_U4 + wave * PER_WAVE + lane;
 #pragma unroll
         for (int i = 0; i < PER_WAVE / 64; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
     };
     // the super-tile's 128 negated norms: wave 0, 16 B per lane of its first half (published with the wave's `filled` count)
     auto stage_norms = [&](int jj, int sl) {
-        if (wave == 0 && lane < KM_ST_ROWS / 4)
-            reinterpret_cast<uint4*>(lds_nn[sl])[lane] = reinterpret_cast<const uint4*>(tnn + (size_t)jj * KM_ST_ROWS)[lane];
+        if (wave == 0 && lane < KT_ST_ROWS / 4)
+            reinterpret_cast<uint4*>(lds_nn[sl])[lane] = reinterpret_cast<const uint4*>(tnn + (size_t)jj * KT_ST_ROWS)[lane];
     };
     auto signal = [&](uint32_t* f) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -194,26 +195,26 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
-    if (tid < KM_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
+    if (tid < KT_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
-    for (int j = 0; j < KM_AHEAD && j < nst; ++j) { stage(j, j); stage_norms(j, j); }
+    for (int j = 0; j < KT_AHEAD && j < nst; ++j) { stage(j, j); stage_norms(j, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int j = 0; j < KM_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    for (int j = 0; j < KT_AHEAD && j < nst; ++j) signal(&s_filled[j]);
     for (int j = 0; j < nst; ++j) {
-        const int slot = j % KM_RING;
-        const int jn = j + KM_AHEAD, ns = jn % KM_RING;
+        const int slot = j % KT_RING;
+        const int jn = j + KT_AHEAD, ns = jn % KT_RING;
         const bool more = jn < nst;
         if (more) {
-            wait_ge(&s_done[ns], (uint32_t)KM_WAVES * (uint32_t)(jn / KM_RING));
+            wait_ge(&s_done[ns], (uint32_t)KT_WAVES * (uint32_t)(jn / KT_RING));
             stage(jn, ns);
         }
-        wait_ge(&s_filled[slot], (uint32_t)KM_WAVES * (uint32_t)(j / KM_RING + 1));
+        wait_ge(&s_filled[slot], (uint32_t)KT_WAVES * (uint32_t)(j / KT_RING + 1));
         const uint4* L = lds[slot] + lane;
         uint4 f0 = L[0], f1 = L[64];
 #pragma unroll 1
-        for (int tile = 0; tile < KM_ST_ROWS / 32; ++tile) {
+        for (int tile = 0; tile < KT_ST_ROWS / 32; ++tile) {
             knl_v16i a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
-            __builtin_amdgcn_s_setprio(KM_MFMA_PRIO);
+            __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);
             {
                 const uint4 f2 = L[tile * 256 + 128], f3 = L[tile * 256 + 192];
                 const knl_v4i v0 = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w}, v1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w};
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
                 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2, bq1[2], a1, 0, 0, 0);
                 a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(v3, bq0[3], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(v3, bq1[3], a1, 0, 0, 0);
-                const uint4* Ln = L + min(tile + 1, KM_ST_ROWS / 32 - 1) * 256;
+                const uint4* Ln = L + min(tile + 1, KT_ST_ROWS / 32 - 1) * 256;
                 f0 = Ln[0]; f1 = Ln[64];
             }
             __builtin_amdgcn_s_setprio(0);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
                         ia[4 * g + k] = 2 * x + n4[k]; ib[4 * g + k] = 2 * y + n4[k];
                     }
                 }
-                const uint32_t row0 = (uint32_t)(j * KM_ST_ROWS + tile * 32 + 4 * half);
+                const uint32_t row0 = (uint32_t)(j * KT_ST_ROWS + tile * 32 + 4 * half);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const int ga = k < 5 ? max(max(ia[3 * (k < 5 ? k : 0)], ia[3 * (k < 5 ? k : 0) + 1]), ia[3 * (k < 5 ? k : 0) + 2]) : ia[15];
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(KM_THREADS, 4) void knn_l2_kernel(const uint8_t* __
                         }
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KM_FLUSH_AT || cntB >= (uint32_t)KM_FLUSH_AT) != 0ull) flush();
+                if (__builtin_amdgcn_ballot_w64(cntA >= (uint32_t)KT_FLUSH_AT || cntB >= (uint32_t)KT_FLUSH_AT) != 0ull) flush();
             }
         }
         signal(&s_done[slot]);

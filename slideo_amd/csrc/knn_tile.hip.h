@@ -17,7 +17,8 @@
 //       Hamming(q, t) = |q| + |t| - 2 dot.
 // |q| is a per-lane constant.  |t| varies per row, which would cost one VALU per accumulator register in the fast path —
 // so the train rows are laid out in ascending |t| order (a stable counting sort when the set is prepared; keys carry the
-// caller's row through a permutation staged next to the tile), and a tile of 32 rows has (nearly) one norm: with
+// caller's row through a permutation staged next to the tile; the TILES are then streamed in a fixed pseudo-random order, see
+// prepare_train_bits in slideo_capi.hip for why), and a tile of 32 rows has (nearly) one norm: with
 // B = the largest distance a query still accepts, a row qualifies iff d <= B  <=>  dot - |t|/2 > h,  h = (|q| - B - 1) / 2,
 // and for a whole tile  max(dot) > h + nmin/2  is necessary (nmin = the tile's smallest norm, a scalar) — one v_add per
 // query tile and train tile, then the same v_max3 ladder on the raw bit patterns as before (dot >= 0, so the integer
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void knn_tile_expand_kernel(const uint32_t* __
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nt_pad * 8) return;
     const int row = i >> 3, c = i & 7;
-    const uint32_t w = row < nt ? t[(size_t)perm[row] * 8 + c] : 0u;
+    const int src = perm[row];                                           // -1: pad row (all zero bits, norm KT_PAD_NORM)
+    const uint32_t w = src >= 0 ? t[(size_t)src * 8 + c] : 0u;
     out[(size_t)(row >> 5) * 256 + c * 32 + (row & 31)] = make_uint4(fp4_bits8(w), fp4_bits8(w >> 8), fp4_bits8(w >> 16), fp4_bits8(w >> 24));
 }
 
@@ -81,16 +83,20 @@ __global__ __launch_bounds__(256) void knn_tile_expand_kernel(const uint32_t* __
 // prune_tol: 0 = exact k-NN lists; > 0 = lists are exact only for the neighbours with d < best * prune_tol (the vote's rule).
 // Grid (ceil(nq / knn_qpb<NT>()), nseg), block 512.  Segment s covers super-tiles [s * st_per_seg, ...).  out: [seg][nq][32] keys.
 template <int NT>
-__global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(const uint32_t* __restrict__ q, int nq,
-                                                                               const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
-                                                                               const float4* __restrict__ nminh, int nt_pad, int st_per_seg,
-                                                                               uint32_t* __restrict__ out, uint32_t* __restrict__ pend_ws,
-                                                                               float prune_tol) {
+__device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
+                                              const uint32_t* __restrict__ side, const float4* __restrict__ nminh, int nt_pad,
+                                              int st_per_seg, uint32_t* __restrict__ out, uint32_t* __restrict__ pend_ws, float prune_tol,
+                                              const uint32_t* __restrict__ nq_dev) {
     static_assert(NT == 2 || NT == 4, "two accumulator groups of NT / 2");
+    // nq_dev != null: the grid was sized by CAPACITY and the query count lives on the device (the host did not wait for the
+    // ORB stage's counts); blocks past the last query leave at once — before any barrier, the test is block-uniform
+    if (nq_dev) nq = (int)*nq_dev;
+    if ((int)blockIdx.x * knn_qpb<NT>() >= nq) return;
     constexpr int G = NT / 2;                                          // accumulators per skew group
     __shared__ uint4 lds[KT_RING][KT_ST_U4];
     __shared__ __attribute__((aligned(16))) uint32_t lds_side[KT_RING][KT_SIDE_U32];
     __shared__ uint32_t s_filled[KT_RING], s_done[KT_RING];           // waves that wrote / finished reading each slot (monotonic)
+    __shared__ float s_nq[KT_WAVES][NT][32];                          // |q| of every query of the block (read in the slow path and the flush only)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, ql = lane & 31;
     const int qbase = blockIdx.x * knn_qpb<NT>() + wave * 32 * NT;
@@ -102,8 +108,10 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
     auto pend = [&](int i) -> uint32_t* { return P0 + (size_t)i * KT_PEND_CAP * 64; };
 
     // B operands: lane l holds, of query (l & 31) of each tile, the 32 bits of packed dword 2s + (l >> 5) for k-step s
+    // (register budget: the kernel must leave room for two waves of the other units' kernels per SIMD — at 2 waves of 224
+    // registers only one 64-register wave fits beside it and the overlapped step lost 4 %; hence |q| in LDS and the four
+    // pending counts packed into one register)
     knn_v8i bq[NT][4];
-    float nqf[NT];                                                     // |q| of this lane's query of each tile
     auto load_queries = [&]() {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -115,10 +123,12 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
                 pc += __popc(w);
                 bq[i][s] = knn_v8i{(int)fp4_bits8(w), (int)fp4_bits8(w >> 8), (int)fp4_bits8(w >> 16), (int)fp4_bits8(w >> 24), 0, 0, 0, 0};
             }
-            nqf[i] = (float)(pc + __shfl_xor(pc, 32));
+            const int tot = pc + __shfl_xor(pc, 32);                   // (all lanes: a shuffle under `if (half == 0)` would read inactive lanes)
+            if (half == 0) s_nq[wave][i][ql] = (float)tot;
         }
     };
     load_queries();
+    auto nq_of = [&](int i) -> float { return s_nq[wave][i][ql]; };     // (same wave wrote it: no barrier needed, the compiler waits for the DS write)
     // list p of this lane: wave-local query 64 p + lane, i.e. tile 2 p + half, column ql
     auto list_of = [&](int p) -> uint4* { return reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qbase + 64 * p + lane, nq - 1)) * 32); };
 #pragma unroll
@@ -130,18 +140,19 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
         }
     // h = (|q| - B - 1) / 2 with B = the largest distance the query still accepts (512 = anything); a row qualifies iff
     // dot - |t| / 2 > h
-    float h[NT]; uint32_t cnt[NT];
+    float h[NT];
+    uint32_t cntp = 0;                                                 // keys pending in this lane's private buffers, 8 bits per query tile
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { h[i] = (nqf[i] - 513.f) * 0.5f; cnt[i] = 0; }
+    for (int i = 0; i < NT; ++i) h[i] = (nq_of(i) - 513.f) * 0.5f;
+    auto cnt_of = [&](uint32_t packed, int i) -> uint32_t { return (packed >> (8 * i)) & 255u; };
 
     // owners drain the pending buffers of their two source lanes into their sorted lists (which live in `out`)
     auto flush = [&]() {
 #pragma unroll
         for (int p = 0; p < G; ++p) {
             const int A = 2 * p, B = 2 * p + 1;
-            const uint32_t cA_lo = __shfl(cnt[A], ql), cA_hi = __shfl(cnt[A], ql + 32);
-            const uint32_t cB_lo = __shfl(cnt[B], ql), cB_hi = __shfl(cnt[B], ql + 32);
-            const uint32_t c_lo = half ? cB_lo : cA_lo, c_hi = half ? cB_hi : cA_hi;
+            const uint32_t p_lo = __shfl(cntp, ql), p_hi = __shfl(cntp, ql + 32);
+            const uint32_t c_lo = cnt_of(p_lo, half ? B : A), c_hi = cnt_of(p_hi, half ? B : A);
             const uint32_t* PP = (half ? pend(B) : pend(A)) + ql;
             uint4* my_list = list_of(p);
             const bool owner_valid = qbase + 64 * p + lane < nq;
@@ -176,10 +187,10 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
             // decreases, so d <= ceil(best * tol) - 1 is necessary for ever counting
             float bnd = lst[31] == KNN_EMPTY ? 512.f : (float)(lst[31] >> KNN_KEY_SHIFT);
             if (prune_tol > 0.f) bnd = fminf(bnd, ceilf((float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol) - 1.f);     // (empty list: 511 * tol, no bound)
-            cnt[A] = 0; cnt[B] = 0;
-            h[A] = (nqf[A] - __shfl(bnd, ql) - 1.f) * 0.5f;
-            h[B] = (nqf[B] - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
+            h[A] = (nq_of(A) - __shfl(bnd, ql) - 1.f) * 0.5f;
+            h[B] = (nq_of(B) - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
         }
+        cntp = 0;
     };
 
     // ---- LDS ring (no block barrier in the main loop) --------------------------------------------------------------
@@ -230,7 +241,10 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     };
     // maxima of the raw bit patterns: triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
-    auto tree = [&](const knn_v16f& acc, int* tk) -> int {
+    // (only the overall maximum is kept: the slow path recomputes the triple maxima it gates on — ten registers per skew group
+    // that would otherwise stay live from the trees to the tests)
+    auto tree = [&](const knn_v16f& acc) -> int {
+        int tk[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             tk[k] = max(max(__float_as_int(acc[3 * k]), __float_as_int(acc[3 * k + 1])), __float_as_int(acc[3 * k + 2]));
@@ -239,29 +253,27 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
     // Slow path (about one tile in twenty): exact per-row test with the rows' own norms; usually ONE value of ONE lane
     // qualifies, so every test is a wave-uniform "nobody" branch that falls through.  Register r of a lane is row
     // (r & 3) + 8 (r >> 2) + 4 half of the tile.
-    auto candidates = [&](const knn_v16f& acc, const int* tk, int thri, const uint32_t* sd, int tt, float& hh, float nq_i, uint32_t* P, uint32_t& c) {
+    auto candidates = [&](const knn_v16f& acc, int thri, const uint32_t* sd, int tt, float& hh, int qt, uint32_t* P) {
         float dbest = 1024.f;
-        // the norms of this lane's 16 rows: four aligned 16-byte LDS reads in flight at once (row by row, every test waited
-        // for its own LDS round trip)
-        // (NT = 2 has no registers to spare at 4 waves per SIMD and reads them one by one)
-        constexpr bool BATCH_NORMS = NT == 4;
-        float nrm16[BATCH_NORMS ? 16 : 1];
-        if constexpr (BATCH_NORMS) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 n4 = *reinterpret_cast<const uint4*>(sd + tt * 32 + 8 * g + 4 * half);
-                nrm16[4 * g] = __uint_as_float(n4.x); nrm16[4 * g + 1] = __uint_as_float(n4.y);
-                nrm16[4 * g + 2] = __uint_as_float(n4.z); nrm16[4 * g + 3] = __uint_as_float(n4.w);
-            }
-        }
+        const float nq_i = nq_of(qt);
+        uint32_t c = cnt_of(cntp, qt);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const bool gate = k < 5 ? tk[k < 5 ? k : 0] > thri : __float_as_int(acc[15]) > thri;
+            const int kk = k < 5 ? k : 0;
+            const bool gate = (k < 5 ? max(max(__float_as_int(acc[3 * kk]), __float_as_int(acc[3 * kk + 1])), __float_as_int(acc[3 * kk + 2]))
+                                     : __float_as_int(acc[15])) > thri;
             if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
+            // the norms of the triple's rows: three LDS reads in flight, one wait (row by row every test paid its own round trip)
+            float nrm3[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int r = min(3 * k + u, 15);
+                nrm3[u] = __uint_as_float(sd[tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half]);
+            }
 #pragma unroll
             for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
                 const int ro = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;           // row within the super-tile
-                const float nrm = BATCH_NORMS ? nrm16[BATCH_NORMS ? r : 0] : __uint_as_float(sd[ro]);
+                const float nrm = nrm3[r - 3 * k];
                 const float v = acc[r];
                 const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;                  // exact: halves of small integers
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
                 }
             }
         }
+        cntp = (cntp & ~(255u << (8 * qt))) | (c << (8 * qt));
         if (prune_tol > 0.f) {
             // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
             // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
@@ -301,8 +314,8 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
         // trees + thresholds of group GB for the tile whose half norm is nmh_; then the tests
 #define KT_TREES(GB, nmh_)                                                                                             \
-        int tk_[G][5], mx_[G], ti_[G];                                                                                \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) { mx_[g_] = tree(a[GB + g_], tk_[g_]); ti_[g_] = __float_as_int(h[GB + g_] + (nmh_)); }
+        int mx_[G], ti_[G];                                                                                           \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) { mx_[g_] = tree(a[GB + g_]); ti_[g_] = __float_as_int(h[GB + g_] + (nmh_)); }
 #define KT_TEST(GB, sd_, tt_)                                                                                          \
         {                                                                                                             \
             bool any_ = false;                                                                                        \
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
             if (__builtin_amdgcn_ballot_w64(any_) != 0ull) {                                                          \
                 _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_)                                                      \
                     if (__builtin_amdgcn_ballot_w64(mx_[g_] > ti_[g_]) != 0ull)                                       \
-                        candidates(a[GB + g_], tk_[g_], ti_[g_], sd_, tt_, h[GB + g_], nqf[GB + g_], pend(GB + g_), cnt[GB + g_]); \
+                        candidates(a[GB + g_], ti_[g_], sd_, tt_, h[GB + g_], GB + g_, pend(GB + g_));                \
             }                                                                                                         \
         }
         // One tile (tt = its index in the super-tile, compile time): (c*) = F(t) are live on entry, (n*) = F(t + 1) on exit;
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
             signal(&s_done[slot]);
             bool need = false;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) need |= cnt[i] >= (uint32_t)KT_FLUSH_AT;
+            for (int i = 0; i < NT; ++i) need |= cnt_of(cntp, i) >= (uint32_t)KT_FLUSH_AT;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
                 flush();
                 // everything the loop carries is rebuilt after the (rare) flush instead of kept alive across it: the flush
@@ -379,6 +392,24 @@ __global__ __launch_bounds__(KT_THREADS, NT == 4 ? 2 : 4) void knn_tile_kernel(c
 #undef KT_MFMAS
     }
     flush();
+}
+
+// The two wave shapes.  KT4_VGPRS caps the 4-tile shape's register allocation: at 2 waves per SIMD the compiler would take up
+// to 256 registers, but what it leaves is what the other units' kernels (ORB, verify: 36 - 64 registers per wave) live in.
+#ifndef KT4_VGPRS
+#define KT4_VGPRS 100      /* the backend doubles the request on gfx90a+ (unified VGPR + AGPR file): 100 -> 200 registers */
+#endif
+__global__ __attribute__((amdgpu_num_vgpr(KT4_VGPRS))) __launch_bounds__(KT_THREADS, 2)
+void knn_tile4_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
+                      const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
+                      uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+    knn_tile_body<4>(q, nq, tx, side, nminh, nt_pad, st_per_seg, out, pend_ws, prune_tol, nq_dev);
+}
+__global__ __launch_bounds__(KT_THREADS, 4)
+void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
+                      const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
+                      uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+    knn_tile_body<2>(q, nq, tx, side, nminh, nt_pad, st_per_seg, out, pend_ws, prune_tol, nq_dev);
 }
 
 }  // namespace slideo

@@ -608,9 +608,12 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
 // with score >= threshold is kept (ties kept).  grid B, block 64 * nlevels.
 // counters layout per frame: see OrbCounters in slideo_capi.hip.
 // ---------------------------------------------------------------------------
+// kp_cap: keypoints per frame the downstream buffers were sized for when the host does NOT wait for the counts (the
+// unit is enqueued in one go); a frame beyond it (ties are kept, so no finite bound is safe) contributes no keypoint and
+// raises flag 8, and the host re-runs the unit through the exact-size path.
 __global__ void threshold_kernel(PyrGeom g, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ cand_count,
                                  uint32_t* __restrict__ thr, uint32_t* __restrict__ lvl_ofs,
-                                 uint32_t* __restrict__ kp_count, uint32_t* __restrict__ flags) {
+                                 uint32_t* __restrict__ kp_count, uint32_t* __restrict__ flags, uint32_t kp_cap) {
     __shared__ uint32_t kept_s[MAX_LEVELS];
     const int f = blockIdx.x;
     const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -656,6 +659,7 @@ __global__ void threshold_kernel(PyrGeom g, const uint32_t* __restrict__ hist, c
     if (threadIdx.x == 0) {
         uint32_t o = 0;
         for (int i = 0; i < g.nlevels; ++i) { lvl_ofs[(size_t)f * g.nlevels + i] = o; o += kept_s[i]; }
+        if (o > kp_cap) { atomicOr(flags, 8u); o = 0; }
         kp_count[f] = o;
         if (o > (uint32_t)KP_CAP_PER_FRAME) atomicOr(flags, 2u);
     }
@@ -792,6 +796,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
     const int wave = threadIdx.x >> 6;
     const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
+    if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
     if (gi >= qtot) return;
     // frame of this keypoint: last f with qofs[f] <= gi (wave-uniform binary search)
     int lo = 0, hi = nframes;
@@ -910,6 +915,7 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
     const int wave = threadIdx.x >> 6;
     const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
+    if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
     if (gi >= qtot) return;
     int lo = 0, hi = nframes;
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }

@@ -16,7 +16,6 @@
 #include "common.h"
 #include "geom.h"
 #include "knn.hip.h"
-#include "knn_mfma.hip.h"
 #include "knn_tile.hip.h"
 #include "knn_l2.hip.h"
 #include "orb.hip.h"
@@ -58,7 +57,9 @@ struct OrbOut {            // where the last ORB run of a slot left its results 
 struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_in = nullptr;
+    hipEvent_t ev_in = nullptr, ev_orb = nullptr;
+    // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
+    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs;
     PinBuf h_info, h_out;
@@ -110,11 +111,18 @@ struct slideo_matcher {
     std::vector<HostPage> pages;
     bool finalized = false;
     int64_t M = -1;
-    DevBuf d_train, d_trainx, d_train_page, d_page_xy, d_pageinfo, d_page_small;
+    DevBuf d_train, d_train_page, d_page_xy, d_pageinfo, d_page_small;
     DevBuf d_trainb, d_train_side, d_train_nminh, d_train_perm;   // {0,1} FP4 operand in norm order + its side arrays (knn_tile.hip.h)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
-                            // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_mfma4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_mfma_kernel)
+                            // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
+    // Units are enqueued in one go, without the mid-unit host wait for the keypoint counts: everything downstream of the ORB
+    // counts is sized by capacity and reads the counts on the device (SLIDEO_ASYNC_SUBMIT=0: the exact-size path with the wait).
+    int async_submit = 1;
+    // ORB stages of consecutive units take turns (each waits for the previous unit's ORB stage on the GPU, event to event):
+    // what the host wait used to enforce as a side effect (SLIDEO_ORB_CHAIN=0: free-running).
+    int orb_chain = 1;
+    hipEvent_t last_orb_ev = nullptr;
 
     // workspaces
     Slot slots[NSLOTS];
@@ -210,7 +218,7 @@ void require_idle(slideo_matcher* m) {
 // the f32 blur of ocv.blur 0 / 1 cannot be evaluated per BRIEF sample in integer arithmetic: those variants always
 // materialise the blurred pyramid (blur_f32_kernel) and describe from it (describe_blurred_kernel)
 void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
-                bool with_blur = false) {
+                bool with_blur = false, uint32_t kp_cap = 0xFFFFFFFFu) {
     hipStream_t st = S.st;
     with_blur = with_blur || blur_is_f32(m);
     GeomEntry& ge = geom_for(m, w, h);
@@ -266,7 +274,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         check_launch("blur kernel");
     }
     threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, S.d_thr.as<uint32_t>(), S.d_lvlofs.as<uint32_t>(),
-                                           S.d_kpcount.as<uint32_t>(), flags);
+                                           S.d_kpcount.as<uint32_t>(), flags, kp_cap);
     check_launch("threshold_kernel");
     scan_kernel<<<1, 1024, 0, st>>>(S.d_kpcount.as<uint32_t>(), n, S.d_qofs.as<uint32_t>(), S.d_info.as<uint32_t>());
     check_launch("scan_kernel");
@@ -287,11 +295,13 @@ void orb_wait_info(slideo_matcher* m, Slot& S) {
 }
 
 // stage 2: compact the kept candidates, canonical sort, IC angle + rotated BRIEF
-void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
+// by_capacity: qtot / maxc are CAPACITIES (n * kp_cap, kp_cap) and the real counts stay on the device
+void orb_stage2(slideo_matcher* m, Slot& S, int w, int h, bool by_capacity = false) {
     hipStream_t st = S.st;
     const PyrGeom& g = geom_for(m, w, h).g;
     const int L = g.nlevels, n = S.orb.nframes;
     const uint32_t qtot = S.orb.qtot, maxc = S.orb.max_count;
+    const uint32_t qtot_arg = by_capacity ? 0xFFFFFFFFu : qtot;
     S.d_items.reserve(std::max<size_t>((size_t)qtot * 8, 16));
     S.d_kp.reserve(std::max<size_t>((size_t)qtot * sizeof(slideo_keypoint), 16));
     S.d_desc.reserve(std::max<size_t>((size_t)qtot * 32, 32));
@@ -307,7 +317,7 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
     check_launch("sort_kernel");
     if (blur_is_f32(m)) {
         describe_blurred_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
-                                                                    S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot,
+                                                                    S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot_arg,
                                                                     m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
                                                                     S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(), m->cfg.ocv.atan);
         check_launch("describe_blurred_kernel");
@@ -315,7 +325,7 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h) {
     }
     const DescWin dw = describe_window(g.half_patch);
     describe_kernel<<<cdiv((int)qtot, 4), 256, (size_t)dw.dwords * 16, st>>>(g, S.d_pyr.as<uint8_t>(), m->d_tables.as<OrbTables>(),
-                                                                             S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot, dw,
+                                                                             S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot_arg, dw,
                                                                              m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
                                                                              S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(), m->cfg.ocv.atan);
     check_launch("describe_kernel");
@@ -335,15 +345,7 @@ void run_orb(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w
 }
 
 // ---- exact Hamming kNN: keys into S.d_keys[0 .. nq*KLIST) ------------------------------
-int knn_pad_rows(int nt) { return cdiv(std::max(nt, 1), KM_ST_ROWS) * KM_ST_ROWS; }
-
-// FP4 tile-major expansion of a packed train matrix (knn_mfma.hip.h)
-void expand_train(const uint32_t* t_dev, int nt, DevBuf& out, hipStream_t st) {
-    const int nt_pad = knn_pad_rows(nt);
-    out.reserve((size_t)nt_pad * 128);
-    knn_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(t_dev, nt, nt_pad, out.as<uint4>());
-    check_launch("knn_expand_train_kernel");
-}
+int knn_pad_rows(int nt) { return cdiv(std::max(nt, 1), KT_ST_ROWS) * KT_ST_ROWS; }
 
 // Operand of the {0,1} x {0,1} engine (knn_tile.hip.h): rows in ascending popcount order (stable counting sort on the host:
 // nt x 32 bytes of popcounts), expanded to tile-major FP4 on the device, plus per super-tile the rows' norms and original
@@ -362,10 +364,28 @@ void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, Tr
     for (int i = 0; i < 257; ++i) hist[i + 1] += hist[i];
     std::vector<int32_t> perm((size_t)nt_pad, -1);
     for (int i = 0; i < nt; ++i) perm[hist[norm[i]]++] = i;             // stable: ties keep row order
+    {
+        // The 32-row TILES (each of one norm, which is all the fast path needs) are then put in a fixed pseudo-random order.
+        // Streaming them in norm order is adversarial for the running thresholds: E[d] = |q| + |t| (1 - |q| / 128), so for every
+        // query with more than 128 set bits the nearest rows would come LAST, the k-th distance would keep falling along the
+        // stream and almost every tile would send some lane to the slow path (measured: 17.3 ms against 11.9 ms for the
+        // +-1 engine on the headline launch).  A shuffled tile order makes the stream i.i.d. again for every query.
+        const int ntiles = cdiv(nt, 32);
+        std::vector<int32_t> order((size_t)ntiles), shuffled((size_t)nt_pad, -1);
+        for (int i = 0; i < ntiles; ++i) order[i] = i;
+        uint64_t st_ = 0x9E3779B97F4A7C15ull;
+        for (int i = ntiles - 1; i > 0; --i) {
+            st_ = st_ * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(order[i], order[(int)((st_ >> 33) % (uint64_t)(i + 1))]);
+        }
+        for (int p = 0; p < ntiles; ++p)
+            for (int r = 0; r < 32; ++r) shuffled[(size_t)p * 32 + r] = perm[(size_t)order[p] * 32 + r];   // (perm is -1 past nt: pad rows)
+        perm.swap(shuffled);
+    }
     std::vector<uint32_t> side((size_t)n_st * KT_SIDE_U32);
     std::vector<float> nminh((size_t)n_st * 4);
     for (int r = 0; r < nt_pad; ++r) {
-        const float nf = r < nt ? (float)norm[perm[r]] : KT_PAD_NORM;
+        const float nf = perm[r] >= 0 ? (float)norm[perm[r]] : KT_PAD_NORM;     // (pad rows may now sit inside the stream: the partial last tile)
         uint32_t bits; std::memcpy(&bits, &nf, 4);
         side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + (r % KT_ST_ROWS)] = bits;
         side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + KT_ST_ROWS + (r % KT_ST_ROWS)] = (uint32_t)perm[r];
@@ -382,123 +402,95 @@ void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, Tr
 }
 
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
-// The matrix-core engine has two wave shapes.  One block of 1024 queries per CU at 2 waves/SIMD (engine 2) keeps half of
-// every SIMD's registers and 96 KB of LDS per CU free for the other unit's ORB / verify kernels during the whole launch:
-// +8 % on the headline step (239 query blocks).  It needs enough queries to put a block on most CUs without splitting the
-// train set; below that (64 4K frames = 125 blocks: -6 %) the 512-query blocks of engine 3 fill the chip better.
+// The matrix-core engine has two wave shapes (knn_tile.hip.h).  One block of 1024 queries per CU at 2 waves/SIMD (engine 2)
+// keeps more than half of every SIMD's registers and 88 KB of LDS per CU free for the other units' ORB / verify kernels
+// during the whole launch.  It needs enough queries to put a block on most CUs without splitting the train set; below that
+// (64 4K frames = 125 blocks) the 512-query blocks of engine 3 fill the chip better.
 int knn_engine_for(const slideo_matcher* m, int nq) {
     if (m->knn_engine != 0) return m->knn_engine;
-    return cdiv(std::max(nq, 1), K4_QPB) >= 192 ? 2 : 3;
+    return cdiv(std::max(nq, 1), knn_qpb<4>()) >= 192 ? 2 : 3;
 }
-KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt) {
+// nq: the query count the plan is made for (the real one, or its estimate when only the device knows it); nq_grid >= nq:
+// what the grid and the buffers are sized for (blocks past the device-side count leave at once)
+KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0) {
     KnnPlan p{};
     nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
+    nq_grid = std::max(nq_grid, nq);
     p.engine = knn_engine_for(m, nq);
-    if ((p.engine == 2 || p.engine == 4) && nt > 0) {
+    if (p.engine == 2 && nt > 0) {
         // one block of 1024 queries per CU: split the train set when fewer query blocks than 3/4 of the CUs exist
-        p.qblocks = cdiv(nq, K4_QPB);
-        const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
+        p.qblocks = cdiv(nq, knn_qpb<4>());
+        const int n_st = knn_pad_rows(nt) / KT_ST_ROWS;
         int nseg = p.qblocks >= 192 ? 1 : std::min(std::max(256 / std::max(p.qblocks, 1), 1), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
-    } else if ((p.engine == 3 || p.engine == 5) && nt > 0) {
-        p.qblocks = cdiv(nq, KM_QPB);
-        const int n_st = knn_pad_rows(nt) / KM_ST_ROWS;
+        p.qblocks = cdiv(nq_grid, knn_qpb<4>());
+    } else if (p.engine == 3 && nt > 0) {
+        p.qblocks = cdiv(nq, knn_qpb<2>());
+        const int n_st = knn_pad_rows(nt) / KT_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
         // segment pays its own list warm-up and the merge); fewer query blocks split the train set so that the blocks
         // fill the chip in ONE round (floor, not ceil: 1.4 rounds of smaller blocks lose more to the tail than the
-        // empty slots do).  Measured: 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
+        // empty slots do).  Measured (r01): 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
         // 3 segments 23.5 ms; 239 query blocks x 517 k rows (128 1080p frames): 2 segments 6.24 ms, 3 segments 6.65 ms
         int nseg = p.qblocks >= 384 ? 1 : std::min(std::max(512 / std::max(p.qblocks, 1), 1), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
+        p.qblocks = cdiv(nq_grid, knn_qpb<2>());
     } else {
+        p.engine = 1;
         p.qblocks = cdiv(nq, KNN_BLOCK);
         int nseg = 1;
         if (p.qblocks < 1024) nseg = std::min(cdiv(1024, p.qblocks), std::max(1, nt / 4096));
         p.nseg = std::max(1, std::min(nseg, 256));
         p.per_seg = cdiv(std::max(nt, 1), p.nseg);
+        p.qblocks = cdiv(nq_grid, KNN_BLOCK);
     }
     return p;
 }
 
-void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt) {
-    const KnnPlan p = knn_plan(m, nq, nt);
-    S.d_keys.reserve((size_t)p.nseg * std::max(nq, 1) * KLIST * 4);
-    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * KM_PEND_WORDS_PER_WAVE * 4);
-    if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KM_WAVES * K4_PEND_WORDS_PER_WAVE * 4);
-    if (p.engine == 4) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<4>() * 4);
-    if (p.engine == 5) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<2>() * 4);
+void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt, int nq_grid = 0) {
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid);
+    S.d_keys.reserve((size_t)p.nseg * std::max(std::max(nq, nq_grid), 1) * KLIST * 4);
+    if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<4>() * 4);
+    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<2>() * 4);
 }
 
-// t_dev: packed [nt][8]; tx_dev: its FP4 expansion (needed by the MFMA engine, may be null for VALU)
-// prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (MFMA engine; the VALU
+// prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (matrix-core engine; the VALU
 // engine always returns full lists)
 struct TrainOps {             // device operands of one train set, per engine
     const uint32_t* t;        // packed [nt][8] (VALU engine)
-    const uint4* tx;          // +-1 FP4 expansion (first matrix-core engine)
     const uint4* txb;         // {0,1} FP4 expansion in norm order + side arrays (knn_tile.hip.h)
     const uint32_t* side;
     const float4* nminh;
 };
 
-void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const TrainOps& T, int nt, float prune_tol) {
-    if (nq <= 0) return;
+// nq_dev != null: the real query count lives on the device (the host did not wait for the ORB counts); then `nq` is the
+// estimate the plan is made for and nq_grid the capacity the grid and the buffers cover.  Only the matrix-core engine.
+void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const TrainOps& T, int nt, float prune_tol,
+             const uint32_t* nq_dev = nullptr, int nq_grid = 0) {
+    if (nq <= 0 && !nq_dev) return;
     hipStream_t st = S.st;
-    const uint32_t* t_dev = T.t;
-    const uint4* tx_dev = T.tx;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
-    const KnnPlan p = knn_plan(m, nq, nt);
-    knn_reserve(m, S, nq, nt);
-    if ((p.engine == 4 || p.engine == 5) && nt > 0) {
-        if (p.engine == 4)
-            knn_tile_kernel<4><<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
-                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid);
+    knn_reserve(m, S, nq, nt, nq_grid);
+    const int nq_all = std::max(std::max(nq, nq_grid), 1);
+    if ((p.engine == 2 || p.engine == 3) && nt > 0) {
+        if (p.engine == 2)
+            knn_tile4_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
         else
-            knn_tile_kernel<2><<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
-                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
+            knn_tile2_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
         check_launch("knn_tile_kernel");
         if (p.nseg > 1) {
-            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
+            knn_merge_kernel<KLIST><<<cdiv(nq_all, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg, nq_dev);
             check_launch("knn_merge_kernel");
         }
         return;
     }
-    if (p.engine == 2 && nt > 0) {
-        knn_mfma4_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
-                                                                         S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
-        check_launch("knn_mfma4_kernel");
-        if (p.nseg > 1) {
-            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
-            check_launch("knn_merge_kernel");
-        }
-        return;
-    }
-    if (p.engine == 3 && nt > 0) {
-#ifdef KM_TIMING
-        static unsigned long long* dbg = nullptr;
-        if (!dbg) HIP_CHECK(hipMalloc(&dbg, 64));
-        HIP_CHECK(hipMemsetAsync(dbg, 0, 64, st));
-        knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
-                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, dbg);
-        unsigned long long hd[8];
-        HIP_CHECK(hipMemcpyAsync(hd, dbg, 64, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        fprintf(stderr, "KM_TIMING waves %llu: per wave total %.0f barrier %.0f flush %.0f slow %.0f cycles; flushes %.1f slow-iters %.1f (of %d iters)\n",
-                hd[6], (double)hd[0] / hd[6], (double)hd[1] / hd[6], (double)hd[2] / hd[6], (double)hd[3] / hd[6],
-                (double)hd[4] / hd[6], (double)hd[5] / hd[6], knn_pad_rows(nt) / 32);
-#else
-        knn_mfma_kernel<<<dim3(p.qblocks, p.nseg), KM_THREADS, 0, st>>>(q_dev, nq, tx_dev, nt, knn_pad_rows(nt), p.per_seg,
-                                                                        S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol);
-#endif
-        check_launch("knn_mfma_kernel");
-        if (p.nseg > 1) {
-            knn_merge_kernel<KLIST><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
-            check_launch("knn_merge_kernel");
-        }
-        return;
-    }
-    knn_hamming_kernel<KLIST><<<dim3(p.qblocks, p.nseg), KNN_BLOCK, 0, st>>>(q_dev, nq, t_dev, nt, p.per_seg, S.d_keys.as<uint32_t>());
+    if (nq_dev) fail(SLIDEO_ERR_STATE, "internal: the VALU kNN engine needs the query count on the host");
+    knn_hamming_kernel<KLIST><<<dim3(p.qblocks, p.nseg), KNN_BLOCK, 0, st>>>(q_dev, nq, T.t, nt, p.per_seg, S.d_keys.as<uint32_t>());
     check_launch("knn_hamming_kernel");
     if (p.nseg > 1) {
         knn_merge_kernel<KLIST><<<p.qblocks, KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg);
@@ -538,17 +530,40 @@ void validate_image(int w, int h, int stride) {
 
 // ---- one unit of the per-frame hot path: enqueue everything, then collect ---------------
 // `frames_dev` must stay valid until the unit is collected (reproject reads the frames).
-void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
+// keypoints per frame the capacity-sized path provides for: twice the quota (ties at a level's retainBest threshold are kept, so
+// no finite bound is safe; a frame beyond it is detected on the device and the unit re-run through the exact-size path)
+uint32_t kp_cap_for(const slideo_matcher* m, const PyrGeom& g) {
+    int cap = std::max(2 * m->cfg.nfeatures, m->cfg.nfeatures + 1024);
+    cap = std::min(cap, KP_CAP_PER_FRAME);
+    return (uint32_t)std::max(1, std::min(cap, std::max(g.cand_per_frame, 1)));
+}
+
+void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+                 bool allow_async = true) {
     const slideo_config& c = m->cfg;
     hipStream_t st = S.st;
     const bool prof = m->profiling;
-    S.timed = prof;
+    const PyrGeom& g = geom_for(m, w, h).g;
+    // Capacity-sized (no host wait in the middle of the unit) when the matrix-core kNN runs: every kernel downstream of the ORB
+    // counts reads them on the device.  The VALU engine (A/B only) keeps the exact-size path.
+    const uint32_t kpcap = kp_cap_for(m, g);
+    const bool async = allow_async && m->async_submit && knn_engine_for(m, n * (int)std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures)) != 1 &&
+                       (int64_t)n * kpcap < ((int64_t)1 << 30);
+    S.timed = prof; S.u_frames = frames_dev; S.u_w = w; S.u_h = h; S.u_stride = stride; S.u_fs = frame_stride; S.u_async = async;
+    if (m->orb_chain && m->last_orb_ev && m->last_orb_ev != S.ev_orb) HIP_CHECK(hipStreamWaitEvent(st, m->last_orb_ev, 0));
     if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
-    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride);
-    orb_wait_info(m, S);                  // the other units' kNN / verify keep the GPU busy meanwhile
-    const uint32_t qtot = S.orb.qtot;
+    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride, false, async ? kpcap : 0xFFFFFFFFu);
+    uint32_t qtot, qplan;
+    if (async) {
+        qtot = (uint32_t)n * kpcap;                                          // capacity
+        qplan = (uint32_t)n * std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures);   // what the kNN plan assumes
+        S.orb.qtot = qtot; S.orb.max_count = kpcap;
+    } else {
+        orb_wait_info(m, S);                  // the other units' kNN / verify keep the GPU busy meanwhile
+        qtot = qplan = S.orb.qtot;
+    }
     // all workspace before the timed kNN interval
-    knn_reserve(m, S, (int)qtot, (int)m->M);
+    knn_reserve(m, S, (int)qplan, (int)m->M, (int)qtot);
     S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
     S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
     S.d_gmask.reserve(std::max<size_t>((size_t)qtot * c.knn_k, 16));
@@ -556,7 +571,9 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
     S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
     S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
-    orb_stage2(m, S, w, h);
+    orb_stage2(m, S, w, h, async);
+    HIP_CHECK(hipEventRecord(S.ev_orb, st));
+    m->last_orb_ev = S.ev_orb;
     const VerifyParams vp = make_vp(c);
     const int P = (int)m->pages.size();
     HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
@@ -567,9 +584,8 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         // current best must still be kept, hence max(tol, 1)
         // (the ratio test needs the exact two nearest rows: exact lists)
         const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
-        const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainx.as<uint4>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(),
-                         m->d_train_nminh.as<float4>()};
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qtot, T, (int)m->M, prune);
+        const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, (int)m->M, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
@@ -601,9 +617,11 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     check_launch("verdict_kernel");
     if (prof) HIP_CHECK(hipEventRecord(S.ev[3], st));
     uint8_t* ho = S.h_out.as<uint8_t>();
+    const size_t tail = (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands));
     HIP_CHECK(hipMemcpyAsync(ho, S.d_verdicts.p, (size_t)n * sizeof(slideo_verdict), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(ho + (size_t)n * sizeof(slideo_verdict), S.d_fcs.p, (size_t)n * sizeof(FrameCands), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(ho + (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)), flags, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(ho + tail, flags, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(ho + tail + 4, S.d_info.p, 8, hipMemcpyDeviceToHost, st));      // {Qtot, max keypoints per frame}
     if (prof) HIP_CHECK(hipEventRecord(S.ev[4], st));
     S.busy = true; S.n = n;
 }
@@ -612,6 +630,22 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
     const int n = S.n;
     HIP_CHECK(hipStreamSynchronize(S.st));
     S.busy = false;
+    const uint8_t* ho = S.h_out.as<uint8_t>();
+    const size_t tail = (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands));
+    uint32_t fl, info[2];
+    std::memcpy(&fl, ho + tail, 4);
+    std::memcpy(info, ho + tail + 4, 8);
+    if (S.u_async) {
+        if (fl & 1u) fail(SLIDEO_ERR_HIP, "internal: FAST candidate list overflow");
+        if (fl & 8u) {
+            // a frame had more keypoints than the capacity-sized path provides for (ties at a retainBest threshold are kept, as
+            // in OpenCV): the whole unit again, through the exact-size path
+            unit_submit(m, S, S.u_frames, n, S.u_w, S.u_h, S.u_stride, S.u_fs, false);
+            unit_collect(m, S, out_host);
+            return;
+        }
+        S.orb.qtot = info[0]; S.orb.max_count = info[1];
+    }
     const uint32_t qtot = S.orb.qtot;
     if (S.timed) {
         float t;
@@ -623,9 +657,6 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
         }
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
     }
-    const uint8_t* ho = S.h_out.as<uint8_t>();
-    uint32_t fl;
-    std::memcpy(&fl, ho + (size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)), 4);
     if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
     std::memcpy(out_host, ho, (size_t)n * sizeof(slideo_verdict));
     const size_t base = m->last_fcs.size();
@@ -751,12 +782,15 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<slideo_matcher> mm(new slideo_matcher());
     mm->cfg = *cfg; mm->device = device;
-    if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 5) mm->knn_engine = v; }
+    if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
+    if (const char* e = std::getenv("SLIDEO_ASYNC_SUBMIT")) mm->async_submit = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
         for (auto& e : S.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&S.ev_orb, hipEventDisableTiming));
     }
     mm->stream = mm->slots[0].st;
     OrbTables t{};
@@ -793,6 +827,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
         if (S.st) { (void)hipStreamSynchronize(S.st); (void)hipStreamDestroy(S.st); }
         for (auto& e : S.ev) if (e) (void)hipEventDestroy(e);
         if (S.ev_in) (void)hipEventDestroy(S.ev_in);
+        if (S.ev_orb) (void)hipEventDestroy(S.ev_orb);
     }
     delete m;
 }
@@ -800,7 +835,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
 int32_t slideo_matcher_max_in_flight(const slideo_matcher* m) { return m ? NSLOTS : 0; }
 
 int32_t slideo_matcher_set_knn_engine(slideo_matcher* m, int32_t engine) {
-    if (!m || engine < 0 || engine > 5) return SLIDEO_ERR_INVALID_ARG;
+    if (!m || engine < 0 || engine > 3) return SLIDEO_ERR_INVALID_ARG;
     m->knn_engine = engine;
     return SLIDEO_OK;
 }
@@ -927,7 +962,6 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         HIP_CHECK(hipMemcpy(m->d_train.p, train.data(), train.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
-        expand_train(m->d_train.as<uint32_t>(), (int)M, m->d_trainx, m->stream);
         prepare_train_bits(train.data(), m->d_train.as<uint32_t>(), (int)M, TrainBits{&m->d_trainb, &m->d_train_side, &m->d_train_nminh, &m->d_train_perm}, m->stream);
         HIP_CHECK(hipStreamSynchronize(m->stream));
     }
@@ -1149,11 +1183,9 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64));
     HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    DevBuf tapx, tapb, tap_side, tap_nminh, tap_perm;
-    const int eng = knn_engine_for(m, nq);
-    if ((eng == 2 || eng == 3) && nt > 0) expand_train(m->d_tapt.as<uint32_t>(), nt, tapx, st);
-    if ((eng == 4 || eng == 5) && nt > 0) prepare_train_bits(t, m->d_tapt.as<uint32_t>(), nt, TrainBits{&tapb, &tap_side, &tap_nminh, &tap_perm}, st);
-    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, TrainOps{m->d_tapt.as<uint32_t>(), tapx.as<uint4>(), tapb.as<uint4>(), tap_side.as<uint32_t>(), tap_nminh.as<float4>()}, nt, 0.f);
+    DevBuf tapb, tap_side, tap_nminh, tap_perm;
+    if (knn_engine_for(m, nq) != 1 && nt > 0) prepare_train_bits(t, m->d_tapt.as<uint32_t>(), nt, TrainBits{&tapb, &tap_side, &tap_nminh, &tap_perm}, st);
+    run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, TrainOps{m->d_tapt.as<uint32_t>(), tapb.as<uint4>(), tap_side.as<uint32_t>(), tap_nminh.as<float4>()}, nt, 0.f);
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");
@@ -1176,12 +1208,12 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     Slot& S = m->slots[0];
     hipStream_t st = S.st;
     const int nt_pad = knn_pad_rows(nt);
-    const int qblocks = cdiv(nq, KM_QPB);
+    const int qblocks = cdiv(nq, KNL_QPB);
     DevBuf d_q, d_t, d_tx, d_tn, d_norm, d_perm, d_keys, d_pend;
     d_q.reserve((size_t)nq * 128); d_t.reserve(std::max<size_t>((size_t)nt * 128, 64));
     d_tx.reserve((size_t)nt_pad * 128); d_tn.reserve((size_t)nt_pad * 4);
     d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64)); d_perm.reserve((size_t)nt_pad * 4);
-    d_keys.reserve((size_t)nq * KLIST * 8); d_pend.reserve((size_t)qblocks * KM_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
+    d_keys.reserve((size_t)nq * KLIST * 8); d_pend.reserve((size_t)qblocks * KT_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
     HIP_CHECK(hipMemcpyAsync(d_q.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
     // train-set preparation (once per set; here per call, this being a tap): norms on the device, the norm order on the
     // host (a stable index sort), then the centred tile-major operand gathered in that order
@@ -1201,13 +1233,13 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     check_launch("knl_expand_train_kernel");
     const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
-        knn_l2_kernel<8><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
+        knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                           d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     else if (kl == 16)
-        knn_l2_kernel<16><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
+        knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                            d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     else
-        knn_l2_kernel<KLIST><<<qblocks, KM_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
+        knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
                                                               d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
     check_launch("knn_l2_kernel");
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);

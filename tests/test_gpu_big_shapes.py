@@ -84,7 +84,7 @@ def test_headline_shape_traces_vs_oracle(capi, oracle, synth, deck500):
     otr = _oracle_traces(db, frames, idx)
     d_frames = torch.from_numpy(frames).cuda()
     ref_v = ref_c = None
-    for engine in ("mfma4", "mfma2", "tile4", "tile2"):
+    for engine in ("mfma4", "mfma2"):
         for exact in (False, True):
             m.set_knn_engine(engine)
             m.set_knn_exact_lists(exact)

@@ -28,7 +28,7 @@ def test_orb_and_blurred_pyramid_bit_exact_per_variant(capi, oracle, cfg0_data, 
     pages, frames, _, _ = cfg0_data
     m = capi.Matcher(capi.default_config(nfeatures=700, **over))
     ocfg = oracle.default_config(nfeatures=700, **over)
-    for img in (_natural(), frames[0], pages[1]):
+    for img in (_natural(), frames[1], pages[1]):          # (frames[0] is a "no slide" frame: no keypoints)
         for lvl in (0, 3, 7):
             for blurred in (False, True):
                 assert np.array_equal(m.pyramid_level(img, lvl, blurred), oracle.pyramid_level(img, ocfg, lvl, blurred)), (lvl, blurred)

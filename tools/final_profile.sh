@@ -12,7 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python profiles/summarize_pmc.py $out/pmc_$c/t_results.db > $out/pmc_$c.txt
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $out/pmc_sq -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > $out/pmc_sq.log 2>&1
-python profiles/summarize_pmc.py $out/pmc_sq/t_results.db knn_mfma > $out/pmc_sq_knn.txt
+python profiles/summarize_pmc.py $out/pmc_sq/t_results.db knn_tile > $out/pmc_sq_knn.txt
 rm -rf $out/stats $out/stats2 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_sq
 { python bench.py --workload cfg1 --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload cfg4 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1

@@ -4,7 +4,7 @@ steps the share of wall time with 0 / 1 / 2+ kNN launches resident."""
 import re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-knn = [(s, e) for n, s, e in rows if "knn_mfma" in n]
+knn = [(s, e) for n, s, e in rows if "knn_tile" in n]
 t0 = knn[0][0]
 prev = None
 for s, e in knn:
@@ -24,7 +24,7 @@ tot = sum(cov.values()) or 1
 print("window %.1f ms: no kNN resident %.1f %%, one %.1f %%, two or more %.1f %%" % (tot / 1e6, 100 * cov[0] / tot, 100 * cov[1] / tot, 100 * cov[2] / tot))
 other = {}
 for n, s, e in rows:
-    if "knn_mfma" in n or s < lo or e > hi: continue
+    if "knn_tile" in n or s < lo or e > hi: continue
     k = re.sub(r"\(.*", "", n).replace("slideo::", "").replace("void ", "")
     other[k] = other.get(k, 0) + (e - s)
 print("other kernels inside the window (sum of durations, ms):", ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(other.items(), key=lambda kv: -kv[1])[:8]))
