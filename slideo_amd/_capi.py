@@ -69,8 +69,8 @@ def lib():
     """Loads libslideo_amd.so (building it in-tree if the sources are newer)."""
     global _lib
     if _lib is None:
-        path = _build.HIP_LIB
-        if not os.path.exists(path) or os.environ.get("SLIDEO_REBUILD"):
+        path = os.environ.get("SLIDEO_LIB_PATH") or _build.HIP_LIB      # (SLIDEO_LIB_PATH: an experiment build of the same sources)
+        if path == _build.HIP_LIB and (not os.path.exists(path) or os.environ.get("SLIDEO_REBUILD")):
             path = _build.build_hip()
         if not os.path.exists(path):
             raise RuntimeError("libslideo_amd.so is missing and could not be built; the HIP "

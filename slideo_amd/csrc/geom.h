@@ -18,7 +18,7 @@ namespace slideo {
 constexpr int MAX_LEVELS = 16;
 constexpr int MAX_DIM = 4096;            // x,y packed in 12 bits each
 constexpr int FAST_TW = 126, FAST_TH = 32; // FAST tile (outputs); + 1-px score halo = 128 x 34 score positions
-constexpr int BLUR_RH = 28;                // blur: output rows per wave (multiple of the 7-row register ring)
+constexpr int BLUR_RH = 56;                // blur: output rows per wave (multiple of 7: the register ring of blur_kernel; and of 8: four row pairs per round of blur_f32_kernel)
 constexpr int BLUR_TW = 248, BLUR_TH = 4 * BLUR_RH;  // blur tile (outputs) per 256-thread block: 62 inner lanes x 4 px, 4 waves stacked
 constexpr int KP_CAP_PER_FRAME = 8192;     // sort capacity (LDS), loud error beyond
 constexpr int RNG_TABLE = 16384;           // pre-drawn cv::RNG outputs for RANSAC

@@ -41,8 +41,14 @@ typedef float knn_v16f __attribute__((ext_vector_type(16)));
 constexpr int KT_WAVES = 8;                    // waves per block
 constexpr int KT_THREADS = KT_WAVES * 64;
 constexpr int KT_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
-constexpr int KT_RING = 4;                     // LDS ring slots (super-tiles resident per block)
-constexpr int KT_AHEAD = 2;                    // a super-tile is staged this many iterations before it is consumed
+#ifndef KT_RING_V
+#define KT_RING_V 4
+#endif
+#ifndef KT_AHEAD_V
+#define KT_AHEAD_V 2
+#endif
+constexpr int KT_RING = KT_RING_V;             // LDS ring slots (super-tiles resident per block)
+constexpr int KT_AHEAD = KT_AHEAD_V;           // a super-tile is staged this many iterations before it is consumed
 constexpr int KT_MFMA_PRIO = 1;                // wave priority while its MFMAs are issued (0 elsewhere)
 constexpr int KT_ST_U4 = KT_ST_ROWS * 128 / 16;  // uint4 per super-tile of operand (1024)
 constexpr int KT_SIDE_U32 = 2 * KT_ST_ROWS;    // per super-tile: 128 f32 norms, then 128 i32 original rows
@@ -144,6 +150,10 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
     uint32_t cntp = 0;                                                 // keys pending in this lane's private buffers, 8 bits per query tile
 #pragma unroll
     for (int i = 0; i < NT; ++i) h[i] = (nq_of(i) - 513.f) * 0.5f;
+#ifdef KT_EXPERIMENT_NOSLOW          // measurement only (tools/knn_experiments.sh): no row ever qualifies, the pure streaming rate
+#pragma unroll
+    for (int i = 0; i < NT; ++i) h[i] = 1e9f;
+#endif
     auto cnt_of = [&](uint32_t packed, int i) -> uint32_t { return (packed >> (8 * i)) & 255u; };
 
     // owners drain the pending buffers of their two source lanes into their sorted lists (which live in `out`)

@@ -537,9 +537,22 @@ __global__ __launch_bounds__(256) void blur_kernel(PyrGeom g, const uint8_t* __r
 // dwords by wave shuffle for the 7-tap row pass, and keeps the last 7 row-filtered rows (4 floats each) in a register ring.
 // grid (blur_tiles, B), block 256.
 // ---------------------------------------------------------------------------
+typedef float blur_f2 __attribute__((ext_vector_type(2)));
+
+// Packed form.  The kernel is bound by VALU issue (PMC, r02: SQ_ACTIVE_INST_VALU ~ all of its SIMD time at about 144
+// instructions per 4-pixel row in the first, scalar version), so the arithmetic is organised for v_pk_*_f32 with operand pairs
+// that are BORN aligned: a lane processes TWO source rows at a time and pairs every pixel with the pixel below it,
+//     P[m] = (p_row a [m], p_row b [m]),  m = 0 .. 9     (20 v_cvt_f32_ubyte, each writing one half of a pair)
+// so the row pass of both rows is 4 outputs x 7 packed instructions, and no pair ever has to be re-assembled with moves (pairing
+// along x needs every pixel in two differently aligned pairs).  Row-pass results live as row pairs A[k] = (r_2k, r_2k+1) plus
+// the interleaved pairs M[k] = (r_2k+1, r_2k+2) (one move per pixel and row pair); the column pass of the output rows (2t, 2t+1)
+//     k3 A[t] + k4 (M[t] + M[t-1]) + k5 (A[t+1] + A[t-1]) + k6 (M[t+1] + M[t-2])
+// is 7 packed instructions per pixel pair, in OpenCV's order of operations component by component.  The final
+// saturate_cast<uchar>(cvRound(s)) is one v_cvt_pk_u8_f32 per pixel (round to nearest even, saturating: tools/cvt_pk_probe.hip).
 template <bool FMA>
 __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                        uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab) {
+    static_assert(BLUR_RH % 8 == 0, "four row pairs per unrolled round");
     const int f = blockIdx.y;
     const int l = level_of_tile(g, blockIdx.x, true);
     const LevelGeom L = g.lv[l];
@@ -552,52 +565,91 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
     const int xs = x0 - 4 + 4 * lane;
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
     uint8_t* out = blur + (int64_t)f * g.frame_bytes + L.ofs;
-    float k[7];
+    blur_f2 kk[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) k[i] = tab->gkf[i];
-    auto mad = [](float a, float b, float c) { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
-    auto load = [&](int y) { return blur_load_dword(img, L.pitch, L.w, reflect101(y, L.h), xs); };
-    // row pass of one source row: the lane's 4 outputs from pixels xs-3 .. xs+6
-    auto rowpass = [&](uint32_t d, float (&o)[4]) {
-        const uint32_t lf = __shfl_up(d, 1), rt = __shfl_down(d, 1);
-        float p[10];
-        p[0] = (float)((lf >> 8) & 255u); p[1] = (float)((lf >> 16) & 255u); p[2] = (float)(lf >> 24);
-        p[3] = (float)(d & 255u); p[4] = (float)((d >> 8) & 255u); p[5] = (float)((d >> 16) & 255u); p[6] = (float)(d >> 24);
-        p[7] = (float)(rt & 255u); p[8] = (float)((rt >> 8) & 255u); p[9] = (float)((rt >> 16) & 255u);
+    for (int i = 0; i < 7; ++i) { const float k = tab->gkf[i]; kk[i] = blur_f2{k, k}; }
+    auto mad2 = [](blur_f2 a, blur_f2 b, blur_f2 c) -> blur_f2 { return FMA ? __builtin_elementwise_fma(a, b, c) : a * b + c; };
+    // a strip whose 4-byte groups all lie inside the level loads aligned dwords; the level's first / last strip (and a level
+    // narrower than a strip) goes through the reflecting byte loads — wave-uniform choice, so the common path has no divergence
+    const bool plain = x0 >= 4 && x0 + 4 * 63 <= L.w;
+    auto load = [&](int y) -> uint32_t {
+        const int gy = reflect101(y, L.h);
+        if (plain) return *reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch + xs);
+        return blur_load_dword(img, L.pitch, L.w, gy, xs);
+    };
+    // row pass of source rows ya, ya + 1 -> the lane's 4 outputs of each row, as (row a, row b) pairs
+    auto rowpass2 = [&](uint32_t da, uint32_t db, blur_f2 (&o)[4]) {
+        const uint32_t la = __shfl_up(da, 1), ra = __shfl_down(da, 1), lb = __shfl_up(db, 1), rb = __shfl_down(db, 1);
+        blur_f2 P[10];
+        P[0] = blur_f2{(float)((la >> 8) & 255u), (float)((lb >> 8) & 255u)};
+        P[1] = blur_f2{(float)((la >> 16) & 255u), (float)((lb >> 16) & 255u)};
+        P[2] = blur_f2{(float)(la >> 24), (float)(lb >> 24)};
+        P[3] = blur_f2{(float)(da & 255u), (float)(db & 255u)};
+        P[4] = blur_f2{(float)((da >> 8) & 255u), (float)((db >> 8) & 255u)};
+        P[5] = blur_f2{(float)((da >> 16) & 255u), (float)((db >> 16) & 255u)};
+        P[6] = blur_f2{(float)(da >> 24), (float)(db >> 24)};
+        P[7] = blur_f2{(float)(ra & 255u), (float)(rb & 255u)};
+        P[8] = blur_f2{(float)((ra >> 8) & 255u), (float)((rb >> 8) & 255u)};
+        P[9] = blur_f2{(float)((ra >> 16) & 255u), (float)((rb >> 16) & 255u)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float a = k[0] * p[j];
+            blur_f2 a = kk[0] * P[j];
 #pragma unroll
-            for (int i = 1; i < 7; ++i) a = mad(k[i], p[j + i], a);
+            for (int i = 1; i < 7; ++i) a = mad2(kk[i], P[j + i], a);
             o[j] = a;
         }
     };
-    float ring[7][4];
+    // Window rows are numbered from y0 - 4: A[k] = window rows (2k, 2k+1), M[k] = (2k+1, 2k+2) = (A[k].y, A[k+1].x), both kept
+    // modulo 4.  The output rows (2j, 2j+1) — the first is j = 2 — take A[j-1 .. j+1] and M[j-2 .. j+1], so A[j+2] is made
+    // first in every round.  (Window row 0 = y0 - 4 is not a tap of any output; it keeps every pair on an even row.)
+    blur_f2 A[4][4], M[4][4];
+    auto interleave = [&](int k) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) rowpass(load(y0 - 3 + j), ring[j]);
+        for (int c = 0; c < 4; ++c) M[k & 3][c] = blur_f2{A[k & 3][c].y, A[(k + 1) & 3][c].x};
+    };
+    rowpass2(load(y0 - 4), load(y0 - 3), A[0]);
+    rowpass2(load(y0 - 2), load(y0 - 1), A[1]);
+    rowpass2(load(y0), load(y0 + 1), A[2]);
+    rowpass2(load(y0 + 2), load(y0 + 3), A[3]);
+    interleave(0); interleave(1); interleave(2);
     const bool inner = lane >= 1 && lane <= 62;
-    uint32_t dn0 = load(y0 + 3), dn1 = load(y0 + 4), dn2 = load(y0 + 5);
-    for (int gI = 0; gI < BLUR_RH / 7; ++gI) {
+    const int lim = y0 + BLUR_RH + 3;                                  // last source row any output of the strip taps (+ its pair partner)
+    // source rows are requested FOUR row pairs (one unrolled round) ahead: 8 loads in flight per lane.  With two pairs ahead
+    // the kernel ran at 1.6 TB/s whatever its instruction count (packed or not: 2.18 -> 2.0 ms) — bytes in flight, not VALU.
+    uint32_t pa[4], pb[4];
 #pragma unroll
-        for (int ph = 0; ph < 7; ++ph) {
-            const int i = gI * 7 + ph;                              // output row y0 + i; rows y0+i-3+j sit in ring[(ph+j)%7]
-            rowpass(dn0, ring[(ph + 6) % 7]);
-            dn0 = dn1; dn1 = dn2;
-            dn2 = load(min(y0 + i + 6, y0 + BLUR_RH + 2));
-            uint32_t o = 0;
+    for (int u = 0; u < 4; ++u) { pa[u] = load(min(y0 + 4 + 2 * u, lim)); pb[u] = load(min(y0 + 5 + 2 * u, lim)); }
+    for (int gI = 0; gI < BLUR_RH / 8; ++gI) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int t = gI * 4 + ph;                                 // output rows y0 + 2t, y0 + 2t + 1
+            constexpr int J0 = 2;
+            const int j = ph + J0;                                     // window pair of the outputs, modulo 4 (4 gI drops out)
+            rowpass2(pa[ph], pb[ph], A[(j + 2) & 3]);                  // source rows y0 + 2t + 4, + 5
+            pa[ph] = load(min(y0 + 2 * t + 12, lim)); pb[ph] = load(min(y0 + 2 * t + 13, lim));    // for round t + 4
+            interleave(j + 1);
+            uint32_t o0 = 0, o1 = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float a = mad(k[3], ring[(ph + 3) % 7][c], 0.f);
-#pragma unroll
-                for (int j = 1; j <= 3; ++j) a = mad(k[3 + j], ring[(ph + 3 + j) % 7][c] + ring[(ph + 3 - j) % 7][c], a);
-                const uint32_t v = min((uint32_t)(int)rintf(a), 255u);      // a >= 0: cvRound, then saturate
-                o |= v << (8 * c);
+                blur_f2 a = kk[3] * A[j & 3][c];                      // (k3 c + delta 0 is k3 c in either form)
+                a = mad2(kk[4], M[j & 3][c] + M[(j - 1) & 3][c], a);
+                a = mad2(kk[5], A[(j + 1) & 3][c] + A[(j - 1) & 3][c], a);
+                a = mad2(kk[6], M[(j + 1) & 3][c] + M[(j - 2) & 3][c], a);
+                o0 = __builtin_amdgcn_cvt_pk_u8_f32(a.x, (uint32_t)c, o0);
+                o1 = __builtin_amdgcn_cvt_pk_u8_f32(a.y, (uint32_t)c, o1);
             }
-            const int gy = y0 + i;
-            if (inner && gy < L.h && xs < L.w) {
+            const int gy = y0 + 2 * t;
+            if (inner && xs < L.w) {
                 uint8_t* d = out + (int64_t)gy * L.pitch + xs;
-                if (xs + 3 < L.w) *reinterpret_cast<uint32_t*>(d) = o;
-                else for (int c = 0; c < 4 && xs + c < L.w; ++c) d[c] = (uint8_t)(o >> (8 * c));
+                if (xs + 3 < L.w) {
+                    if (gy < L.h) *reinterpret_cast<uint32_t*>(d) = o0;
+                    if (gy + 1 < L.h) *reinterpret_cast<uint32_t*>(d + L.pitch) = o1;
+                } else {
+                    for (int c = 0; c < 4 && xs + c < L.w; ++c) {
+                        if (gy < L.h) d[c] = (uint8_t)(o0 >> (8 * c));
+                        if (gy + 1 < L.h) d[L.pitch + c] = (uint8_t)(o1 >> (8 * c));
+                    }
+                }
             }
         }
     }

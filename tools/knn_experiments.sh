@@ -1,0 +1,23 @@
+#!/bin/bash
+# Where does the kNN kernel's time go?  Experiment builds of the same sources (never shipped: results are wrong by design in
+# the first one), each timed with bench.py --no-overlap (kernel alone on the GPU).  Build them in the CPU container:
+#   tools/knn_experiments.sh build      -> slideo_amd/lib/exp_*.so
+# and run on the GPU box:
+#   tools/knn_experiments.sh run        -> gpurun_out/knn_experiments.txt
+set -e
+cd "$(dirname "$0")/.."
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-gpu-rdc -I include -I slideo_amd/csrc"
+declare -A V=( [noslow]="-DKT_EXPERIMENT_NOSLOW" [ring6]="-DKT_RING_V=6 -DKT_AHEAD_V=3" [noslow_ring6]="-DKT_EXPERIMENT_NOSLOW -DKT_RING_V=6 -DKT_AHEAD_V=3" )
+if [ "$1" = build ]; then
+  for k in "${!V[@]}"; do hipcc $FLAGS ${V[$k]} -o slideo_amd/lib/exp_$k.so slideo_amd/csrc/slideo_capi.hip & done; wait
+  ls -la slideo_amd/lib/exp_*.so
+else
+  out=gpurun_out/knn_experiments.txt; : > $out
+  for k in base "${!V[@]}" base; do
+    if [ $k = base ]; then unset SLIDEO_LIB_PATH; else export SLIDEO_LIB_PATH=$PWD/slideo_amd/lib/exp_$k.so; fi
+    python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-overlap 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$k', 'knn_ms', d['roofline']['avg_launch_ms'], 'step_ms', d['ms_per_step'], 'acc', d['config']['accuracy_vs_synthetic_truth'])" >> $out
+  done
+  cat $out
+fi
