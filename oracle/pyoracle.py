@@ -191,6 +191,16 @@ def knn_hamming(q, t, k):
     return idx, dist
 
 
+def knn_hamming_blocked(q, t, k):
+    """The cache-blocked / AVX-512 VPOPCNTDQ form of knn_hamming (what the frame path runs); returns (idx, dist, simd_used)."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.uint16)
+    simd = lib().so_knn_hamming_blocked(_p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist))
+    return idx, dist, bool(simd)
+
+
 def knn_l2_u8(q, t, k):
     q = np.ascontiguousarray(q, np.uint8).reshape(-1, 128)
     t = np.ascontiguousarray(t, np.uint8).reshape(-1, 128)

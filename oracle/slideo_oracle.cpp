@@ -251,7 +251,16 @@ static void fast_score_map(const Img8& im, int t, Img8& sc) {
     if (im.w < 7 || im.h < 7) return;
     for (int y = 3; y < im.h - 3; ++y) {
         uint8_t* s = sc.row(y);
-        for (int x = 3; x < im.w - 3; ++x) s[x] = (uint8_t)fast_score_at(im, x, y, t);
+        const uint8_t* c = im.row(y);
+        const int st = im.w;
+        for (int x = 3; x < im.w - 3; ++x) {
+            // quick reject (fast.cpp tests the same antipodal pairs first): every arc of 9 contains one pixel of each antipodal
+            // pair, so a pair whose two pixels are both within t of the centre rules the corner out.  Score 0 either way.
+            const int v = c[x];
+            auto far = [&](int dx, int dy) { const int p = c[x + dy * st + dx]; return p > v + t || p < v - t; };
+            if (!(far(0, 3) || far(0, -3)) || !(far(3, 0) || far(-3, 0)) || !(far(2, 2) || far(-2, -2)) || !(far(2, -2) || far(-2, 2))) continue;
+            s[x] = (uint8_t)fast_score_at(im, x, y, t);
+        }
     }
 }
 
@@ -586,6 +595,104 @@ static void knn_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int 
             idx[(size_t)i * k + r] = r < cnt ? bi[r] : -1;
             dist[(size_t)i * k + r] = r < cnt ? (uint16_t)bd[r] : (uint16_t)65535;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same exact k-NN, cache-blocked and vectorised — what the frame path and bench.py's cpu_baseline leg run, so that the
+// CPU number beside the GPU's is not a strawman (the plain loop above streams the 16.5 MB train matrix once per
+// QUERY and scaled 6.7x on 256 threads).  Train rows are re-laid in blocks of 8 rows, qword-interleaved
+// (block b = [w = 0..3][row = 0..7] u64: one 64-byte vector per descriptor qword), so that for a broadcast query qword the
+// eight distances of a block are 4 x (xor, popcount, add) on full vectors with no horizontal step; queries are taken 16 at a
+// time against train tiles of 512 rows (16 KB: the tile stays in L1 while the 16 queries sweep it, and the whole matrix is
+// read once per 16 queries).  AVX-512 VPOPCNTDQ when the CPU has it (runtime dispatch), scalar popcnt on the same layout
+// otherwise.  Rows are visited in ascending order per query and the test is strict, so the result equals knn_hamming's bit
+// for bit (tests/test_oracle_primitives.py).
+// ---------------------------------------------------------------------------
+static void knn_block_train(const uint8_t* t, int nt, std::vector<uint64_t>& tb) {
+    const int nb = (nt + 7) / 8;
+    tb.assign((size_t)nb * 32, ~0ull);                      // pad rows: all ones (never selected: excluded by row index)
+    for (int r = 0; r < nt; ++r) {
+        uint64_t w[4];
+        std::memcpy(w, t + (size_t)r * 32, 32);
+        for (int k = 0; k < 4; ++k) tb[(size_t)(r >> 3) * 32 + k * 8 + (r & 7)] = w[k];
+    }
+}
+
+static inline void knn_offer(int d, int row, int k, int& cnt, int* bd, int* bi) {
+    if (cnt == k && d >= bd[k - 1]) return;                 // strict: a later equal distance never enters
+    int p = cnt < k ? cnt++ : k - 1;
+    while (p > 0 && bd[p - 1] > d) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+    bd[p] = d; bi[p] = row;
+}
+
+static void knn_scan_scalar(const uint64_t* tb, int b0, int b1, int nt, const uint64_t* q, int k, int& cnt, int* bd, int* bi) {
+    for (int b = b0; b < b1; ++b) {
+        const uint64_t* T = tb + (size_t)b * 32;
+        for (int r = 0; r < 8; ++r) {
+            const int row = b * 8 + r;
+            if (row >= nt) break;
+            const int d = __builtin_popcountll(T[r] ^ q[0]) + __builtin_popcountll(T[8 + r] ^ q[1]) +
+                          __builtin_popcountll(T[16 + r] ^ q[2]) + __builtin_popcountll(T[24 + r] ^ q[3]);
+            knn_offer(d, row, k, cnt, bd, bi);
+        }
+    }
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx512f,avx512vpopcntdq")))
+static void knn_scan_avx512(const uint64_t* tb, int b0, int b1, int nt, const uint64_t* q, int k, int& cnt, int* bd, int* bi) {
+    const __m512i q0 = _mm512_set1_epi64((long long)q[0]), q1 = _mm512_set1_epi64((long long)q[1]);
+    const __m512i q2 = _mm512_set1_epi64((long long)q[2]), q3 = _mm512_set1_epi64((long long)q[3]);
+    for (int b = b0; b < b1; ++b) {
+        const __m512i* T = reinterpret_cast<const __m512i*>(tb + (size_t)b * 32);
+        __m512i d = _mm512_popcnt_epi64(_mm512_xor_si512(_mm512_loadu_si512(T), q0));
+        d = _mm512_add_epi64(d, _mm512_popcnt_epi64(_mm512_xor_si512(_mm512_loadu_si512(T + 1), q1)));
+        d = _mm512_add_epi64(d, _mm512_popcnt_epi64(_mm512_xor_si512(_mm512_loadu_si512(T + 2), q2)));
+        d = _mm512_add_epi64(d, _mm512_popcnt_epi64(_mm512_xor_si512(_mm512_loadu_si512(T + 3), q3)));
+        const long long thr = cnt == k ? bd[k - 1] : 257;
+        __mmask8 m = _mm512_cmplt_epu64_mask(d, _mm512_set1_epi64(thr));
+        if (!m) continue;
+        alignas(64) uint64_t dv[8];
+        _mm512_store_si512(dv, d);
+        for (int r = 0; r < 8; ++r)                       // ascending rows; the threshold tightens inside the block
+            if (((m >> r) & 1) && b * 8 + r < nt) knn_offer((int)dv[r], b * 8 + r, k, cnt, bd, bi);
+    }
+}
+static bool cpu_has_vpopcntdq() {
+    static const bool have = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vpopcntdq");
+    return have;
+}
+#else
+static bool cpu_has_vpopcntdq() { return false; }
+#endif
+
+// tb: knn_block_train(train); same outputs as knn_hamming
+static void knn_hamming_blocked(const uint8_t* q, int nq, const uint64_t* tb, int nt, int k, int32_t* idx, uint16_t* dist) {
+    constexpr int QB = 16, TILE_BLOCKS = 64;               // 16 queries x 512 train rows
+    const int nb = (nt + 7) / 8;
+    const bool simd = cpu_has_vpopcntdq();
+    std::vector<int> bd((size_t)QB * k), bi((size_t)QB * k);
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        const int qn = std::min(QB, nq - q0);
+        int cnt[QB] = {0};
+        uint64_t qw[QB][4];
+        for (int i = 0; i < qn; ++i) std::memcpy(qw[i], q + (size_t)(q0 + i) * 32, 32);
+        for (int b0 = 0; b0 < nb; b0 += TILE_BLOCKS) {
+            const int b1 = std::min(nb, b0 + TILE_BLOCKS);
+            for (int i = 0; i < qn; ++i) {
+#if defined(__x86_64__)
+                if (simd) { knn_scan_avx512(tb, b0, b1, nt, qw[i], k, cnt[i], &bd[(size_t)i * k], &bi[(size_t)i * k]); continue; }
+#endif
+                knn_scan_scalar(tb, b0, b1, nt, qw[i], k, cnt[i], &bd[(size_t)i * k], &bi[(size_t)i * k]);
+            }
+        }
+        for (int i = 0; i < qn; ++i)
+            for (int r = 0; r < k; ++r) {
+                idx[(size_t)(q0 + i) * k + r] = r < cnt[i] ? bi[(size_t)i * k + r] : -1;
+                dist[(size_t)(q0 + i) * k + r] = r < cnt[i] ? (uint16_t)bd[(size_t)i * k + r] : (uint16_t)65535;
+            }
     }
 }
 
@@ -1071,6 +1178,7 @@ struct so_pagedb {
     slideo_config cfg;
     std::vector<Page> pages;
     std::vector<uint8_t> train;       // M x 32
+    std::vector<uint64_t> train_blocked;   // the same rows in knn_hamming_blocked's layout
     std::vector<int32_t> train_page;  // M
     std::vector<int32_t> page_ofs;    // P+1
     bool finalized = false;
@@ -1092,7 +1200,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
     if (K == 0) return;
     std::vector<int32_t> idx((size_t)K * k);
     std::vector<uint16_t> dist((size_t)K * k);
-    knn_hamming(fr.desc.data(), K, db.train.data(), M, k, idx.data(), dist.data());  // :266
+    knn_hamming_blocked(fr.desc.data(), K, db.train_blocked.data(), M, k, idx.data(), dist.data());  // :266 (== knn_hamming)
     int P = (int)db.pages.size();
     // tolerance vote, mo/lib.rs:268-282: d < best * 1.05 (f32, strict)
     std::vector<std::vector<Vote>> votes(P);
@@ -1312,6 +1420,12 @@ int so_orb_bgr8(const uint8_t* bgr, int w, int h, int stride, const slideo_confi
 void so_knn_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint16_t* dist) {
     knn_hamming(q, nq, t, nt, k, idx, dist);
 }
+// the cache-blocked / vectorised form the frame path uses; simd: 1 = AVX-512 VPOPCNTDQ was used
+int so_knn_hamming_blocked(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint16_t* dist) {
+    std::vector<uint64_t> tb; knn_block_train(t, nt, tb);
+    knn_hamming_blocked(q, nq, tb.data(), nt, k, idx, dist);
+    return cpu_has_vpopcntdq() ? 1 : 0;
+}
 
 // Exact squared-L2 k-NN between 128-dimensional u8 descriptors (SURVEY §8(d) cfg2 / §8(f) N4 — a north-star extension
 // with no counterpart in the reference: this brute force IS the parity target of slideo_knn_l2_u8).  k smallest
@@ -1434,6 +1548,7 @@ int so_pagedb_finalize(so_pagedb* db) {   // mo/flann.rs:65-71 (exact index = th
         db->train_page.insert(db->train_page.end(), o.kp.size(), (int32_t)p);
         db->page_ofs.push_back((int32_t)db->train_page.size());
     }
+    knn_block_train(db->train.data(), (int)db->train_page.size(), db->train_blocked);
     db->finalized = true;
     return db->train_page.empty() ? 6 : 0;
 }

@@ -179,3 +179,17 @@ def test_knn_l2_u8_known_answers(oracle):
     d = ((q[:, None, :].astype(np.int64) - t[None, :, :].astype(np.int64)) ** 2).sum(2)
     order = np.lexsort((np.broadcast_to(np.arange(300), d.shape), d), axis=1)[:, :7]
     assert np.array_equal(idx, order) and np.array_equal(dist, np.take_along_axis(d, order, 1))
+
+
+def test_blocked_knn_equals_plain_knn(oracle):
+    """The cache-blocked / vectorised k-NN the frame path and bench.py's cpu_baseline run is the plain restatement, bit for bit:
+    random rows, duplicates (distance 0, massive ties -> lowest row wins), fewer rows than k, sizes off the 8-row blocks."""
+    rng = np.random.default_rng(11)
+    for nq, nt, k in ((37, 1001, 30), (5, 7, 30), (64, 4099, 2), (1, 1, 1), (130, 515, 32)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nt > 100:
+            t[50:90] = q[0]; t[10:20] = q[min(3, nq - 1)]; t[nt - 5:] = q[0]
+        i0, d0 = oracle.knn_hamming(q, t, k)
+        i1, d1, _ = oracle.knn_hamming_blocked(q, t, k)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1), (nq, nt, k)
