@@ -189,6 +189,19 @@ int32_t     slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages,
                                           const int32_t* width, const int32_t* height,
                                           const int32_t* stride_bytes);
 
+/* The page side of ProcessedImage (mo/lib.rs:77-83) computed elsewhere — by another rank that analysed a share of the deck
+ * (the page-sharded build of SURVEY.md section 8e: ranks all-gather these records instead of each analysing every page) or by
+ * an earlier run (the reference caches per-PDF state, crates/app/src/db.rs).  Appends ONE page: its size, its keypoints and
+ * descriptors in canonical order (as slideo_matcher_get_page_features returns them) and its small image (as
+ * slideo_matcher_get_page_small returns it; small_w x small_h x 3 bytes, must be the to_small_image size of the page).
+ * A matcher built from imported pages behaves exactly like one that analysed the images itself. */
+int32_t     slideo_matcher_add_page_features(slideo_matcher* m, int32_t width, int32_t height, int32_t n_keypoints,
+                                             const slideo_keypoint* kp, const uint8_t* desc32,
+                                             const uint8_t* small_bgr, int32_t small_w, int32_t small_h);
+/* Copies page `page_idx`'s small image (to_small_image, mo/lib.rs:128) to host; *sw, *sh receive its size. */
+int32_t     slideo_matcher_get_page_small(const slideo_matcher* m, int32_t page_idx, uint8_t* out, int64_t out_capacity,
+                                          int32_t* sw, int32_t* sh);
+
 /* Replaces FlannMatcher::new (mo/flann.rs:65-71; add :28-34, train :45-47):
  * freezes the page descriptor set into the device-resident train matrix. */
 int32_t     slideo_matcher_finalize_pages(slideo_matcher* m);
@@ -228,6 +241,10 @@ int32_t     slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames,
                                            int32_t stride_bytes, int64_t frame_stride_bytes,
                                            void* hip_stream, int64_t* ticket_out);
 int32_t     slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out);
+/* The same, and the unit's verdict records are also left in caller-provided DEVICE memory (n_frames records of
+ * slideo_verdict, complete when the call returns): what a multi-GPU caller hands to its one all-gather of verdicts
+ *  without a host round trip.  verdicts_dev_out may be NULL. */
+int32_t     slideo_match_frames_collect_dev(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out, void* verdicts_dev_out);
 
 /* Replaces MarkSimilarIter (mo/video_capture.rs:86-98) for a run of sampled
  * frames in host memory: changed[i] = 1 iff similarity(small(frame i-1),

@@ -53,7 +53,8 @@ EXPORTS = [
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_knn_l2_u8", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
-    "slideo_match_frames_submit_dev", "slideo_match_frames_collect",
+    "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
+    "slideo_matcher_add_page_features", "slideo_matcher_get_page_small",
 ]
 
 _lib = None
@@ -156,6 +157,24 @@ class Matcher:
         s = (C.c_int32 * n)(*[p.shape[1] * 3 for p in pages])
         self._check(lib().slideo_matcher_add_pages_bgr8(self._h, n, ptrs, w, h, s))
 
+    def page_small(self, page):
+        """Small image of a page (to_small_image), as slideo_matcher_get_page_small returns it."""
+        sw = C.c_int32(); sh = C.c_int32()
+        rc = lib().slideo_matcher_get_page_small(self._h, page, None, C.c_int64(1 << 40), C.byref(sw), C.byref(sh))
+        self._check(rc)
+        out = np.empty((sh.value, sw.value, 3), np.uint8)
+        self._check(lib().slideo_matcher_get_page_small(self._h, page, _p(out), C.c_int64(out.size), C.byref(sw), C.byref(sh)))
+        return out
+
+    def add_page_features(self, width, height, kp, desc, small):
+        """A page analysed elsewhere (another rank's share of the deck, a cache): slideo_matcher_add_page_features."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        small = np.ascontiguousarray(small, np.uint8)
+        assert len(kp) == len(desc) and small.ndim == 3 and small.shape[2] == 3
+        self._check(lib().slideo_matcher_add_page_features(self._h, int(width), int(height), len(kp), _p(kp), _p(desc), _p(small),
+                                                           small.shape[1], small.shape[0]))
+
     def finalize(self):
         self._check(lib().slideo_matcher_finalize_pages(self._h))
 
@@ -210,10 +229,11 @@ class Matcher:
                                                          C.c_int64(frame_stride), C.c_void_p(stream), C.byref(t)))
         return (t.value, n)
 
-    def collect(self, ticket):
+    def collect(self, ticket, dev_out=0):
+        """dev_out: optional device pointer that also receives the n verdict records (16 bytes each)."""
         t, n = ticket
         out = np.zeros(n, VERDICT_DTYPE)
-        self._check(lib().slideo_match_frames_collect(self._h, C.c_int64(t), _p(out)))
+        self._check(lib().slideo_match_frames_collect_dev(self._h, C.c_int64(t), _p(out), C.c_void_p(dev_out or None)))
         return out
 
     def last_candidates(self, frame_in_batch):

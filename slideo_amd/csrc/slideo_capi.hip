@@ -925,6 +925,39 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
     API_CATCH(m)
 }
 
+int32_t slideo_matcher_add_page_features(slideo_matcher* m, int32_t width, int32_t height, int32_t n_keypoints, const slideo_keypoint* kp,
+                                         const uint8_t* desc32, const uint8_t* small_bgr, int32_t small_w, int32_t small_h) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (m->finalized) fail(SLIDEO_ERR_STATE, "pages cannot be added after finalize");
+    if (n_keypoints < 0 || (n_keypoints > 0 && (!kp || !desc32)) || !small_bgr) fail(SLIDEO_ERR_INVALID_ARG, "null page feature arrays");
+    validate_image(width, height, width * 3);
+    HIP_CHECK(hipSetDevice(m->device));
+    const int ac = area_class_for(m, width, height);              // (also checks that the page is large enough for to_small_image)
+    if (small_w != m->area_geoms[ac].dw || small_h != m->area_geoms[ac].dh)
+        fail(SLIDEO_ERR_INVALID_ARG, "small image %dx%d is not the to_small_image size %dx%d of a %dx%d page", small_w, small_h,
+             m->area_geoms[ac].dw, m->area_geoms[ac].dh, width, height);
+    HostPage pg;
+    pg.w = width; pg.h = height; pg.sw = small_w; pg.sh = small_h; pg.area_idx = ac;
+    pg.kp.assign(kp, kp + n_keypoints);
+    pg.desc.assign(desc32, desc32 + (size_t)n_keypoints * 32);
+    pg.small_img.assign(small_bgr, small_bgr + (size_t)small_w * small_h * 3);
+    m->pages.push_back(std::move(pg));
+    API_CATCH(m)
+}
+
+int32_t slideo_matcher_get_page_small(const slideo_matcher* cm, int32_t page_idx, uint8_t* out, int64_t out_capacity, int32_t* sw, int32_t* sh) {
+    slideo_matcher* m = const_cast<slideo_matcher*>(cm);
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (page_idx < 0 || page_idx >= (int)m->pages.size() || !sw || !sh) fail(SLIDEO_ERR_INVALID_ARG, "page %d out of range", page_idx);
+    const HostPage& pg = m->pages[page_idx];
+    *sw = pg.sw; *sh = pg.sh;
+    if ((int64_t)pg.small_img.size() > out_capacity) fail(SLIDEO_ERR_CAPACITY, "small image needs %zu bytes", pg.small_img.size());
+    if (out) std::memcpy(out, pg.small_img.data(), pg.small_img.size());
+    API_CATCH(m)
+}
+
 int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
@@ -1038,7 +1071,7 @@ int32_t slideo_match_frames_submit_dev(slideo_matcher* m, int32_t n_frames, cons
     API_CATCH(m)
 }
 
-int32_t slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out) {
+int32_t slideo_match_frames_collect_dev(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out, void* verdicts_dev_out) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
     if (!verdicts_out) fail(SLIDEO_ERR_INVALID_ARG, "null verdicts_out");
@@ -1048,7 +1081,15 @@ int32_t slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_ve
     if (!S) fail(SLIDEO_ERR_STATE, "ticket %lld is not in flight", (long long)ticket);
     for (Slot& c : m->slots) if (c.busy && c.ticket < ticket) fail(SLIDEO_ERR_STATE, "collect ticket %lld first (in order)", (long long)c.ticket);
     unit_collect(m, *S, verdicts_out);
+    if (verdicts_dev_out) {           // (after the collect: a unit re-run through the exact-size path has rewritten d_verdicts)
+        HIP_CHECK(hipMemcpyAsync(verdicts_dev_out, S->d_verdicts.p, (size_t)S->n * sizeof(slideo_verdict), hipMemcpyDeviceToDevice, S->st));
+        HIP_CHECK(hipStreamSynchronize(S->st));
+    }
     API_CATCH(m)
+}
+
+int32_t slideo_match_frames_collect(slideo_matcher* m, int64_t ticket, slideo_verdict* verdicts_out) {
+    return slideo_match_frames_collect_dev(m, ticket, verdicts_out, nullptr);
 }
 
 int32_t slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_batch, slideo_candidate* out, int32_t capacity,

@@ -79,3 +79,33 @@ def timeline(verdicts, times_s, frame_idx, total_time_s, total_frames, changed=N
         last = r[2]
         out.append(r)
     return out
+
+
+def build_page_db_sharded(make_matcher, pages, rank, world):
+    """Page-sharded build of the page DB: rank r analyses pages [lo, hi) of the deck on its GPU, the
+    ranks all-gather the per-page records (size, keypoints, descriptors, small image) and every rank assembles the whole
+    DB, in page order, from the records (slideo_matcher_add_page_features).  ProcessedImage::compute is independent per page
+    (crates/matching-opencv/src/lib.rs:45-47), so the result equals the redundant build bit for bit.
+    make_matcher(): a fresh Matcher with the run's config.  Returns the finalized matcher."""
+    import torch.distributed as dist
+    lo, hi = shard_range(len(pages), rank, world)
+    recs = []
+    if hi > lo:
+        part = make_matcher()
+        for i in range(lo, hi, 50):
+            part.add_pages(list(pages[i:min(hi, i + 50)]))
+        for j in range(hi - lo):
+            kp, desc = part.page_features(j)
+            recs.append((int(pages[lo + j].shape[1]), int(pages[lo + j].shape[0]), kp, desc, part.page_small(j)))
+        part.close()
+    allrecs = [None] * world
+    if world > 1:
+        dist.all_gather_object(allrecs, recs)
+    else:
+        allrecs = [recs]
+    m = make_matcher()
+    for r in range(world):
+        for w, h, kp, desc, small in allrecs[r]:
+            m.add_page_features(w, h, kp, desc, small)
+    m.finalize()
+    return m

@@ -48,3 +48,28 @@ def test_two_ranks_control_flow_over_gloo():
         assert k in j, k
     assert j["n_gpus"] == 2 and j["steps"] == 2 and "cpu_baseline" not in j       # the CPU leg runs at N=1 only
     assert j["config"]["frames_per_step_per_gpu"] == 16 and j["value"] > 0
+    assert j["config"]["collective"] == {"backend": "gloo", "all_gather_of_verdicts_checked": True}
+
+
+def test_rccl_path_executes_on_one_gpu():
+    """The driver's multi-GPU runs use the nccl (= RCCL) backend; on a single-GPU box that code — init_process_group("nccl"),
+    the library writing the verdict records into the gather's DEVICE input, all_gather_into_tensor on the device, the
+    max-over-ranks all_reduce — is executed at world size 1 under torchrun (SLIDEO_BENCH_FORCE_DIST=1)."""
+    env = dict(os.environ, SLIDEO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SLIDEO_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "tiny", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["config"]["collective"] == {"backend": "nccl", "all_gather_of_verdicts_checked": True}
+
+
+def test_strong_scaling_mode():
+    """--total-frames: a fixed job (BASELINE configs[3] is one) split over steps and GPUs; the line says "strong"."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "4", "--warmup", "1",
+                        "--total-frames", "96", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 24 and j["value"] > 0

@@ -213,3 +213,38 @@ def test_configs3_shape_lecture_two_ranks_one_gpu(capi, synth):
     want, have = set(map(k, tt)), set(map(k, tl2))
     assert len(want - have) <= max(1, len(want) // 20) and len(have - want) <= max(1, len(want) // 20), (sorted(want - have), sorted(have - want))
     assert 0.02 < changed1.mean() < 0.5                                   # the mask removes most sampled frames
+
+
+def test_page_db_from_imported_features_equals_direct_build(capi, synth):
+    """The page-sharded build of SURVEY 8e in one process: two 'ranks' analyse half the deck each, the records are imported in
+    page order (slideo_matcher_add_page_features) — the assembled matcher equals the one that analysed every page itself."""
+    from slideo_amd import distributed as D
+    pages = synth.pages(12, 800, 450)
+    frames, truth, _ = synth.frames(pages, 10, 640, 360)
+    mk = lambda: capi.Matcher(capi.default_config(nfeatures=500, min_rating=12.0))
+    direct = mk(); direct.add_pages(list(pages)); direct.finalize()
+    recs = []
+    for r in range(2):
+        lo, hi = D.shard_range(12, r, 2)
+        part = mk(); part.add_pages(list(pages[lo:hi]))
+        for j in range(hi - lo):
+            kp, desc = part.page_features(j)
+            recs.append((800, 450, kp, desc, part.page_small(j)))
+        part.close()
+    imp = mk()
+    for w, h, kp, desc, small in recs:
+        imp.add_page_features(w, h, kp, desc, small)
+    imp.finalize()
+    assert imp.page_count == direct.page_count == 12 and imp.descriptor_count == direct.descriptor_count
+    for p in (0, 5, 11):
+        a, b = imp.page_features(p), direct.page_features(p)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(imp.page_small(p), direct.page_small(p))
+    va, vb = imp.match_frames(frames), direct.match_frames(frames)
+    assert np.array_equal(va, vb) and (va["page_idx"] == truth).mean() >= 0.8
+    # the one-call form (world 1: no collective)
+    m1 = D.build_page_db_sharded(mk, pages, 0, 1)
+    assert np.array_equal(m1.match_frames(frames), vb)
+    with pytest.raises(capi.SlideoError):
+        imp2 = mk(); imp2.add_page_features(800, 450, recs[0][2], recs[0][3], recs[0][4][:10])
+    for x in (direct, imp, m1):
+        x.close()
