@@ -50,6 +50,26 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0   # dense FP4/FP6 MFMA peak (MI355X_MICROARCH.md;
 LANEOPS_PER_PAIR = 16          # 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 per 256-bit pair
 
 
+def host_cpu_budget():
+    """CPUs this process may really use: logical CPUs, scheduler affinity, cgroup CPU quota (v2 cpu.max, v1 cfs_quota)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    usable = aff if quota is None else max(1, min(aff, int(round(quota))))
+    return {"logical": os.cpu_count() or 1, "affinity": aff, "cgroup_quota_cpus": quota, "usable": usable}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,7 +294,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
         ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"])
-        cores = ncpu
+        budget = host_cpu_budget()
+        cores = max(1, min(ncpu, budget["usable"]))
         db = pyoracle.PageDB(ocfg)
         t0 = time.time()
         db.add_pages(pages, threads=cores)
@@ -303,7 +324,9 @@ def main():
                                "what": "exact brute-force restatement of the same path (oracle/: cache-blocked Hamming k-NN, %s); the reference's own CPU path searches a FLANN-LSH index instead (mo/flann.rs:16-21) and could not be built or timed here" % ("AVX-512 VPOPCNTDQ" if simd else "scalar popcnt"),
                                "single_thread": {"value": round(rate_1, 4), "unit": "frames/s", "cores": 1, "sample": "%d frames" % n1},
                                "thread_scaling": {"speedup": round(rate_n / rate_1, 1), "efficiency": round(rate_n / rate_1 / used, 3),
-                                                  "note": "%d threads on %d hardware threads (SMT siblings share a core's vector units)" % (used, cores)}}
+                                                  "host": budget,
+                                                  "note": "%d threads; the host shows %d logical CPUs, the scheduler affinity %d, the cgroup quota %s "
+                                                          "(SMT siblings share a core's vector units)" % (used, ncpu, budget["affinity"], budget["cgroup_quota_cpus"])}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     m.close()

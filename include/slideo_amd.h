@@ -23,6 +23,18 @@
  *   - a matcher is NOT re-entrant: calls on one handle must come from one thread at
  *     a time (the reference's caller is single threaded, crates/app/src/main.rs:77-93,
  *     and parallelism lives inside the call); different handles are independent.
+ *
+ * Limits (each is checked; beyond it the call fails with SLIDEO_ERR_UNSUPPORTED and says which one — nothing is clamped):
+ *   image width / height   1..4096        x and y of a FAST candidate travel packed in 12 bits each (geom.h MAX_DIM); the
+ *                                         reference's inputs are <= 1920x1080 video frames and 2001x1125 renders, the 4K
+ *                                         config is 3840x2160
+ *   train descriptors      < 2^23         a k-NN key is distance << 23 | row; 500 pages x ~1850 = 0.92 M rows, 4000 pages fit
+ *   pages                  <= 16384       the vote kernel keeps one counter per page in LDS
+ *   knn_k                  1..32          the per-query list lives in registers (the reference uses 30)
+ *   max_candidate_pages    1..64, max_rated 1..16, nlevels 1..16, ransac_max_iters 1..1000000
+ *   NOT limits: keypoints per frame (beyond 8192 the canonical sort moves from LDS to global memory; a frame beyond the
+ *   capacity the asynchronous path provides for is re-run through the exact-size path), the RANSAC sample schedule (the
+ *   pre-drawn cv::RNG stream is extended on demand), frames per call (cut into units that fit the workspace budget).
  */
 #ifndef SLIDEO_AMD_H
 #define SLIDEO_AMD_H

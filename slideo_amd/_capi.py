@@ -280,11 +280,16 @@ class Matcher:
         bgr = _img3(bgr)
         h, w, _ = bgr.shape
         cap = cap or 8192
-        kp = np.zeros(cap, KEYPOINT_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
-        n = C.c_int32()
-        self._check(lib().slideo_orb_bgr8(self._h, _p(bgr), w, h, w * 3, _p(kp), _p(desc), cap, C.byref(n)))
-        return kp[: n.value].copy(), desc[: n.value].copy()
+        while True:
+            kp = np.zeros(cap, KEYPOINT_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            n = C.c_int32()
+            rc = lib().slideo_orb_bgr8(self._h, _p(bgr), w, h, w * 3, _p(kp), _p(desc), cap, C.byref(n))
+            if rc == 7 and n.value > cap:                  # SLIDEO_ERR_CAPACITY: *n_out holds the number found
+                cap = n.value
+                continue
+            self._check(rc)
+            return kp[: n.value].copy(), desc[: n.value].copy()
 
     def pyramid_level(self, bgr, level, blurred):
         bgr = _img3(bgr)

@@ -20,8 +20,8 @@ constexpr int MAX_DIM = 4096;            // x,y packed in 12 bits each
 constexpr int FAST_TW = 126, FAST_TH = 32; // FAST tile (outputs); + 1-px score halo = 128 x 34 score positions
 constexpr int BLUR_RH = 56;                // blur: output rows per wave (multiple of 7: the register ring of blur_kernel; and of 8: four row pairs per round of blur_f32_kernel)
 constexpr int BLUR_TW = 248, BLUR_TH = 4 * BLUR_RH;  // blur tile (outputs) per 256-thread block: 62 inner lanes x 4 px, 4 waves stacked
-constexpr int KP_CAP_PER_FRAME = 8192;     // sort capacity (LDS), loud error beyond
-constexpr int RNG_TABLE = 16384;           // pre-drawn cv::RNG outputs for RANSAC
+constexpr int KP_SORT_LDS = 8192;          // items the in-LDS canonical sort holds (64 KB); larger frames sort in global memory
+constexpr int RNG_TABLE_MIN = 16384;       // pre-drawn cv::RNG outputs for RANSAC: at least this many, 4 per iteration + slack; grown on demand
 
 struct LevelGeom {
     int32_t w, h, pitch;       // level image
@@ -193,7 +193,7 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (!(c.ratio_test >= 0.f) || (c.ratio_test > 0.f && c.knn_k < 2)) { *why = "ratio_test must be >= 0 and needs knn_k >= 2"; return false; }
     if (c.max_candidate_pages < 1 || c.max_candidate_pages > 64) { *why = "max_candidate_pages must be 1..64"; return false; }
     if (c.max_rated < 1 || c.max_rated > 16) { *why = "max_rated must be 1..16"; return false; }
-    if (c.ransac_max_iters < 1 || c.ransac_max_iters > 5000) { *why = "ransac_max_iters must be 1..5000"; return false; }
+    if (c.ransac_max_iters < 1 || c.ransac_max_iters > 1000000) { *why = "ransac_max_iters must be 1..1000000"; return false; }
     if (c.small_area < 64) { *why = "small_area too small"; return false; }
     // OpenCV-variant switches: the values this library implements ([hip] in slideo_amd.h)
     const slideo_ocv_variants& o = c.ocv;

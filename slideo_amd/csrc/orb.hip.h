@@ -713,7 +713,6 @@ __global__ void threshold_kernel(PyrGeom g, const uint32_t* __restrict__ hist, c
         for (int i = 0; i < g.nlevels; ++i) { lvl_ofs[(size_t)f * g.nlevels + i] = o; o += kept_s[i]; }
         if (o > kp_cap) { atomicOr(flags, 8u); o = 0; }
         kp_count[f] = o;
-        if (o > (uint32_t)KP_CAP_PER_FRAME) atomicOr(flags, 2u);
     }
 }
 
@@ -770,7 +769,7 @@ __global__ __launch_bounds__(1024) void sort_kernel(const uint32_t* __restrict__
     extern __shared__ __attribute__((aligned(16))) uint64_t sbuf[];
     const int f = blockIdx.x;
     const uint32_t o = qofs[f], n = qofs[f + 1] - o;
-    if (n <= 1) return;
+    if (n <= 1 || n > (uint32_t)npow2) return;        // n > npow2 (= KP_SORT_LDS): sort_global_kernel's frame
     int np = 2;
     while ((uint32_t)np < n) np <<= 1;     // np <= npow2
     for (int i = threadIdx.x; i < np; i += 1024) sbuf[i] = (uint32_t)i < n ? items[o + i] : ~0ull;
@@ -788,6 +787,41 @@ __global__ __launch_bounds__(1024) void sort_kernel(const uint32_t* __restrict__
             __syncthreads();
         }
     for (uint32_t i = threadIdx.x; i < n; i += 1024) items[o + i] = sbuf[i];
+}
+
+// Frames with more items than the LDS sort holds (nfeatures in the thousands, or a flood of ties at a retainBest
+// threshold): the bitonic network run in place on the frame's items in global memory (they stay in L2).  The variant
+// whose comparisons all point the same way — each merge starts with a "flip" (t <-> k-1-t inside a block of k) and
+// continues with half-cleaners — so the tail up to the next power of two can stay virtual: a partner index >= n stands
+// for +infinity and its compare-exchange is a no-op.  grid B, block 1024; a frame with n <= lds_cap exits at once.
+__global__ __launch_bounds__(1024) void sort_global_kernel(const uint32_t* __restrict__ qofs, uint64_t* __restrict__ items, uint32_t lds_cap) {
+    const int f = blockIdx.x;
+    const uint32_t o = qofs[f], n = qofs[f + 1] - o;
+    if (n <= lds_cap) return;
+    uint64_t* a = items + o;
+    uint32_t np = 2;
+    while (np < n) np <<= 1;
+    auto cmpx = [&](uint32_t lo, uint32_t hi) {
+        if (hi < n) {
+            const uint64_t x = a[lo], y = a[hi];
+            if (x > y) { a[lo] = y; a[hi] = x; }
+        }
+    };
+    for (uint32_t k = 2; k <= np; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t i = threadIdx.x; i < np / 2; i += 1024) {
+            const uint32_t base = (i / hk) * k, t = i % hk;
+            cmpx(base + t, base + k - 1 - t);
+        }
+        __syncthreads();
+        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np / 2; i += 1024) {
+                const uint32_t lo = (i / j) * 2 * j + (i % j);
+                cmpx(lo, lo + j);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

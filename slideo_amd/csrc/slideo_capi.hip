@@ -97,6 +97,7 @@ struct slideo_matcher {
     size_t ws_budget = (size_t)48 << 30;      // all slots together (SLIDEO_WS_GB); 288 GB of HBM per GPU
 
     DevBuf d_tables, d_rng, d_ictab;
+    uint32_t rng_len = 0;
     int ic_shift = 0, ic_entries = 0;     // intensity-centroid weight table of describe_kernel (geom.h ic_weight_table)
     std::vector<std::unique_ptr<GeomEntry>> geoms;
 
@@ -288,9 +289,6 @@ void orb_wait_info(slideo_matcher* m, Slot& S) {
     HIP_CHECK(hipStreamSynchronize(S.st));
     const uint32_t qtot = S.h_info.as<uint32_t>()[0], maxc = S.h_info.as<uint32_t>()[1], fl = S.h_info.as<uint32_t>()[2];
     if (fl & 1u) fail(SLIDEO_ERR_HIP, "internal: FAST candidate list overflow");
-    if (fl & 2u)
-        fail(SLIDEO_ERR_CAPACITY, "a frame produced %u keypoints (ties at the retainBest threshold are kept, as in OpenCV); the in-LDS canonical sort holds %d",
-             maxc, KP_CAP_PER_FRAME);
     S.orb.qtot = qtot; S.orb.max_count = maxc;
 }
 
@@ -312,9 +310,13 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h, bool by_capacity = fal
                                                S.d_lvlofs.as<uint32_t>(), S.d_qofs.as<uint32_t>(), cursor, S.d_items.as<uint64_t>());
     check_launch("compact_kernel");
     int np2 = 2;
-    while ((uint32_t)np2 < maxc) np2 <<= 1;
+    while ((uint32_t)np2 < maxc && np2 < KP_SORT_LDS) np2 <<= 1;
     sort_kernel<<<n, 1024, (size_t)np2 * 8, st>>>(S.d_qofs.as<uint32_t>(), S.d_items.as<uint64_t>(), np2);
     check_launch("sort_kernel");
+    if (maxc > (uint32_t)np2) {                       // only reachable through the exact-size path (kp_cap_for <= KP_SORT_LDS)
+        sort_global_kernel<<<n, 1024, 0, st>>>(S.d_qofs.as<uint32_t>(), S.d_items.as<uint64_t>(), (uint32_t)np2);
+        check_launch("sort_global_kernel");
+    }
     if (blur_is_f32(m)) {
         describe_blurred_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
                                                                     S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot_arg,
@@ -532,9 +534,20 @@ void validate_image(int w, int h, int stride) {
 // `frames_dev` must stay valid until the unit is collected (reproject reads the frames).
 // keypoints per frame the capacity-sized path provides for: twice the quota (ties at a level's retainBest threshold are kept, so
 // no finite bound is safe; a frame beyond it is detected on the device and the unit re-run through the exact-size path)
+// the cv::RNG((uint64)-1) stream RANSACPointSetRegistrator draws its samples from, pre-drawn (ptsetreg.cpp: rng state
+// starts at -1 on every call, so every candidate reads the same stream from position 0)
+void upload_rng_stream(slideo_matcher* m, uint32_t len) {
+    std::vector<uint32_t> rng(len);
+    CvRng r((uint64_t)-1, m->cfg.ocv.rng_mul);
+    for (auto& v : rng) v = r.next();
+    m->d_rng.reserve(rng.size() * 4);
+    HIP_CHECK(hipMemcpy(m->d_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
+    m->rng_len = len;
+}
+
 uint32_t kp_cap_for(const slideo_matcher* m, const PyrGeom& g) {
     int cap = std::max(2 * m->cfg.nfeatures, m->cfg.nfeatures + 1024);
-    cap = std::min(cap, KP_CAP_PER_FRAME);
+    cap = std::min(cap, KP_SORT_LDS);
     return (uint32_t)std::max(1, std::min(cap, std::max(g.cand_per_frame, 1)));
 }
 
@@ -574,7 +587,8 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     orb_stage2(m, S, w, h, async);
     HIP_CHECK(hipEventRecord(S.ev_orb, st));
     m->last_orb_ev = S.ev_orb;
-    const VerifyParams vp = make_vp(c);
+    VerifyParams vp = make_vp(c);
+    vp.rng_len = m->rng_len;
     const int P = (int)m->pages.size();
     HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
     uint32_t* flags = S.d_flags.as<uint32_t>();   // zeroed by orb_stage1
@@ -657,7 +671,16 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
         }
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
     }
-    if (fl & 4u) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded the %d pre-drawn RNG outputs", RNG_TABLE);
+    if (fl & 4u) {
+        // a candidate's sample schedule (2 draws per iteration + the redraws of equal pairs) ran past the pre-drawn stream: draw
+        // four times as much and run the unit again.  (Other units may be reading the table: drain the device first.)
+        if (m->rng_len >= (1u << 26)) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded %u pre-drawn RNG outputs", m->rng_len);
+        HIP_CHECK(hipDeviceSynchronize());
+        upload_rng_stream(m, m->rng_len * 4);
+        unit_submit(m, S, S.u_frames, n, S.u_w, S.u_h, S.u_stride, S.u_fs, false);
+        unit_collect(m, S, out_host);
+        return;
+    }
     std::memcpy(out_host, ho, (size_t)n * sizeof(slideo_verdict));
     const size_t base = m->last_fcs.size();
     m->last_fcs.resize(base + n);
@@ -807,11 +830,11 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         mm->d_ictab.reserve(ict.size() * 4);
         HIP_CHECK(hipMemcpy(mm->d_ictab.p, ict.data(), ict.size() * 4, hipMemcpyHostToDevice));
     }
-    std::vector<uint32_t> rng(RNG_TABLE);
-    CvRng r((uint64_t)-1, cfg->ocv.rng_mul);
-    for (auto& v : rng) v = r.next();
-    mm->d_rng.reserve(rng.size() * 4);
-    HIP_CHECK(hipMemcpy(mm->d_rng.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
+    {
+        int64_t len = std::max<int64_t>(RNG_TABLE_MIN, 4ll * std::max(cfg->ransac_max_iters, 1) + 1024);
+        if (const char* e = getenv("SLIDEO_RNG_STREAM_LEN")) len = std::max<int64_t>(512, atoll(e));     // tests: force the growth path
+        upload_rng_stream(mm.get(), (uint32_t)std::min<int64_t>(len, 1ll << 26));
+    }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   describe_window(cfg->patch_size / 2).dwords * 16));

@@ -63,6 +63,7 @@ struct VerifyParams {
     float tol, min_similarity, ratio;       // ratio > 0: ratio test instead of the tolerance vote
     double thr, conf, min_rating, min_rating_ratio;
     int32_t max_iters, refine_iters;
+    uint32_t rng_len;                       // entries of the pre-drawn cv::RNG stream (grown on demand by the host)
 };
 
 // ---------------------------------------------------------------------------
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
         uint32_t pos = 0;
         for (int base = 0; base < niters; base += 64) {
             // sample schedule: cv::RNG((uint64)-1) stream, idx = next() % count, second index redrawn while equal
-            if (pos + 4 * 64 + 64 > (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
+            if (pos + 4 * 64 + 64 > vp.rng_len) { if (lane == 0) atomicOr(flags, 4u); break; }
             uint32_t a = rng_tab[pos + 2 * lane] % (uint32_t)count;
             uint32_t b = rng_tab[pos + 2 * lane + 1] % (uint32_t)count;
             if (__builtin_amdgcn_ballot_w64(a == b) == 0ull) pos += 128;
@@ -328,11 +329,11 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
                 uint32_t shift = 0, total = 0;
                 for (;;) {
                     const uint32_t p0 = pos + 2 * lane + shift;
-                    const uint32_t i0 = rng_tab[min(p0, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count;
+                    const uint32_t i0 = rng_tab[min(p0, vp.rng_len - 1)] % (uint32_t)count;
                     uint32_t e = 0, i1;
                     for (;;) {
-                        i1 = rng_tab[min(p0 + 1 + e, (uint32_t)RNG_TABLE - 1)] % (uint32_t)count;
-                        if (i1 != i0 || p0 + 1 + e >= (uint32_t)RNG_TABLE - 1) break;
+                        i1 = rng_tab[min(p0 + 1 + e, vp.rng_len - 1)] % (uint32_t)count;
+                        if (i1 != i0 || p0 + 1 + e >= vp.rng_len - 1) break;
                         ++e;
                     }
                     uint32_t inc = e;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
                     if (__builtin_amdgcn_ballot_w64(changed) == 0ull) { a = i0; b = i1; total = __shfl(inc, 63); break; }
                 }
                 pos += 128 + total;
-                if (pos >= (uint32_t)RNG_TABLE) { if (lane == 0) atomicOr(flags, 4u); break; }
+                if (pos >= vp.rng_len) { if (lane == 0) atomicOr(flags, 4u); break; }
             }
             double M[6];
             similarity_from_2(pts[a], pts[b], M);

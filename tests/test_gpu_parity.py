@@ -646,3 +646,41 @@ def test_ratio_test_mode_matches_oracle(capi, oracle, cfg0_data, ratio):
         assert a["n_votes"].sum() <= b["n_votes"].sum()
         assert a["n_votes"].sum() <= v["n_keypoints"][i]
     m.close(); m2.close()
+
+
+# ---- capacity: nothing on the path stops at a fixed table size -------------------------------
+
+def test_orb_more_keypoints_than_the_lds_sort_holds(capi, oracle):
+    """nfeatures 12000 on a busy image: > 8192 keypoints in one frame -> the canonical sort runs in global memory
+    (sort_global_kernel); the result is still the oracle's, keypoint for keypoint."""
+    rng = np.random.default_rng(5)
+    img = np.kron(rng.integers(0, 256, (220, 400), dtype=np.uint8), np.ones((7, 7), np.uint8))
+    img = np.ascontiguousarray(np.repeat(img[:, :, None], 3, 2))
+    m = capi.Matcher(capi.default_config(nfeatures=12000))
+    n = _cmp_orb(capi, oracle, m, oracle.default_config(nfeatures=12000), img)
+    assert n > 8192, n
+    m.close()
+    # and through the batched path (a distance-0 best match casts no vote: d < 0 * 1.05 never holds, lib.rs:275 — so the
+    # frame is the page with noise); the verdicts are the oracle's
+    noisy = np.clip(img.astype(np.int16) + rng.integers(-12, 13, img.shape), 0, 255).astype(np.uint8)
+    both = np.stack([noisy, img[::-1].copy()])
+    m2, db = _build_both(capi, oracle, capi.default_config(nfeatures=12000, min_rating=10.0),
+                         oracle.default_config(nfeatures=12000, min_rating=10.0), [img])
+    v = m2.match_frames(both)
+    _compare_traces(m2, db, both, v)
+    assert v["page_idx"][0] == 0
+    m2.close()
+
+
+def test_ransac_rng_stream_grows_on_demand(capi, oracle, cfg0_data, monkeypatch):
+    """The pre-drawn cv::RNG stream starts far too short for 2000 iterations (512 entries): the unit that runs past it is
+    re-run with a stream 4x as long until it fits, and the verdicts are the oracle's."""
+    pages, frames, truth, _ = cfg0_data
+    monkeypatch.setenv("SLIDEO_RNG_STREAM_LEN", "512")
+    m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
+    monkeypatch.delenv("SLIDEO_RNG_STREAM_LEN")
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    assert list(v["page_idx"]) == list(truth)
+    assert np.array_equal(m.match_frames(frames), v)                  # and again, the stream now long enough
+    m.close()
