@@ -37,6 +37,11 @@ WORKLOADS = {
     # BASELINE.json configs[4] shape on one GPU: 4K frames, ORB-2000, 1000-page deck (2 M train descriptors)
     "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64,
                  name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000"),
+    # BASELINE.json configs[2]: SIFT-128 descriptors, L2 BFMatcher as an N x M x 128 MFMA contraction, 1080p vs 500 pages.
+    # The k-NN stage only (bench_cfg2): there is no SIFT extractor on the device, so the descriptor
+    # sets are synthetic SIFT-shaped u8 vectors of the sizes the ORB path produces (1000 per frame, ~1850 per page).
+    "cfg2": dict(frame=(1920, 1080), page=(2001, 1125), pages=500, nfeatures=1000, batch=256, per_page=1850, knn_k=2,
+                 name="configs[2]: L2 k-NN stage, 256 frames x 1000 SIFT-128 (u8) descriptors vs 500 pages x 1850, k=2 (ratio-test shape)"),
     # small, for smoke runs
     "tiny": dict(frame=(640, 360), page=(800, 450), pages=8, nfeatures=500, batch=16,
                  name="tiny: 640x360 vs 8 pages, ORB-500"),
@@ -68,6 +73,80 @@ def host_cpu_budget():
             pass
     usable = aff if quota is None else max(1, min(aff, int(round(quota))))
     return {"logical": os.cpu_count() or 1, "affinity": aff, "cgroup_quota_cpus": quota, "usable": usable}
+
+
+MFMA_I8_PEAK_TOPS = 5000.0       # dense int8 MFMA peak (2x the ~2.5 PF bf16 rate; the guide's microbenchmark reaches >= 3944)
+
+
+def sift_like(rng, n):
+    """OpenCV-SIFT-shaped descriptors: non-negative, most mass in few bins, L2 norm ~512, clipped to 255."""
+    x = rng.gamma(0.6, 40.0, (n, 128)).astype(np.float32)
+    x *= 512.0 / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+
+
+def bench_cfg2(args, wl, rank, world, local_rank, use_dist, barrier_fn):
+    """configs[2]: the squared-L2 k-NN of SIFT-shaped descriptors on the int8 matrix cores (slideo_l2_knn_dev), train set prepared once,
+    queries resident in HBM.  A step = the descriptor sets of one batch of frames against the whole page set."""
+    import torch
+    import torch.distributed as dist
+    from slideo_amd import _capi
+    B, P, per_frame, per_page, k = wl["batch"], wl["pages"], wl["nfeatures"], wl["per_page"], wl["knn_k"]
+    nq, nt = B * per_frame, P * per_page
+    rng = np.random.default_rng(1234)
+    t = sift_like(rng, nt)                                         # same page set on every rank
+    q = sift_like(np.random.default_rng(99 + rank), nq)
+    q[::7] = np.clip(t[rng.integers(0, nt, len(q[::7]))].astype(np.int16) + rng.integers(-6, 7, (len(q[::7]), 128)), 0, 255).astype(np.uint8)
+    m = _capi.Matcher(_capi.default_config(), device=local_rank)
+    t0 = time.time(); m.l2_set_train(t); t_prep = time.time() - t0
+    d_q = torch.from_numpy(q).cuda()
+    d_idx = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    d_dist = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    kms = []
+    step = lambda: kms.append(m.l2_knn_dev(d_q.data_ptr(), nq, k, d_idx.data_ptr(), d_dist.data_ptr()))
+    for _ in range(args.warmup):
+        step()
+    kms.clear()
+    barrier_fn()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_fn()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        td = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td.item())
+    # checker (outside the timed region): a sample of queries against a numpy recomputation of the exact squared distances
+    idx = d_idx.cpu().numpy(); dd = d_dist.cpu().numpy().view(np.uint32)
+    sample = np.random.default_rng(5).integers(0, nq, 64)
+    ok = True
+    for i in sample:
+        diff = t.astype(np.int32) - q[i].astype(np.int32)
+        d2 = (diff * diff).sum(1)
+        order = np.lexsort((np.arange(nt), d2))[:k]
+        ok &= bool(np.array_equal(order, idx[i]) and np.array_equal(d2[order].astype(np.uint32), dd[i]))
+    assert ok, "L2 k-NN disagrees with the numpy recomputation"
+    ms = 1e3 * dt / args.steps
+    kavg = float(np.mean(kms))
+    pairs = float(nq) * nt
+    out = {
+        "metric": "frames/sec matched (L2 k-NN stage, SIFT-128)", "value": round(B * world * args.steps / dt, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+        "config": {"workload": wl["name"], "pages": P, "train_descriptors_M": nt, "frames_per_step_per_gpu": B,
+                   "query_descriptors_per_step": nq, "knn": "exact brute force squared L2, k=%d, v_mfma_i32_32x32x32_i8" % k,
+                   "stage": "k-NN only: no SIFT extractor on the device (SURVEY section 8f row N4); the reference has no float-descriptor path",
+                   "parallelism": "frames sharded over %d GPU(s), train set replicated" % world,
+                   "train_set_prepare_s": round(t_prep, 3), "checked_against_numpy": ok},
+        "roofline": {"kernel": "knn_l2_kernel", "bound": "mfma", "achieved": round(pairs * 256 / (kavg * 1e-3) / 1e12, 2),
+                     "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(pairs * 256 / (kavg * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                     "flops_per_pair": 256, "traffic": None, "avg_launch_ms": round(kavg, 4), "launches": len(kms),
+                     "pairs_per_launch": int(pairs), "interval": "knn_l2_kernel + unpack, HIP events on the launch stream"},
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    m.close()
 
 
 def main():
@@ -121,6 +200,15 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch: wl["batch"] = args.batch
     if args.pages: wl["pages"] = args.pages
+    if args.workload == "cfg2":
+        def _barrier():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+        bench_cfg2(args, wl, rank, world, local_rank, use_dist, _barrier)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     fw, fh = wl["frame"]; pw, ph = wl["page"]
     B, P = wl["batch"], wl["pages"]
     strong = args.total_frames > 0

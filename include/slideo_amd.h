@@ -334,6 +334,13 @@ int32_t     slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq,
 int32_t     slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
                              int32_t* idx_out, uint32_t* dist_out);
 
+/* The same search with the train set prepared once and kept on the device (what a SIFT matcher over a page DB would hold:
+ * the counterpart of FlannMatcher::new for float descriptors) and queries / results in device memory.  kernel_ms (may be
+ * null) receives the HIP-event time of the search kernels of this call.  bench.py --workload cfg2 times this. */
+int32_t     slideo_l2_set_train(slideo_matcher* m, const uint8_t* t, int32_t nt);
+int32_t     slideo_l2_knn_dev(slideo_matcher* m, const void* q_dev, int32_t nq, int32_t k, void* idx_dev /* i32 [nq*k] */,
+                              void* dist_dev /* u32 [nq*k] */, float* kernel_ms);
+
 /* to_small_image (mo/image_utils.rs:8-20) of one host image. */
 int32_t     slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
                                     int32_t height, int32_t stride_bytes, uint8_t* out,

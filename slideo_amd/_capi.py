@@ -54,7 +54,7 @@ EXPORTS = [
     "slideo_knn_hamming", "slideo_knn_l2_u8", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
-    "slideo_matcher_add_page_features", "slideo_matcher_get_page_small",
+    "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
 ]
 
 _lib = None
@@ -307,6 +307,16 @@ class Matcher:
         dist = np.empty((q.shape[0], k), np.uint16)
         self._check(lib().slideo_knn_hamming(self._h, _p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist)))
         return idx, dist
+
+    def l2_set_train(self, t):
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 128)
+        self._check(lib().slideo_l2_set_train(self._h, _p(t), t.shape[0]))
+
+    def l2_knn_dev(self, q_dev, nq, k, idx_dev, dist_dev):
+        """device pointers in, device pointers out; returns the search kernels' HIP-event time in ms"""
+        ms = C.c_float()
+        self._check(lib().slideo_l2_knn_dev(self._h, C.c_void_p(q_dev), nq, k, C.c_void_p(idx_dev), C.c_void_p(dist_dev), C.byref(ms)))
+        return ms.value
 
     def knn_l2_u8(self, q, t, k):
         """Exact squared-L2 k-NN of 128-dim u8 descriptors on the matrix cores (north-star extension, see the header)."""

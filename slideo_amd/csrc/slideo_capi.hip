@@ -97,6 +97,7 @@ struct slideo_matcher {
     size_t ws_budget = (size_t)48 << 30;      // all slots together (SLIDEO_WS_GB); 288 GB of HBM per GPU
 
     DevBuf d_tables, d_rng, d_ictab;
+    struct L2Set { DevBuf d_tx, d_tn, d_perm, d_keys, d_pend; int nt = 0, nt_pad = 0; bool ready = false; } l2;   // cfg2: the L2 train set
     uint32_t rng_len = 0;
     int ic_shift = 0, ic_entries = 0;     // intensity-centroid weight table of describe_kernel (geom.h ic_weight_table)
     std::vector<std::unique_ptr<GeomEntry>> geoms;
@@ -1259,6 +1260,86 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     API_CATCH(m)
 }
 
+// ---- L2 k-NN (cfg2): train set prepared once, queries from device memory ----
+void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
+    slideo_matcher::L2Set& L = m->l2;
+    const int nt_pad = knn_pad_rows(nt);
+    DevBuf d_t, d_norm;
+    d_t.reserve(std::max<size_t>((size_t)nt * 128, 64)); d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64));
+    L.d_tx.reserve((size_t)nt_pad * 128); L.d_tn.reserve((size_t)nt_pad * 4); L.d_perm.reserve((size_t)nt_pad * 4);
+    // norms on the device, the norm order on the host (a stable index sort), then the centred tile-major operand gathered in
+    // that order
+    std::vector<int32_t> h_norm((size_t)std::max(nt, 1)), h_perm((size_t)nt_pad, -1);
+    if (nt) {
+        HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
+        knl_norms_kernel<<<cdiv(nt, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, d_norm.as<int32_t>());
+        check_launch("knl_norms_kernel");
+        HIP_CHECK(hipMemcpyAsync(h_norm.data(), d_norm.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < nt; ++i) h_perm[i] = i;
+        std::stable_sort(h_perm.begin(), h_perm.begin() + nt, [&](int32_t a, int32_t b) { return h_norm[a] < h_norm[b]; });
+    }
+    HIP_CHECK(hipMemcpyAsync(L.d_perm.p, h_perm.data(), (size_t)nt_pad * 4, hipMemcpyHostToDevice, st));
+    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, L.d_perm.as<int32_t>(), d_norm.as<int32_t>(),
+                                                                   L.d_tx.as<uint4>(), L.d_tn.as<int32_t>());
+    check_launch("knl_expand_train_kernel");
+    HIP_CHECK(hipStreamSynchronize(st));            // d_t / d_norm / h_perm go out of scope
+    L.nt = nt; L.nt_pad = nt_pad; L.ready = true;
+}
+
+// queries on the device -> idx / dist on the device (m->d_tapidx / d_tapdist); kernel time between two events if asked for
+void l2_query(slideo_matcher* m, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed) {
+    slideo_matcher::L2Set& L = m->l2;
+    const int qblocks = cdiv(nq, KNL_QPB);
+    L.d_keys.reserve((size_t)nq * KLIST * 8); L.d_pend.reserve((size_t)qblocks * KT_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
+    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
+    if (timed) HIP_CHECK(hipEventRecord(S.ev[0], st));
+    const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
+    if (kl == 8)
+        knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+                                                          L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+    else if (kl == 16)
+        knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+                                                           L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+    else
+        knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+                                                              L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+    check_launch("knn_l2_kernel");
+    knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(L.d_keys.as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
+    check_launch("knl_unpack_kernel");
+    if (timed) HIP_CHECK(hipEventRecord(S.ev[1], st));
+}
+
+int32_t slideo_l2_set_train(slideo_matcher* m, const uint8_t* t, int32_t nt) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (nt < 0 || (nt && !t)) fail(SLIDEO_ERR_INVALID_ARG, "null train set");
+    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    l2_prepare(m, t, nt, m->slots[0].st);
+    API_CATCH(m)
+}
+
+int32_t slideo_l2_knn_dev(slideo_matcher* m, const void* q_dev, int32_t nq, int32_t k, void* idx_dev, void* dist_dev, float* kernel_ms) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!m->l2.ready) fail(SLIDEO_ERR_STATE, "slideo_l2_set_train must be called first");
+    if (nq < 0 || k < 1 || k > KLIST) fail(SLIDEO_ERR_INVALID_ARG, "bad nq/k (k must be 1..%d)", KLIST);
+    if (nq && (!q_dev || !idx_dev || !dist_dev)) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (nq == 0) return SLIDEO_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    l2_query(m, static_cast<const uint8_t*>(q_dev), nq, k, S.st, S, kernel_ms != nullptr);
+    HIP_CHECK(hipMemcpyAsync(idx_dev, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, S.st));
+    HIP_CHECK(hipMemcpyAsync(dist_dev, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, S.st));
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    if (kernel_ms) HIP_CHECK(hipEventElapsedTime(kernel_ms, S.ev[0], S.ev[1]));
+    API_CATCH(m)
+}
+
 int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
                          int32_t* idx_out, uint32_t* dist_out) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
@@ -1271,44 +1352,11 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     require_idle(m);
     Slot& S = m->slots[0];
     hipStream_t st = S.st;
-    const int nt_pad = knn_pad_rows(nt);
-    const int qblocks = cdiv(nq, KNL_QPB);
-    DevBuf d_q, d_t, d_tx, d_tn, d_norm, d_perm, d_keys, d_pend;
-    d_q.reserve((size_t)nq * 128); d_t.reserve(std::max<size_t>((size_t)nt * 128, 64));
-    d_tx.reserve((size_t)nt_pad * 128); d_tn.reserve((size_t)nt_pad * 4);
-    d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64)); d_perm.reserve((size_t)nt_pad * 4);
-    d_keys.reserve((size_t)nq * KLIST * 8); d_pend.reserve((size_t)qblocks * KT_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
+    l2_prepare(m, t, nt, st);
+    DevBuf d_q;
+    d_q.reserve((size_t)nq * 128);
     HIP_CHECK(hipMemcpyAsync(d_q.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
-    // train-set preparation (once per set; here per call, this being a tap): norms on the device, the norm order on the
-    // host (a stable index sort), then the centred tile-major operand gathered in that order
-    std::vector<int32_t> h_norm((size_t)std::max(nt, 1)), h_perm((size_t)nt_pad, -1);
-    if (nt) {
-        HIP_CHECK(hipMemcpyAsync(d_t.p, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
-        knl_norms_kernel<<<cdiv(nt, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, d_norm.as<int32_t>());
-        check_launch("knl_norms_kernel");
-        HIP_CHECK(hipMemcpyAsync(h_norm.data(), d_norm.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        for (int i = 0; i < nt; ++i) h_perm[i] = i;
-        std::stable_sort(h_perm.begin(), h_perm.begin() + nt, [&](int32_t a, int32_t b) { return h_norm[a] < h_norm[b]; });
-    }
-    HIP_CHECK(hipMemcpyAsync(d_perm.p, h_perm.data(), (size_t)nt_pad * 4, hipMemcpyHostToDevice, st));
-    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, d_perm.as<int32_t>(), d_norm.as<int32_t>(),
-                                                                   d_tx.as<uint4>(), d_tn.as<int32_t>());
-    check_launch("knl_expand_train_kernel");
-    const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
-    if (kl == 8)
-        knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
-                                                          d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
-    else if (kl == 16)
-        knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
-                                                           d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
-    else
-        knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(d_q.as<uint8_t>(), nq, d_tx.as<uint4>(), d_tn.as<int32_t>(), d_perm.as<int32_t>(), nt_pad,
-                                                              d_keys.as<unsigned long long>(), d_pend.as<unsigned long long>());
-    check_launch("knn_l2_kernel");
-    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
-    knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(d_keys.as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
-    check_launch("knl_unpack_kernel");
+    l2_query(m, d_q.as<uint8_t>(), nq, k, st, S, false);
     HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

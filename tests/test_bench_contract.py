@@ -73,3 +73,13 @@ def test_strong_scaling_mode():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 24 and j["value"] > 0
+
+
+def test_cfg2_l2_knn_line():
+    """--workload cfg2 (BASELINE configs[2]): the L2 k-NN stage on the int8 matrix cores, checked against numpy inside the run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--batch", "8", "--pages", "20",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["dtype"] == "i8" and j["roofline"]["bound"] == "mfma" and j["roofline"]["kernel"] == "knn_l2_kernel"
+    assert j["config"]["checked_against_numpy"] is True and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1

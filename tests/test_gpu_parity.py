@@ -539,6 +539,22 @@ def test_knn_l2_fewer_rows_than_k_and_unaligned(capi, oracle, mdef):
         assert (gi[:, min(nt, 30):] == -1).all()
 
 
+def test_knn_l2_prepared_set_device_queries(capi, oracle, mdef):
+    """slideo_l2_set_train + slideo_l2_knn_dev (train set kept on the device, queries and results in device memory) return what the
+    one-shot tap and the oracle return; a second query batch reuses the prepared set."""
+    import torch
+    rng = np.random.default_rng(21)
+    t = _sift_like(rng, 5000)
+    mdef.l2_set_train(t)
+    for nq, k in ((700, 2), (333, 30)):
+        q = _sift_like(rng, nq)
+        d_q = torch.from_numpy(q).cuda()
+        d_i = torch.empty((nq, k), dtype=torch.int32, device="cuda"); d_d = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        ms = mdef.l2_knn_dev(d_q.data_ptr(), nq, k, d_i.data_ptr(), d_d.data_ptr())
+        oi, od = oracle.knn_l2_u8(q, t, k)
+        assert ms > 0 and np.array_equal(d_i.cpu().numpy(), oi) and np.array_equal(d_d.cpu().numpy().view(np.uint32), od)
+
+
 def test_knn_l2_property_larger(capi, mdef):
     """60 k x 40 k pairs: the first neighbour of a row queried against a set that contains it is itself (distance 0),
     lists are sorted by (distance, row), and distances equal a numpy recomputation on a sample."""
