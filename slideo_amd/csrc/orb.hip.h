@@ -23,6 +23,7 @@
 // neither stage ever reads outside the level: no reflected border is
 // materialised (OpenCV stores one of 63 px; it is never sampled).
 #pragma once
+#include <limits.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
     const LevelGeom L = g.lv[l];
     const int tile = blockIdx.x - L.btile0;
     const int ty = tile / L.btx, tx = tile - ty * L.btx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the row arithmetic stays on the SALU)
     const int x0 = tx * BLUR_TW;
     const int y0 = ty * BLUR_TH + wave * BLUR_RH;
     if (y0 >= L.h) return;
@@ -569,16 +570,46 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
 #pragma unroll
     for (int i = 0; i < 7; ++i) { const float k = tab->gkf[i]; kk[i] = blur_f2{k, k}; }
     auto mad2 = [](blur_f2 a, blur_f2 b, blur_f2 c) -> blur_f2 { return FMA ? __builtin_elementwise_fma(a, b, c) : a * b + c; };
-    // a strip whose 4-byte groups all lie inside the level loads aligned dwords; the level's first / last strip (and a level
-    // narrower than a strip) goes through the reflecting byte loads — wave-uniform choice, so the common path has no divergence
-    const bool plain = x0 >= 4 && x0 + 4 * 63 <= L.w;
-    auto load = [&](int y) -> uint32_t {
-        const int gy = reflect101(y, L.h);
-        if (plain) return *reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch + xs);
-        return blur_load_dword(img, L.pitch, L.w, gy, xs);
+    // A strip whose 4-byte groups all lie inside the level loads one aligned dword per lane and row.  The level's first / last
+    // strip (a quarter to two thirds of the strips, depending on the level) has lanes whose group crosses the border.  Four
+    // consecutive columns reflect (BORDER_REFLECT_101) onto at most four consecutive bytes, i.e. into two neighbouring aligned
+    // dwords: per strip every lane works out ONCE the column of that pair and a v_perm_b32 selector, and per row it loads the
+    // two dwords and permutes — no branch, no per-byte loop.  (Reflecting inside the row loop, a while loop per byte executed
+    // by the whole wave, made an edge strip cost several times a plain one: 288 VALU instructions per round over the whole
+    // launch against 120 for the plain loop.)
+    const bool plain = x0 >= 4 && x0 + 4 * 63 <= L.w;              // wave-uniform
+    int xa = xs, xb = xs;
+    uint32_t sel = 0x03020100u;
+    if (!plain) {
+        int r[4], lo = INT_MAX;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { r[c] = reflect101(xs + c, L.w); lo = min(lo, r[c]); }
+        xa = min(lo & ~3, max(L.pitch - 8, 0));
+        xb = min(xa + 4, L.pitch - 4);
+        sel = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int o = r[c] - xa;                                // 0..7 (3 < o: in the second dword)
+            sel |= (uint32_t)(o < 4 ? o : min(r[c] - xb, 3) + 4) << (8 * c);
+        }
+    }
+    const int hh = L.h;
+    auto row_of = [&](int y) -> int {                              // BORDER_REFLECT_101 of a row; one fold covers every row an output taps
+        if (hh < 8) return reflect101(y, hh);
+        int r = y < 0 ? -y : y;
+        r = r >= hh ? 2 * (hh - 1) - r : r;
+        return min(max(r, 0), hh - 1);                             // (rows past the taps of the last stored output: any valid row)
     };
+    // (the permute is applied where the row is consumed, rounds after the loads were issued — not behind a wait right here)
+    auto load = [&](int y) -> uint2 {
+        const uint8_t* row = img + (int64_t)row_of(y) * L.pitch;
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(row + xa);
+        return make_uint2(a, *reinterpret_cast<const uint32_t*>(row + xb));     // (plain strip: xb == xa, the same dword again — no branch, no wait)
+    };
+    auto px4 = [&](uint2 r) -> uint32_t { return __builtin_amdgcn_perm(r.y, r.x, sel); };
     // row pass of source rows ya, ya + 1 -> the lane's 4 outputs of each row, as (row a, row b) pairs
-    auto rowpass2 = [&](uint32_t da, uint32_t db, blur_f2 (&o)[4]) {
+    auto rowpass2 = [&](uint2 ra2, uint2 rb2, blur_f2 (&o)[4]) {
+        const uint32_t da = px4(ra2), db = px4(rb2);
         const uint32_t la = __shfl_up(da, 1), ra = __shfl_down(da, 1), lb = __shfl_up(db, 1), rb = __shfl_down(db, 1);
         blur_f2 P[10];
         P[0] = blur_f2{(float)((la >> 8) & 255u), (float)((lb >> 8) & 255u)};
@@ -616,7 +647,7 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
     const int lim = y0 + BLUR_RH + 3;                                  // last source row any output of the strip taps (+ its pair partner)
     // source rows are requested FOUR row pairs (one unrolled round) ahead: 8 loads in flight per lane.  With two pairs ahead
     // the kernel ran at 1.6 TB/s whatever its instruction count (packed or not: 2.18 -> 2.0 ms) — bytes in flight, not VALU.
-    uint32_t pa[4], pb[4];
+    uint2 pa[4], pb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { pa[u] = load(min(y0 + 4 + 2 * u, lim)); pb[u] = load(min(y0 + 5 + 2 * u, lim)); }
     for (int gI = 0; gI < BLUR_RH / 8; ++gI) {
