@@ -30,8 +30,23 @@
  *     elimination with partial pivoting (OpenCV: DECOMP_EIG); equal to f64
  *     round-off.
  *
+ * Every primitive whose exact OpenCV rounding could only be RECALLED (Appendix A,
+ * confidence M / L) exists here in more than one form, selected by
+ * slideo_config.ocv (slideo_ocv_variants, include/slideo_amd.h) — the same switches
+ * the product's host tables read (slideo_amd/csrc/geom.h).  Value 0 of each is the
+ * default; DESIGN.md section 5 says why.  tools/pin_opencv.py (run where cv2 4.5.2
+ * exists) + tests/test_opencv_pin.py turn "unpinned" into a per-switch verdict in
+ * one command; until that has happened this header keeps saying PARITY UNPINNED.
+ *
+ * The k-NN of match_frame is the cache-blocked form (knn_hamming_blocked: train rows
+ * re-laid in 8-row qword-interleaved blocks, 16 queries x 512-row tiles, AVX-512
+ * VPOPCNTDQ by runtime dispatch, scalar popcnt otherwise) — same results as the
+ * plain so_knn_hamming (tests/test_oracle_primitives.py), so that bench.py's CPU leg
+ * is not a strawman.
+ *
  * Build: see oracle/Makefile.  All floating point is compiled with
- * -ffp-contract=off so that results do not depend on FMA availability.
+ * -ffp-contract=off so that results do not depend on FMA availability (the FMA
+ * variants call fma() explicitly).
  */
 #include "../include/slideo_amd.h"
 
