@@ -345,7 +345,7 @@ def main():
                 # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
                 flops = 2.0 * 256 * pairs_per_launch
                 achieved = flops / avg_s / 1e12
-                out["roofline"] = dict({"kernel": "knn_tile4_kernel / knn_tile2_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 x FP4; wave shape per launch)", "bound": "mfma",
+                out["roofline"] = dict({"kernel": "knn_tile2_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4; --knn mfma4 selects knn_tile4_kernel)", "bound": "mfma",
                                         "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512}, **common)
             else:

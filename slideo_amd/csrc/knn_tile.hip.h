@@ -49,13 +49,19 @@ constexpr int KT_ST_ROWS = 128;                // rows per super-tile (the unit 
 #endif
 constexpr int KT_RING = KT_RING_V;             // LDS ring slots (super-tiles resident per block)
 constexpr int KT_AHEAD = KT_AHEAD_V;           // a super-tile is staged this many iterations before it is consumed
-constexpr int KT_MFMA_PRIO = 1;                // wave priority while its MFMAs are issued (0 elsewhere)
+#ifndef KT_MFMA_PRIO_V
+#define KT_MFMA_PRIO_V 1
+#endif
+constexpr int KT_MFMA_PRIO = KT_MFMA_PRIO_V;                // wave priority while its MFMAs are issued (0 elsewhere)
 constexpr int KT_ST_U4 = KT_ST_ROWS * 128 / 16;  // uint4 per super-tile of operand (1024)
 constexpr int KT_SIDE_U32 = 2 * KT_ST_ROWS;    // per super-tile: 128 f32 norms, then 128 i32 original rows
-constexpr int KT_FLUSH_AT = 16;
+#ifndef KT_FLUSH_AT_V
+#define KT_FLUSH_AT_V 16
+#endif
+constexpr int KT_FLUSH_AT = KT_FLUSH_AT_V;
 constexpr int KT_FLUSH_BATCH = 4;
 constexpr int KT_TPS = KT_ST_ROWS / 32;        // tiles per super-tile
-constexpr int KT_PEND_CAP = 80;                // >= KT_FLUSH_AT - 1 + KT_TPS * 16 (flush test once per super-tile; a lane pushes <= 16 keys per tile and query)
+constexpr int KT_PEND_CAP = (KT_FLUSH_AT - 1 + (KT_ST_ROWS / 32) * 16 + 7) & ~7;   // = 80;               // >= KT_FLUSH_AT - 1 + KT_TPS * 16 (flush test once per super-tile; a lane pushes <= 16 keys per tile and query)
 constexpr float KT_PAD_NORM = 1024.f;          // norm of the pad rows: no distance bound (<= 512) admits them
 
 template <int NT> constexpr int knn_qpb() { return KT_WAVES * 32 * NT; }                         // queries per block

@@ -411,7 +411,13 @@ struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // (64 4K frames = 125 blocks) the 512-query blocks of engine 3 fill the chip better.
 int knn_engine_for(const slideo_matcher* m, int nq) {
     if (m->knn_engine != 0) return m->knn_engine;
-    return cdiv(std::max(nq, 1), knn_qpb<4>()) >= 192 ? 2 : 3;
+    // The 2-tile shape (4 waves/SIMD, two 512-query blocks per CU) for every size: since the {0,1} operand alphabet it runs the
+    // headline launch in 10.0 ms alone against 11.3 for the 4-tile shape (four waves per SIMD interleave their max trees with
+    // each other's MFMAs better than two waves with twice the accumulators do), 12.5 against 15.0 ms inside the timed region,
+    // and the step is 2 % shorter.  (Round 1's kernels were equally fast alone and the 4-tile shape won by leaving registers to
+    // the other units' kernels; it stays selectable: slideo_matcher_set_knn_engine 2.)
+    (void)nq;
+    return 3;
 }
 // nq: the query count the plan is made for (the real one, or its estimate when only the device knows it); nq_grid >= nq:
 // what the grid and the buffers are sized for (blocks past the device-side count leave at once)
