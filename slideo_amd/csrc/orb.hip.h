@@ -552,9 +552,14 @@ typedef float blur_f2 __attribute__((ext_vector_type(2)));
 // saturate_cast<uchar>(cvRound(s)) is one v_cvt_pk_u8_f32 per pixel (round to nearest even, saturating: tools/cvt_pk_probe.hip).
 template <bool FMA>
 __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
-                                                       uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab) {
+                                                       uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab,
+                                                       const uint8_t* __restrict__ strip_mask) {
     static_assert(BLUR_RH % 8 == 0, "four row pairs per unrolled round");
     const int f = blockIdx.y;
+    // strip_mask (frame path): one byte per (frame, tile, wave) strip, set by blur_mark_kernel iff some keypoint's BRIEF
+    // samples can fall into the strip; the other strips of the blurred pyramid are never read, so they are not computed.
+    // null (pyramid tap): every strip.
+    if (strip_mask && !strip_mask[((size_t)f * g.blur_tiles + blockIdx.x) * 4 + (threadIdx.x >> 6)]) return;
     const int l = level_of_tile(g, blockIdx.x, true);
     const LevelGeom L = g.lv[l];
     const int tile = blockIdx.x - L.btile0;
@@ -1024,6 +1029,29 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
 // blur_f32_kernel materialises the blurred pyramid and this kernel reads it: the intensity centroid over the disc from the
 // UNBLURRED level (dword gathers straight from global memory / L2: one disc row is 16 dwords), then the 512 samples as
 // single bytes of the BLURRED level.  One wave per keypoint, 4 keypoints per block, no LDS.  grid ceil(Qtot / 4).
+// Which strips of the blurred pyramid will be sampled: one thread per kept keypoint (sorted items), marking every
+// (tile, wave) strip of blur_f32_kernel that its sample disc — radius ceil(half_patch sqrt 2) + 1 around the keypoint,
+// the reach of the rotated BRIEF pattern after rounding — overlaps.  Keypoints cluster (text, figures), so most strips of a
+// frame stay unmarked: 17 % are marked on the benchmark's frames.  qtot == 0xFFFFFFFF: the count is on the device.
+__global__ __launch_bounds__(256) void blur_mark_kernel(PyrGeom g, const uint32_t* __restrict__ qofs, int nframes,
+                                                        const uint64_t* __restrict__ items, uint32_t qtot, uint8_t* __restrict__ strip_mask) {
+    const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+    if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];
+    if (gi >= qtot) return;
+    int lo = 0, hi = nframes;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
+    const uint64_t it = items[gi];
+    const int px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
+    const LevelGeom& L = g.lv[l];
+    const int R = (int)ceilf((float)g.half_patch * 1.41421357f) + 1;
+    const int sx0 = max(px - R, 0) / BLUR_TW, sx1 = min(px + R, L.w - 1) / BLUR_TW;
+    const int sy0 = max(py - R, 0) / BLUR_RH, sy1 = min(py + R, L.h - 1) / BLUR_RH;      // strip rows: 4 per tile row
+    uint8_t* mk = strip_mask + (size_t)lo * g.blur_tiles * 4;
+    for (int sy = sy0; sy <= sy1; ++sy)
+        for (int sx = sx0; sx <= sx1; ++sx)
+            mk[(size_t)(L.btile0 + (sy >> 2) * L.btx + sx) * 4 + (sy & 3)] = 1;
+}
+
 __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                                const OrbTables* __restrict__ tab, const uint32_t* __restrict__ qofs, int nframes,
                                                                const uint64_t* __restrict__ items, uint32_t qtot,

@@ -49,6 +49,7 @@ struct HostPage {
 struct OrbOut {            // where the last ORB run of a slot left its results (device)
     uint32_t qtot = 0, max_count = 0;
     int nframes = 0;
+    bool full_blur = false;       // stage 1 materialised the whole blurred pyramid (pyramid tap)
     std::vector<uint32_t> qofs;   // host copy, nframes+1
 };
 
@@ -61,7 +62,7 @@ struct Slot {
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
-    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask;
     PinBuf h_info, h_out;
     OrbOut orb;
     // unit in flight
@@ -75,10 +76,10 @@ struct Slot {
     // stream of batches; sizing every idle slot when one grows keeps every later unit allocation-free.
     void match_capacity(const Slot& o) {
         DevBuf* mine[] = {&d_stage, &d_pyr, &d_blur, &d_cand, &d_hist, &d_candcount, &d_flags, &d_thr, &d_lvlofs, &d_kpcount, &d_qofs,
-                          &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs};
+                          &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs, &d_blurmask};
         const DevBuf* theirs[] = {&o.d_stage, &o.d_pyr, &o.d_blur, &o.d_cand, &o.d_hist, &o.d_candcount, &o.d_flags, &o.d_thr, &o.d_lvlofs,
                                   &o.d_kpcount, &o.d_qofs, &o.d_info, &o.d_items, &o.d_kp, &o.d_desc, &o.d_keys, &o.d_knn_pend, &o.d_votes,
-                                  &o.d_gpts, &o.d_gmask, &o.d_fcs, &o.d_verdicts, &o.d_pairs};
+                                  &o.d_gpts, &o.d_gmask, &o.d_fcs, &o.d_verdicts, &o.d_pairs, &o.d_blurmask};
         static_assert(sizeof(mine) / sizeof(mine[0]) == sizeof(theirs) / sizeof(theirs[0]), "same buffer lists");
         for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); ++i) mine[i]->reserve_cap(theirs[i]->cap);
         h_info.reserve_cap(o.h_info.cap); h_out.reserve_cap(o.h_out.cap);
@@ -216,12 +217,24 @@ void require_idle(slideo_matcher* m) {
 
 // ---- ORB over `n` equally sized frames already on the device, in three steps -------------
 // stage 1: gray, pyramid, FAST+NMS, blur, retainBest thresholds, per-frame offsets; copies {Qtot, max, flags} to pinned memory
-// `with_blur`: also materialise the blurred pyramid (only the pyramid tap wants it; describe_kernel blurs at its samples)
+void launch_blur(slideo_matcher* m, Slot& S, const PyrGeom& g, int n, const uint8_t* strip_mask) {
+    hipStream_t st = S.st;
+    if (m->cfg.ocv.blur == 0)
+        blur_f32_kernel<true><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(), strip_mask);
+    else if (m->cfg.ocv.blur == 1)
+        blur_f32_kernel<false><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(), strip_mask);
+    else
+        blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
+    check_launch("blur kernel");
+}
+
+// `with_blur`: also materialise the WHOLE blurred pyramid (only the pyramid tap wants it)
 // the f32 blur of ocv.blur 0 / 1 cannot be evaluated per BRIEF sample in integer arithmetic: those variants always
 // materialise the blurred pyramid (blur_f32_kernel) and describe from it (describe_blurred_kernel)
 void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
                 bool with_blur = false, uint32_t kp_cap = 0xFFFFFFFFu) {
     hipStream_t st = S.st;
+    const bool full_blur = with_blur;
     with_blur = with_blur || blur_is_f32(m);
     GeomEntry& ge = geom_for(m, w, h);
     const PyrGeom& g = ge.g;
@@ -266,15 +279,9 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
         check_launch("fast_kernel");
     }
-    if (with_blur && g.blur_tiles > 0) {
-        if (m->cfg.ocv.blur == 0)
-            blur_f32_kernel<true><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
-        else if (m->cfg.ocv.blur == 1)
-            blur_f32_kernel<false><<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
-        else
-            blur_kernel<<<dim3(g.blur_tiles, n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>());
-        check_launch("blur kernel");
-    }
+    // the whole blurred pyramid only for the pyramid tap; on the frame path the f32 variants blur in stage 2, and only the strips
+    // the kept keypoints sample (blur_mark_kernel)
+    if (full_blur && g.blur_tiles > 0) launch_blur(m, S, g, n, nullptr);
     threshold_kernel<<<n, 64 * L, 0, st>>>(g, hist, cand_count, S.d_thr.as<uint32_t>(), S.d_lvlofs.as<uint32_t>(),
                                            S.d_kpcount.as<uint32_t>(), flags, kp_cap);
     check_launch("threshold_kernel");
@@ -283,6 +290,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
     HIP_CHECK(hipMemcpyAsync(S.h_info.p, S.d_info.p, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_info.as<uint32_t>() + 2, flags, 4, hipMemcpyDeviceToHost, st));
     S.orb.nframes = n;
+    S.orb.full_blur = full_blur;
 }
 
 // the one mid-pipeline host sync: 12 bytes that size everything downstream
@@ -319,6 +327,14 @@ void orb_stage2(slideo_matcher* m, Slot& S, int w, int h, bool by_capacity = fal
         check_launch("sort_global_kernel");
     }
     if (blur_is_f32(m)) {
+        if (!S.orb.full_blur && g.blur_tiles > 0) {
+            const size_t mask_bytes = (size_t)n * g.blur_tiles * 4;
+            S.d_blurmask.reserve(mask_bytes);
+            HIP_CHECK(hipMemsetAsync(S.d_blurmask.p, 0, mask_bytes, st));
+            blur_mark_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(g, S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot_arg, S.d_blurmask.as<uint8_t>());
+            check_launch("blur_mark_kernel");
+            launch_blur(m, S, g, n, S.d_blurmask.as<uint8_t>());
+        }
         describe_blurred_kernel<<<cdiv((int)qtot, 4), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_blur.as<uint8_t>(), m->d_tables.as<OrbTables>(),
                                                                     S.d_qofs.as<uint32_t>(), n, S.d_items.as<uint64_t>(), qtot_arg,
                                                                     m->d_ictab.as<uint2>(), m->ic_shift, m->ic_entries,
