@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
                                                    uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
-    __shared__ uint16_t queue[FAST_SW * FAST_SH];
-    __shared__ uint32_t qn;
+    constexpr int FAST_Q1W = ((FAST_SH + 3) / 4) * FAST_SW;            // a wave's private share of queue1: its score rows (sy % 4 == wave)
+    __shared__ uint16_t queue[4 * FAST_Q1W];
+    __shared__ uint32_t qcnt[4];
     // survivors of the block's tiles are staged in LDS and appended to the level's candidate list with ONE returning
     // global atomic per flush (a flush per tile kept every tile waiting for its own round trip); same for the histogram
     __shared__ uint32_t stage[FAST_STAGE_CAP], shist[256], nstage, stage_end, stage_base;
@@ -273,7 +274,6 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         const int i = (int)threadIdx.x + 256 * k;
         if (i < FAST_NDW * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = pre[k];
     }
-    if (threadIdx.x == 0) qn = 0;
     for (int i = threadIdx.x; i < FAST_SW * FAST_SH / 16; i += 256) reinterpret_cast<uint4*>(&sc[0][0])[i] = make_uint4(0, 0, 0, 0);
     // next tile's pixels (always issued — past the end the last tile is re-read and dropped — so that `pre` stays a
     // plain register array)
@@ -305,12 +305,17 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         m1 = __builtin_elementwise_max(absd(pk(c0[-3 * FAST_RW], c1[-3 * FAST_RW]), v), absd(pk(c0[3 * FAST_RW], c1[3 * FAST_RW]), v));
         return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(m1, tt)) & inmask;
     };
-    auto stage2 = [&](const uint8_t* c0, const uint8_t* c1, fast_us2 v, fast_us2 m1) {
-        const fast_us2 mh = __builtin_elementwise_max(absd(pk(c0[3], c1[3]), v), absd(pk(c0[-3], c1[-3]), v));
-        const fast_us2 md1 = __builtin_elementwise_max(absd(pk(c0[2 * FAST_RW + 2], c1[2 * FAST_RW + 2]), v), absd(pk(c0[-2 * FAST_RW - 2], c1[-2 * FAST_RW - 2]), v));
-        const fast_us2 md2 = __builtin_elementwise_max(absd(pk(c0[-2 * FAST_RW + 2], c1[-2 * FAST_RW + 2]), v), absd(pk(c0[2 * FAST_RW - 2], c1[2 * FAST_RW - 2]), v));
-        const fast_us2 mall = __builtin_elementwise_min(__builtin_elementwise_min(m1, mh), __builtin_elementwise_min(md1, md2));
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mall, tt)) & inmask;
+    // A1 — the vertical pair on every position, packed two positions per register; survivors (5 - 10 % of the positions of a
+    // text frame) are queued.  The other three pairs used to be tested here too, by the whole wave whenever ANY of its 256
+    // positions survived the first — 16 of the kernel's 29 instructions per pixel; now only the survivors take them (A2).
+    // Every wave appends to its own quarter of the queue with a wave-uniform count: no atomics, no waits.
+    uint32_t myn = 0;
+    uint16_t* const myq = queue + wave * FAST_Q1W;
+    auto push1 = [&](bool cond, uint32_t val) {
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(cond);
+        if (mk == 0ull) return;                                          // wave-uniform
+        if (cond) myq[myn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)val;
+        myn += (uint32_t)__popcll(mk);
     };
     for (int sy = wave; sy < FAST_SH; sy += 8) {
         if (y0 - 1 + sy > L.ry1) break;
@@ -322,18 +327,43 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         const uint32_t s1a = stage1(a0, a0 + 64, va, ma);
         const uint32_t s1b = rowb ? stage1(b0, b0 + 64, vb, mb) : (stage1(b0, b0 + 64, vb, mb), 0u);
         if (__builtin_amdgcn_ballot_w64((s1a | s1b) != 0u) == 0ull) continue;
-        const uint32_t s2a = stage2(a0, a0 + 64, va, ma);
-        const uint32_t s2b = rowb ? stage2(b0, b0 + 64, vb, mb) : 0u;
-        if (s2a & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane);
-        if (s2a >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(sy * FAST_SW + lane + 64);
-        if (s2b & 0xFFFFu) queue[atomicAdd(&qn, 1u)] = (uint16_t)(syb * FAST_SW + lane);
-        if (s2b >> 16) queue[atomicAdd(&qn, 1u)] = (uint16_t)(syb * FAST_SW + lane + 64);
+        push1((s1a & 0xFFFFu) != 0u, (uint32_t)(sy * FAST_SW + lane));
+        push1((s1a >> 16) != 0u, (uint32_t)(sy * FAST_SW + lane + 64));
+        push1((s1b & 0xFFFFu) != 0u, (uint32_t)(syb * FAST_SW + lane));
+        push1((s1b >> 16) != 0u, (uint32_t)(syb * FAST_SW + lane + 64));
     }
+    // A2 — the horizontal pair and the two diagonals, one survivor per lane, by the wave that queued it (score rows are dealt
+    // to the waves modulo 4, so the shares are balanced): its quarter of the queue is compacted in place — a chunk's 64 reads
+    // precede its writes, and the write position never passes the read position.  No barrier between A1 and A2.
+    uint32_t mym = 0;
+    for (uint32_t k0 = 0; k0 < myn; k0 += 64) {
+        const uint32_t kq = k0 + lane;
+        bool pass = false;
+        uint32_t i = 0;
+        if (kq < myn) {
+            i = myq[kq];
+            const uint8_t* c = &raw[(i >> 7) + 3][(i & 127u) + 3 + xoff];
+            const int v = c[0];
+            const int p0 = c[3], p1 = c[-3], p2 = c[2 * FAST_RW + 2], p3 = c[-2 * FAST_RW - 2], p4 = c[-2 * FAST_RW + 2], p5 = c[2 * FAST_RW - 2];
+            pass = (fast_differs(p0, v, t) | fast_differs(p1, v, t)) & (fast_differs(p2, v, t) | fast_differs(p3, v, t)) &
+                   (fast_differs(p4, v, t) | fast_differs(p5, v, t));
+        }
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) myq[mym + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)i;
+        mym += (uint32_t)__popcll(mk);
+    }
+    if (lane == 0) qcnt[wave] = mym;
     __syncthreads();
+    // the queue = the four quarters back to back
+    const uint32_t qc1 = qcnt[0], qc2 = qc1 + qcnt[1], qc3 = qc2 + qcnt[2];
+    auto qat = [&](uint32_t kq) -> int {
+        const uint32_t r = (kq >= qc1) + (kq >= qc2) + (kq >= qc3);
+        return queue[r * FAST_Q1W + kq - (r == 0 ? 0u : r == 1 ? qc1 : r == 2 ? qc2 : qc3)];
+    };
     // Phase B — segment test + cornerScore<16> on the queued positions only
-    const uint32_t nqueued = qn;
+    const uint32_t nqueued = qc3 + qcnt[3];
     for (uint32_t kq = threadIdx.x; kq < nqueued; kq += 256) {
-        const int i = queue[kq];
+        const int i = qat(kq);
         const int sy = i >> 7, sx = i & 127;
         int score = 0;
         {
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         bool keep = false;
         int s = 0, gx = 0, gy = 0;
         if (kq < nqueued) {
-            const int i = queue[kq];
+            const int i = qat(kq);
             const int sy = i >> 7, sx = i & 127;
             gx = x0 - 1 + sx; gy = y0 - 1 + sy;
             if (sx >= 1 && sx <= FAST_TW && sy >= 1 && sy <= FAST_TH && gx < L.rx1 && gy < L.ry1) {
