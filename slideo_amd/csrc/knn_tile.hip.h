@@ -421,7 +421,11 @@ void knn_tile4_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __res
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
     knn_tile_body<4>(q, nq, tx, side, nminh, nt_pad, st_per_seg, out, pend_ws, prune_tol, nq_dev);
 }
+#ifdef KT2_VGPRS           /* experiments only (tools/knn_experiments.sh): a cap below the 128 that 4 waves per SIMD allow */
+__global__ __attribute__((amdgpu_num_vgpr(KT2_VGPRS))) __launch_bounds__(KT_THREADS, 4)
+#else
 __global__ __launch_bounds__(KT_THREADS, 4)
+#endif
 void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                       const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {

@@ -37,6 +37,9 @@ struct GeomEntry {
     int w = 0, h = 0;
     PyrGeom g;
     DevBuf lin_tab;
+    std::vector<PyrChain> chains;     // fused pyramid launches (empty: the per-level kernels)
+    DevBuf spans;
+    size_t chain_lds_max = 0;
 };
 
 struct HostPage {
@@ -125,6 +128,8 @@ struct slideo_matcher {
     // ORB stages of consecutive units take turns (each waits for the previous unit's ORB stage on the GPU, event to event):
     // what the host wait used to enforce as a side effect (SLIDEO_ORB_CHAIN=0: free-running).
     int orb_chain = 1;
+    int pyr_chain = 0;               // SLIDEO_PYR_CHAIN=1: fused pyramid launches (pyr_chain_kernel) instead of gray_kernel + one resize_kernel per level.
+                                     // Off: measured SLOWER — 1.24 + 0.69 + 0.2 ms for the three launches against 0.41 + 1.2 ms
     hipEvent_t last_orb_ev = nullptr;
 
     // workspaces
@@ -173,6 +178,16 @@ GeomEntry& geom_for(slideo_matcher* m, int w, int h) {
     if (tab.empty()) tab.push_back(0);
     e->lin_tab.reserve(tab.size() * 4);
     HIP_CHECK(hipMemcpyAsync(e->lin_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->stream));
+    // fused pyramid chains: the LDS form of the resize step reads a group's taps from three dwords (shrink factor <= 2)
+    std::vector<PyrSpan> spans;
+    if (m->pyr_chain && m->cfg.scale_factor <= 2.0f) build_pyr_chains(e->g, tab, e->chains, spans);
+    if (!e->chains.empty()) {
+        e->spans.reserve(std::max<size_t>(spans.size() * sizeof(PyrSpan), 16));
+        HIP_CHECK(hipMemcpyAsync(e->spans.p, spans.data(), spans.size() * sizeof(PyrSpan), hipMemcpyHostToDevice, m->stream));
+        for (const PyrChain& c : e->chains)
+            e->chain_lds_max = std::max(e->chain_lds_max, (size_t)c.buf_bytes[0] + c.buf_bytes[1] + (size_t)c.xt_entries * 8 + (size_t)c.yt_entries * 4);
+        if (e->chain_lds_max > 60 * 1024) e->chains.clear();              // (never with 256 x 32 tiles; the per-level kernels then)
+    }
     HIP_CHECK(hipStreamSynchronize(m->stream));
     m->geoms.push_back(std::move(e));
     return *m->geoms.back();
@@ -257,6 +272,20 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
     S.h_info.reserve(64);
 
     const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
+    if (!ge.chains.empty()) {
+        const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
+        for (const PyrChain& c : ge.chains) {
+            const size_t lds = (size_t)c.buf_bytes[0] + c.buf_bytes[1] + (size_t)c.xt_entries * 8 + (size_t)c.yt_entries * 4;
+            const dim3 grid(c.tiles_x * c.tiles_y, n);
+            if (c.from_bgr)
+                pyr_chain_kernel<true><<<grid, 256, lds, st>>>(g, c, ge.spans.as<PyrSpan>(), ge.lin_tab.as<uint32_t>(), frames_dev, frame_stride, stride,
+                                                               aligned4, gc, S.d_pyr.as<uint8_t>());
+            else
+                pyr_chain_kernel<false><<<grid, 256, lds, st>>>(g, c, ge.spans.as<PyrSpan>(), ge.lin_tab.as<uint32_t>(), frames_dev, frame_stride, stride,
+                                                                aligned4, gc, S.d_pyr.as<uint8_t>());
+            check_launch("pyr_chain_kernel");
+        }
+    } else {
     {
         dim3 grid(cdiv(cdiv(w, 4), 256), h, n);
         const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
@@ -274,6 +303,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
                                             nxq, magic);
         check_launch("resize_kernel");
+    }
     }
     if (g.fast_tiles > 0) {
         fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
@@ -831,6 +861,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_ASYNC_SUBMIT")) mm->async_submit = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_PYR_CHAIN")) mm->pyr_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));

@@ -700,3 +700,21 @@ def test_ransac_rng_stream_grows_on_demand(capi, oracle, cfg0_data, monkeypatch)
     assert list(v["page_idx"]) == list(truth)
     assert np.array_equal(m.match_frames(frames), v)                  # and again, the stream now long enough
     m.close()
+
+
+def test_fused_pyramid_chain_equals_per_level_kernels(capi, oracle, synth, monkeypatch):
+    """SLIDEO_PYR_CHAIN=1 builds the pyramid with pyr_chain_kernel (gray + two levels, then three levels per launch, LDS to LDS)
+    instead of one kernel per level; off by default because it measured slower, kept honest here: same pyramid, same features."""
+    pages = synth.pages(2, 1000, 700)
+    monkeypatch.setenv("SLIDEO_PYR_CHAIN", "1")
+    mc = capi.Matcher(capi.default_config(nfeatures=700))
+    monkeypatch.delenv("SLIDEO_PYR_CHAIN")
+    mp = capi.Matcher(capi.default_config(nfeatures=700))
+    for img in (pages[0], pages[1][3:, 5:].copy(), np.random.default_rng(3).integers(0, 256, (131, 257, 3), dtype=np.uint8)):
+        for lvl in range(8):
+            a, b = mc.pyramid_level(img, lvl, False), mp.pyramid_level(img, lvl, False)
+            assert a.shape == b.shape and np.array_equal(a, b), lvl
+        ka, da = mc.orb(img); kb, db = mp.orb(img)
+        assert np.array_equal(da, db) and np.array_equal(ka["x"], kb["x"]) and np.array_equal(ka["angle"], kb["angle"])
+    _cmp_orb(capi, oracle, mc, oracle.default_config(nfeatures=700), pages[0])
+    mc.close(); mp.close()
