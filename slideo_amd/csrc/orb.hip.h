@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void compact_kernel(PyrGeom g, const uint32_t*
         if ((e >> 24) >= T) {
             uint32_t slot = lo + atomicAdd(cur, 1u);
             if (slot < f_kp)
-                dst[slot] = ((uint64_t)(((uint32_t)l << 24) | (e & 0xFFFFFFu)) << 8) | (e >> 24);
+                dst[slot] = ((uint64_t)f << 40) | ((uint64_t)(((uint32_t)l << 24) | (e & 0xFFFFFFu)) << 8) | (e >> 24);   // (frame: constant per sort, spares the consumers a search)
         }
     }
 }
@@ -1068,11 +1068,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
     const int lane = threadIdx.x & 63;
     if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
     if (gi >= qtot) return;
-    // frame of this keypoint: last f with qofs[f] <= gi (wave-uniform binary search)
-    int lo = 0, hi = nframes;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
-    const int f = lo;
     const uint64_t it = items[gi];
+    const int f = (int)(it >> 40);                                  // (compact_kernel put the frame there)
     const int score = (int)(it & 255), px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
     const LevelGeom L = g.lv[l];
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
@@ -1186,9 +1183,8 @@ __global__ __launch_bounds__(256) void blur_mark_kernel(PyrGeom g, const uint32_
     const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
     if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];
     if (gi >= qtot) return;
-    int lo = 0, hi = nframes;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
     const uint64_t it = items[gi];
+    const int lo = (int)(it >> 40);                                 // frame
     const int px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
     const LevelGeom& L = g.lv[l];
     const int R = (int)ceilf((float)g.half_patch * 1.41421357f) + 1;
@@ -1210,10 +1206,8 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
     const int lane = threadIdx.x & 63;
     if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
     if (gi >= qtot) return;
-    int lo = 0, hi = nframes;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; }
-    const int f = lo;
     const uint64_t it = items[gi];
+    const int f = (int)(it >> 40);                                  // (compact_kernel put the frame there)
     const int score = (int)(it & 255), px = (int)((it >> 8) & 4095), py = (int)((it >> 20) & 4095), l = (int)((it >> 32) & 15);
     const LevelGeom L = g.lv[l];
     const uint8_t* img = pyr + (int64_t)f * g.frame_bytes + L.ofs;
