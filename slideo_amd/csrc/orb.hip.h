@@ -104,18 +104,19 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     for (int r = 0; r < RESIZE_ROWS; ++r) ye[r] = lin_tab[dst.ytab_ofs + min(y0 + r, dst.h - 1)];
     const uint32_t xe[4] = {xq.x, xq.y, xq.z, xq.w};
     const uint32_t cp[4] = {cq.x, cq.y, cq.z, cq.w};
-    const int xa = (int)(xe[0] & 0xffff) & ~3;         // aligned start; rows are 16-byte aligned with pitch % 16 == 0
-    const bool narrow = (int)(xe[3] & 0xffff) + 1 - xa < 12;
-    const int maxd = (src.pitch >> 2) - 1, d0 = xa >> 2;
-    const int i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd);
-    uint32_t a[RESIZE_ROWS][3], b[RESIZE_ROWS][3];     // (loaded unconditionally: a conditionally filled array would live in scratch)
+    // The 4 outputs tap at most 8 consecutive source bytes per row (shrink factors < 2.3): ONE unaligned 8-byte load per source
+    // row, starting at the first output's left tap (clamped so that it stays inside the row's pitch), instead of three aligned
+    // dwords and a per-tap choice between them — a third of the load instructions and half the VALU of the tap selection.
+    const int xs = min((int)(xe[0] & 0xffff), src.pitch - 8);
+    const bool narrow = (int)(xe[3] & 0xffff) + 1 - xs < 8 || ((int)(xe[3] & 0xffff) - xs < 8 && (xe[3] >> 16) == 0);
+    uint2 a[RESIZE_ROWS], b[RESIZE_ROWS];              // (loaded unconditionally: a conditionally filled array would live in scratch)
 #pragma unroll
     for (int r = 0; r < RESIZE_ROWS; ++r) {
         const int yo = ye[r] & 0xffff;
-        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(base + src.ofs + __umul24(yo, src.pitch));
-        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch));
-        a[r][0] = p0[d0]; a[r][1] = p0[i1]; a[r][2] = p0[i2];
-        b[r][0] = p1[d0]; b[r][1] = p1[i1]; b[r][2] = p1[i2];
+        const uint8_t* p0 = base + src.ofs + __umul24(yo, src.pitch) + xs;
+        const uint8_t* p1 = base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch) + xs;
+        __builtin_memcpy(&a[r], p0, 8);
+        __builtin_memcpy(&b[r], p1, 8);
     }
 #pragma unroll
     for (int r = 0; r < RESIZE_ROWS; ++r) {
@@ -126,15 +127,15 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
         if (narrow) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // tap 2 is byte p+1 even at the right edge: there c1 == 0, so its value is irrelevant
-                const int p = (int)(xe[i] & 0xffff) - xa;                    // 0..10
-                const bool up = p >= 4;
-                const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
-                const uint32_t ta = __builtin_amdgcn_perm(up ? a[r][2] : a[r][1], up ? a[r][1] : a[r][0], sel);
-                const uint32_t tb = __builtin_amdgcn_perm(up ? b[r][2] : b[r][1], up ? b[r][1] : b[r][0], sel);
+                // tap 2 is byte p + 1 even at the right edge: there c1 == 0, so its value is irrelevant (p + 1 = 8 selects a
+                // constant byte)
+                const uint32_t pq = (uint32_t)((int)(xe[i] & 0xffff) - xs);                  // 0..7
+                const uint32_t sel = pq * 0x00010001u + 0x0c010c00u;                         // bytes (p, 0, p + 1, 0)
+                const uint32_t ta = __builtin_amdgcn_perm(a[r].y, a[r].x, sel);
+                const uint32_t tb = __builtin_amdgcn_perm(b[r].y, b[r].x, sel);
                 v[i] = __umul24(cy0, dot2_u16(ta, cp[i])) + (__umul24(cy1, dot2_u16(tb, cp[i])) + (1u << 15));   // 9 x 16 bits: full-rate 24-bit multiplies
             }
-        } else {      // (shrink factors >= 2; kept for generality)
+        } else {      // (shrink factors >= 2.3; kept for generality)
             const uint8_t* r0 = base + src.ofs + __umul24(yo, src.pitch);
             const uint8_t* r1 = base + src.ofs + __umul24(min(yo + 1, src.h - 1), src.pitch);
 #pragma unroll
