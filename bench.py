@@ -249,6 +249,10 @@ def main():
             if not dev_out:                      # gloo stand-in: host tensors
                 d_verdicts.copy_(torch.from_numpy(v.view(np.int32).reshape(B, verdict_words)), non_blocking=False)
             dist.all_gather_into_tensor(d_all, d_verdicts)      # the one collective of the path (RCCL over xGMI)
+            if dev_out:
+                # the next collect overwrites d_verdicts from one of the library's streams, which are not ordered behind the
+                # collective's: wait for it (4 KB per rank; the collect just before was a host sync anyway)
+                torch.cuda.current_stream().synchronize()
         return v
 
     def run_steps(k, depth=None, local=False):
