@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void knl_norms_kernel(const uint8_t* __restric
     norm[row] = ss;
 }
 
-// train [nt][128] u8 -> centred i8, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]) IN NORM ORDER: sorted row i
-// is the caller's row perm[i] (ascending |t'|^2, ties by row), padded to a multiple of KT_ST_ROWS rows;
+// train [nt][128] u8 -> centred i8, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]); row i of the stream is the
+// caller's row perm[i]: ascending |t'|^2 (ties by row) INSIDE a tile, the tiles in a shuffled order (slideo_capi.hip
+// l2_prepare), padded to a multiple of KT_ST_ROWS rows;
 // neg_norm[i] = -|t'|^2 (pad rows: -2^30, perm -1).  One thread per (sorted row, chunk).
 __global__ __launch_bounds__(256) void knl_expand_train_kernel(const uint8_t* __restrict__ t, int nt, int nt_pad,
                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ norm,
@@ -61,12 +62,13 @@ __global__ __launch_bounds__(256) void knl_expand_train_kernel(const uint8_t* __
     if (i >= nt_pad * 8) return;
     const int row = i >> 3, c = i & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < nt) {
-        v = reinterpret_cast<const uint4*>(t + (size_t)perm[row] * 128)[c];
+    const int src = perm[row];                                          // -1: pad row (the tile order is shuffled: pads can sit inside the stream)
+    if (src >= 0) {
+        v = reinterpret_cast<const uint4*>(t + (size_t)src * 128)[c];
         v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
     }
     out[(size_t)(row >> 5) * 256 + c * 32 + (row & 31)] = v;
-    if (c == 0) neg_norm[row] = row < nt ? -norm[perm[row]] : -KNL_PAD_NORM;
+    if (c == 0) neg_norm[row] = src >= 0 ? -norm[src] : -KNL_PAD_NORM;
 }
 
 template <int KL>

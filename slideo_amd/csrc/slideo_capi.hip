@@ -1331,6 +1331,20 @@ void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
         HIP_CHECK(hipStreamSynchronize(st));
         for (int i = 0; i < nt; ++i) h_perm[i] = i;
         std::stable_sort(h_perm.begin(), h_perm.begin() + nt, [&](int32_t a, int32_t b) { return h_norm[a] < h_norm[b]; });
+        // the 32-row tiles (each of nearly one norm, which is all the fast path needs) in a fixed pseudo-random order: streamed in
+        // norm order a query meets its neighbours — rows of about its own norm — only at its own place in the stream and keeps a
+        // loose threshold until then (the Hamming engine's finding, prepare_train_bits)
+        const int ntiles = cdiv(nt, 32);
+        std::vector<int32_t> order((size_t)ntiles), shuffled((size_t)nt_pad, -1);
+        for (int i = 0; i < ntiles; ++i) order[i] = i;
+        uint64_t st_ = 0x9E3779B97F4A7C15ull;
+        for (int i = ntiles - 1; i > 0; --i) {
+            st_ = st_ * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(order[i], order[(int)((st_ >> 33) % (uint64_t)(i + 1))]);
+        }
+        for (int p = 0; p < ntiles; ++p)
+            for (int r = 0; r < 32; ++r) shuffled[(size_t)p * 32 + r] = h_perm[(size_t)order[p] * 32 + r];
+        h_perm.swap(shuffled);
     }
     HIP_CHECK(hipMemcpyAsync(L.d_perm.p, h_perm.data(), (size_t)nt_pad * 4, hipMemcpyHostToDevice, st));
     knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, L.d_perm.as<int32_t>(), d_norm.as<int32_t>(),
