@@ -577,7 +577,9 @@ def test_knn_l2_property_larger(capi, mdef):
 
 @pytest.mark.parametrize("over", [
     dict(scale_factor=1.5, nlevels=5),                     # coarser pyramid
-    dict(scale_factor=3.0, nlevels=3),                     # shrink factor >= 2: the generic resize path
+    dict(scale_factor=3.0, nlevels=3),                     # shrink factor >= 2.3: the generic resize path
+    dict(scale_factor=2.0, nlevels=4),                     # the widest groups the 8-byte resize loads still cover
+    dict(scale_factor=2.4, nlevels=3),                     # groups on both sides of that limit
     dict(nlevels=1),                                       # no pyramid at all
     dict(patch_size=40, edge_threshold=34),                # other BRIEF / centroid radius and border
     dict(fast_threshold=8),                                # many more corners
