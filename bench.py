@@ -5,14 +5,17 @@ One "step" = one pass of the hot path (ORB detect+describe -> exact Hamming kNN
 k=30 -> 5 % vote -> RANSAC similarity -> re-projection verdict) over one batch of
 synthetic frames that is already resident in HBM when the timed region starts.
 One process per GPU; ranks shard frames (weak scaling: the per-GPU batch is
-fixed), the page DB is replicated, and each step ends with ONE RCCL all-gather of
-the per-frame verdict records.
+fixed; --total-frames T: a fixed job, strong scaling), the page DB is replicated, and
+each step ends with ONE RCCL all-gather of the per-frame verdict records, left on
+the device by the library.  --workload cfg2: the L2 k-NN stage of
+BASELINE configs[2] instead.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the exact
-Hamming kNN: knn_tile4_kernel / knn_tile2_kernel, or knn_hamming_kernel with --knn valu), timed with HIP events on its launch stream inside the
+Hamming kNN: knn_tile2_kernel by default, knn_tile4_kernel with --knn mfma4, knn_hamming_kernel with --knn valu), timed with HIP events on its
+launch stream inside the
 library; `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
 bounded sample of the same workload on the host cores.
 """
