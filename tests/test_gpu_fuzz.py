@@ -1,0 +1,75 @@
+"""Randomised parity: HIP path vs the CPU restatement over random image sizes, contents and configurations.
+
+The fixed-shape tests pin the reference's literals and the benchmark shapes; the kernels' edge code (border strips of the
+blur, the last groups of a resize row, partial FAST tiles, levels that vanish, ties, tiny decks) depends on sizes modulo 4,
+16, 126, 248 ... — a seeded sweep covers combinations nobody wrote down.  Same bar as test_gpu_parity.py: bit-exact keypoints,
+angles, descriptors, votes, inliers; |d similarity| <= 1e-4.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _build_both, _cmp_orb, _compare_traces
+
+pytestmark = pytest.mark.gpu
+
+
+def _image(rng, synth, w, h):
+    kind = rng.integers(0, 4)
+    if kind == 0:                                    # blocky noise (many corners, many ties)
+        cell = int(rng.integers(3, 9))
+        base = rng.integers(0, 256, ((h + cell - 1) // cell, (w + cell - 1) // cell), dtype=np.uint8)
+        img = np.kron(base, np.ones((cell, cell), np.uint8))[:h, :w]
+        img = np.repeat(img[:, :, None], 3, 2)
+    elif kind == 1:                                  # a crop of a synthetic slide
+        pg = synth.pages(1, max(w, 320), max(h, 240), seed=int(rng.integers(1, 1 << 30)))[0]
+        img = pg[:h, :w]
+    elif kind == 2:                                  # smooth gradient + sparse dots (few corners; flat tiles)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = ((xx * 255 // max(w - 1, 1)) ^ (yy * 3)).astype(np.uint8)
+        img = np.repeat(img[:, :, None], 3, 2).copy()
+        for _ in range(60):
+            y, x = int(rng.integers(0, h - 6)), int(rng.integers(0, w - 6))
+            img[y:y + 5, x:x + 5] = rng.integers(0, 256, 3)
+    else:                                            # independent colour noise, quantised
+        img = (rng.integers(0, 256, (h, w, 3), dtype=np.uint8) // 32 * 32).astype(np.uint8)
+    return np.ascontiguousarray(img)
+
+
+def _config(rng):
+    over = dict(nfeatures=int(rng.choice([60, 300, 1000, 2500])), fast_threshold=int(rng.choice([6, 12, 20, 35])),
+                nlevels=int(rng.choice([1, 3, 5, 8])), scale_factor=float(rng.choice([1.1, 1.2, 1.35, 1.7])))
+    over["ocv_blur"] = int(rng.integers(0, 4)); over["ocv_gray"] = int(rng.integers(0, 2))
+    over["ocv_resize"] = int(rng.integers(0, 2)); over["ocv_atan"] = int(rng.integers(0, 2))
+    return over
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_orb_random_sizes_contents_configs(capi, oracle, synth, seed):
+    rng = np.random.default_rng(1000 + seed)
+    over = _config(rng)
+    m = capi.Matcher(capi.default_config(**over))
+    ocfg = oracle.default_config(**over)
+    total = 0
+    for _ in range(3):
+        w, h = int(rng.integers(131, 1000)), int(rng.integers(131, 700))
+        total += _cmp_orb(capi, oracle, m, ocfg, _image(rng, synth, w, h))
+    m.close()
+    assert total >= 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_end_to_end_random_decks(capi, oracle, synth, seed):
+    rng = np.random.default_rng(2000 + seed)
+    pw, ph = int(rng.integers(500, 1100)), int(rng.integers(300, 700))
+    fw, fh = int(rng.integers(400, 1000)), int(rng.integers(260, 640))
+    npages, nframes = int(rng.integers(2, 7)), int(rng.integers(3, 9))
+    pages = synth.pages(npages, pw, ph, seed=int(rng.integers(1, 1 << 30)))
+    frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=int(rng.integers(1, 1 << 30)))
+    over = dict(nfeatures=int(rng.choice([300, 800, 1500])), min_rating=float(rng.choice([8.0, 20.0, 50.0])),
+                vote_tolerance=float(rng.choice([1.0, 1.05, 1.2])), ocv_blur=int(rng.integers(0, 4)))
+    m, db = _build_both(capi, oracle, capi.default_config(**over), oracle.default_config(**over), pages)
+    assert m.descriptor_count == db.descriptor_count
+    if m.descriptor_count > 0:
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)
+    m.close()
