@@ -316,6 +316,24 @@ constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dw
 
 struct FastTile { int l, x0, y0, xa, xoff; };
 
+// host-side twin of fast_tile_geo: the per-tile table fast_kernel reads (one 16-byte scalar load per tile instead of a loop
+// over the levels' descriptors and an integer division)
+inline int4 fast_tile_entry(const PyrGeom& g, int tile_id) {
+    int l = 0;
+    for (int i = 1; i < g.nlevels; ++i) if (g.lv[i].ftx * g.lv[i].fty > 0 && tile_id >= g.lv[i].ftile0) l = i;
+    const LevelGeom& L = g.lv[l];
+    const int tile = tile_id - L.ftile0, ty = tile / (L.ftx > 0 ? L.ftx : 1), tx = tile - ty * L.ftx;
+    const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH, xa = (x0 - 4) & ~3;
+    return make_int4(l, x0, y0, xa | (((x0 - 4) - xa) << 16));
+}
+
+__device__ __forceinline__ FastTile fast_tile_geo(const int4* __restrict__ tab, int tile_id) {
+    const int4 e = tab[tile_id];
+    FastTile T;
+    T.l = e.x; T.x0 = e.y; T.y0 = e.z; T.xa = e.w & 0xffff; T.xoff = e.w >> 16;
+    return T;
+}
+
 __device__ __forceinline__ FastTile fast_tile_geo(const PyrGeom& g, int tile_id) {
     FastTile T;
     T.l = level_of_tile(g, tile_id, false);
@@ -345,7 +363,7 @@ __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTil
 
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
-                                                   uint32_t* __restrict__ hist) {
+                                                   uint32_t* __restrict__ hist, const int4* __restrict__ tile_tab) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
     constexpr int FAST_Q1W = ((FAST_SH + 3) / 4) * FAST_SW;            // a wave's private share of queue1: its score rows (sy % 4 == wave)
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const int t = g.fast_thr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = blockIdx.x * FAST_TPB;
-    FastTile T = fast_tile_geo(g, first);
+    FastTile T = fast_tile_geo(tile_tab, first);
     uint32_t pre[FAST_NLD];
     fast_issue_loads(g, T, frame_pyr, pre);
     shist[threadIdx.x] = 0;
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     for (int i = threadIdx.x; i < FAST_SW * FAST_SH / 16; i += 256) reinterpret_cast<uint4*>(&sc[0][0])[i] = make_uint4(0, 0, 0, 0);
     // next tile's pixels (always issued — past the end the last tile is re-read and dropped — so that `pre` stays a
     // plain register array)
-    const FastTile Tn = fast_tile_geo(g, min(first + it + 1, g.fast_tiles - 1));
+    const FastTile Tn = fast_tile_geo(tile_tab, min(first + it + 1, g.fast_tiles - 1));
     fast_issue_loads(g, Tn, frame_pyr, pre);
     const int l = T.l;
     const LevelGeom& L = g.lv[l];

@@ -37,6 +37,7 @@ struct GeomEntry {
     int w = 0, h = 0;
     PyrGeom g;
     DevBuf lin_tab;
+    DevBuf fast_tiles;                // per FAST tile: level, origin, raw-column alignment (orb.hip.h fast_tile_entry)
     std::vector<PyrChain> chains;     // fused pyramid launches (empty: the per-level kernels)
     DevBuf spans;
     size_t chain_lds_max = 0;
@@ -178,6 +179,13 @@ GeomEntry& geom_for(slideo_matcher* m, int w, int h) {
     if (tab.empty()) tab.push_back(0);
     e->lin_tab.reserve(tab.size() * 4);
     HIP_CHECK(hipMemcpyAsync(e->lin_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->stream));
+    {
+        std::vector<int4> ft((size_t)std::max(e->g.fast_tiles, 1));
+        for (int t = 0; t < e->g.fast_tiles; ++t) ft[t] = fast_tile_entry(e->g, t);
+        e->fast_tiles.reserve(ft.size() * sizeof(int4));
+        HIP_CHECK(hipMemcpyAsync(e->fast_tiles.p, ft.data(), ft.size() * sizeof(int4), hipMemcpyHostToDevice, m->stream));
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
     // fused pyramid chains: the LDS form of the resize step reads a group's taps from three dwords (shrink factor <= 2)
     std::vector<PyrSpan> spans;
     if (m->pyr_chain && m->cfg.scale_factor <= 2.0f) build_pyr_chains(e->g, tab, e->chains, spans);
@@ -306,7 +314,7 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
     }
     }
     if (g.fast_tiles > 0) {
-        fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist);
+        fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist, ge.fast_tiles.as<int4>());
         check_launch("fast_kernel");
     }
     // the whole blurred pyramid only for the pyramid tap; on the frame path the f32 variants blur in stage 2, and only the strips
