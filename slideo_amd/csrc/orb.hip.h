@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrGeom g, const uint8_t*
                                                        const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
                                                        slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int atan_fma) {
     extern __shared__ __attribute__((aligned(16))) uint32_t desc_lds[];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the keypoint, its level and frame stay on the SALU)
     const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
     if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
                                                                const uint64_t* __restrict__ items, uint32_t qtot,
                                                                const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
                                                                slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int atan_fma) {
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the keypoint, its level and frame stay on the SALU)
     const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
     if (qtot == 0xFFFFFFFFu) qtot = qofs[nframes];                  // grid sized by capacity: the count is on the device only
