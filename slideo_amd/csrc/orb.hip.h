@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const int f = blockIdx.y;
     const uint8_t* frame_pyr = pyr + (int64_t)f * g.frame_bytes;
     const int t = g.fast_thr;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row loops and queue bases are wave-uniform)
     const int first = blockIdx.x * FAST_TPB;
     FastTile T = fast_tile_geo(tile_tab, first);
     uint32_t pre[FAST_NLD];
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
     // strip_mask (frame path): one byte per (frame, tile, wave) strip, set by blur_mark_kernel iff some keypoint's BRIEF
     // samples can fall into the strip; the other strips of the blurred pyramid are never read, so they are not computed.
     // null (pyramid tap): every strip.
-    if (strip_mask && !strip_mask[((size_t)f * g.blur_tiles + blockIdx.x) * 4 + (threadIdx.x >> 6)]) return;
+    if (strip_mask && !strip_mask[((size_t)f * g.blur_tiles + blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)]) return;
     const int l = level_of_tile(g, blockIdx.x, true);
     const LevelGeom L = g.lv[l];
     const int tile = blockIdx.x - L.btile0;
