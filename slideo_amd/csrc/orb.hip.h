@@ -482,8 +482,10 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
             const uint8_t* c = &raw[(i >> 7) + 3][(i & 127u) + 3 + xoff];
             const int v = c[0];
             const int p0 = c[3], p1 = c[-3], p2 = c[2 * FAST_RW + 2], p3 = c[-2 * FAST_RW - 2], p4 = c[-2 * FAST_RW + 2], p5 = c[2 * FAST_RW - 2];
-            pass = (fast_differs(p0, v, t) | fast_differs(p1, v, t)) & (fast_differs(p2, v, t) | fast_differs(p3, v, t)) &
-                   (fast_differs(p4, v, t) | fast_differs(p5, v, t));
+            // (ints, not bools: no short-circuit, the six LDS reads above are issued together)
+            const int d0 = fast_differs(p0, v, t), d1 = fast_differs(p1, v, t), d2 = fast_differs(p2, v, t), d3 = fast_differs(p3, v, t),
+                      d4 = fast_differs(p4, v, t), d5 = fast_differs(p5, v, t);
+            pass = ((d0 | d1) & (d2 | d3) & (d4 | d5)) != 0;
         }
         const uint64_t mk = __builtin_amdgcn_ballot_w64(pass);
         if (pass) myq[mym + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)i;
