@@ -43,7 +43,7 @@ def _config(rng):
     return over
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_orb_random_sizes_contents_configs(capi, oracle, synth, seed):
     rng = np.random.default_rng(1000 + seed)
     over = _config(rng)
@@ -57,7 +57,7 @@ def test_orb_random_sizes_contents_configs(capi, oracle, synth, seed):
     assert total >= 0
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(30))
 def test_end_to_end_random_decks(capi, oracle, synth, seed):
     rng = np.random.default_rng(2000 + seed)
     pw, ph = int(rng.integers(500, 1100)), int(rng.integers(300, 700))
