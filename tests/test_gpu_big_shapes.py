@@ -36,7 +36,7 @@ def _compare_trace(gv, gc, ov, oc, tag):
     for a, b in zip(gc, oc):
         if b["inliers"] > 0:
             scale = np.array([1, 1, 1e3, 1, 1, 1e3])
-            assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale), tag
+            assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale, equal_nan=True), tag
         assert abs(a["similarity"] - b["similarity"]) <= 1e-4, tag
     assert gv["page_idx"] == ov["page_idx"] and gv["inliers"] == ov["inliers"], tag
     assert abs(gv["similarity"] - ov["similarity"]) <= 1e-4, tag
