@@ -32,6 +32,9 @@
  *   pages                  <= 16384       the vote kernel keeps one counter per page in LDS
  *   knn_k                  1..32          the per-query list lives in registers (the reference uses 30)
  *   max_candidate_pages    1..64, max_rated 1..16, nlevels 1..16, ransac_max_iters 1..1000000
+ *   page / frame area      >= small_area  to_small_image (mo/image_utils.rs:8-20) only ever SHRINKS here; for an image below
+ *                                         120 000 px OpenCV's INTER_AREA turns into a bilinear upscale, which is not restated
+ *                                         (the reference's frames are >= 640x360)
  *   NOT limits: keypoints per frame (beyond 8192 the canonical sort moves from LDS to global memory; a frame beyond the
  *   capacity the asynchronous path provides for is re-run through the exact-size path), the RANSAC sample schedule (the
  *   pre-drawn cv::RNG stream is extended on demand), frames per call (cut into units that fit the workspace budget).

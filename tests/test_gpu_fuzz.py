@@ -62,6 +62,7 @@ def test_end_to_end_random_decks(capi, oracle, synth, seed):
     rng = np.random.default_rng(2000 + seed)
     pw, ph = int(rng.integers(500, 1100)), int(rng.integers(300, 700))
     fw, fh = int(rng.integers(400, 1000)), int(rng.integers(260, 640))
+    fh = max(fh, 120000 // fw + 1)                                   # (to_small_image only shrinks: area >= small_area, a stated limit)
     npages, nframes = int(rng.integers(2, 7)), int(rng.integers(3, 9))
     pages = synth.pages(npages, pw, ph, seed=int(rng.integers(1, 1 << 30)))
     frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=int(rng.integers(1, 1 << 30)))
