@@ -1,4 +1,6 @@
-// knn_tile.hip.h — exact Hamming k-NN on the CDNA4 matrix cores, {0,1} x {0,1} FP4 operands.
+// knn_tile.hip.h — the exact k-NN engine on the CDNA4 matrix cores: ONE kernel body (knn_tile_body) over the wave shape (NT)
+// and the metric — Hamming distance of 256-bit descriptors on {0,1} x {0,1} FP4 operands (KtHamming, the hot path, described
+// below) and squared L2 of 128-dimensional u8 descriptors on centred i8 operands (KtL2, knn_l2.hip.h).
 //
 // Same contract as knn.hip.h (keys = distance << 23 | train_row, the k smallest, ties to the lower row) and the same
 // skeleton as the first matrix-core engine (LDS ring filled by LDS-DMA and guarded by per-slot counters, several 32-query
@@ -76,6 +78,68 @@ __host__ __device__ __forceinline__ uint32_t fp4_bits8(uint32_t byte) {
     return y << 1;
 }
 
+// ---- the two metrics of the engine ---------------------------------------------------------------------------------------
+// Everything that is the same for both — the LDS ring and its counters, LDS-DMA staging, the skewed accumulator groups and
+// their interleaved max trees, the tile test, the push / flush protocol, capacity-sized grids — lives ONCE in knn_tile_body;
+// a metric supplies the operand encoding, the matrix instruction, the score arithmetic and the key format.
+typedef int knl_v4i __attribute__((ext_vector_type(4)));
+typedef int knl_v16i __attribute__((ext_vector_type(16)));
+
+// Hamming distance of 256-bit descriptors (the hot path): {0,1} FP4 operands, f32 accumulators, u32 keys d << 23 | row,
+// lists of 32; a row qualifies iff dot - |t| / 2 > h, h = (|q| - B - 1) / 2 (header).
+struct KtHamming {
+    typedef knn_v16f Acc; typedef knn_v8i Bop; typedef uint32_t Key; typedef float Thr;
+    static constexpr bool hamming = true;
+    static constexpr int KL = 32, QBYTES = 32;
+    static __device__ __forceinline__ Acc mfma(Acc acc, const uint4& f, const Bop& b) {
+        const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    static __device__ __forceinline__ int raw(float x) { return __float_as_int(x); }
+    // k-step s of one query row: its operand fragment and the contribution to |q|
+    static __device__ __forceinline__ void load_b(const uint8_t* qrow, int s, int half, Bop& b, int& norm) {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(qrow)[2 * s + half];
+        norm += __popc(w);
+        b = knn_v8i{(int)fp4_bits8(w), (int)fp4_bits8(w >> 8), (int)fp4_bits8(w >> 16), (int)fp4_bits8(w >> 24), 0, 0, 0, 0};
+    }
+    static __device__ __forceinline__ Thr open_thr(Thr nq) { return (nq - 513.f) * 0.5f; }       // B = 512: anything
+    static __device__ __forceinline__ int tile_thr(Thr h, uint32_t tile_norm_bits) { return __float_as_int(h + __uint_as_float(tile_norm_bits)); }
+    static __device__ __forceinline__ void insert(Key (&lst)[KL], Key e) { knn_insert<32>(lst, e); }
+};
+
+// squared L2 of 128-dimensional u8 descriptors (BASELINE configs[2]): components centred to i8 (x XOR 0x80),
+// v_mfma_i32_32x32x32_i8, score s = 2 <q',t'> - |t'|^2 (larger is nearer, d^2 = |q'|^2 - s), u64 keys d^2 << 32 | row,
+// lists of KL; a row qualifies iff s >= thr, thr = |q'|^2 - (k-th d^2)  (non-strict: see the header).  The side array holds
+// the NEGATED norms, a tile's bound is its first (smallest-norm) row's.
+constexpr int KNL_PAD_NORM = 1 << 30;
+constexpr int KNL_THR_OPEN = -(1 << 30) + (1 << 24);        // below every real row's score (>= -3 * 2^21), above every pad row's (-2^30)
+constexpr unsigned long long KNL_EMPTY = ~0ull;
+template <int KL> __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsigned long long key);
+template <int KL_>
+struct KtL2 {
+    typedef knl_v16i Acc; typedef knl_v4i Bop; typedef unsigned long long Key; typedef int Thr;
+    static constexpr bool hamming = false;
+    static constexpr int KL = KL_, QBYTES = 128;
+    static __device__ __forceinline__ Acc mfma(Acc acc, const uint4& f, const Bop& b) {
+        const knl_v4i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w};
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(v, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int raw(int x) { return x; }
+    static __device__ __forceinline__ void load_b(const uint8_t* qrow, int s, int half, Bop& b, int& norm) {
+        const uint4 w = reinterpret_cast<const uint4*>(qrow)[2 * s + half];
+        const uint32_t a[4] = {w.x ^ 0x80808080u, w.y ^ 0x80808080u, w.z ^ 0x80808080u, w.w ^ 0x80808080u};
+        b = knl_v4i{(int)a[0], (int)a[1], (int)a[2], (int)a[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int x = (int)(int8_t)(a[k] >> (8 * c)); norm += x * x; }
+    }
+    static __device__ __forceinline__ Thr open_thr(Thr) { return KNL_THR_OPEN; }
+    // 2 max(dot) + nnmax >= thr  <=>  max(dot) > ceil((thr - nnmax) / 2) - 1
+    static __device__ __forceinline__ int tile_thr(Thr thr, uint32_t tile_norm_bits) { return ((thr - (int)tile_norm_bits + 1) >> 1) - 1; }
+    static __device__ __forceinline__ void insert(Key (&lst)[KL], Key e) { knl_insert<KL>(lst, e); }
+};
+
 // train [nt][8] u32 (packed) -> FP4 {0,1}, tile-major (tile of 32 rows = [chunk 0..7][row 0..31][16 B]: MFMA k-step s of a wave
 // needs chunk 2s + (lane >> 5) of row (lane & 31) == byte s*1024 + lane*16 of the tile, one linear KB per k-step), IN NORM
 // ORDER: sorted row i is the caller's row perm[i]; padded with all-zero rows to a multiple of KT_ST_ROWS.  One thread per
@@ -94,11 +158,15 @@ __global__ __launch_bounds__(256) void knn_tile_expand_kernel(const uint32_t* __
 // nminh: [n_st] float4 = half the smallest norm of each of the super-tile's 4 tiles.
 // prune_tol: 0 = exact k-NN lists; > 0 = lists are exact only for the neighbours with d < best * prune_tol (the vote's rule).
 // Grid (ceil(nq / knn_qpb<NT>()), nseg), block 512.  Segment s covers super-tiles [s * st_per_seg, ...).  out: [seg][nq][32] keys.
-template <int NT>
-__device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
-                                              const uint32_t* __restrict__ side, const float4* __restrict__ nminh, int nt_pad,
-                                              int st_per_seg, uint32_t* __restrict__ out, uint32_t* __restrict__ pend_ws, float prune_tol,
-                                              const uint32_t* __restrict__ nq_dev) {
+template <int NT, typename M>
+__device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
+                                              const uint32_t* __restrict__ side, const uint4* __restrict__ nminh, int nt_pad,
+                                              int st_per_seg, typename M::Key* __restrict__ out, typename M::Key* __restrict__ pend_ws,
+                                              float prune_tol, const uint32_t* __restrict__ nq_dev) {
+    typedef typename M::Acc Acc;
+    typedef typename M::Key Key;
+    typedef typename M::Thr Thr;
+    constexpr int KL = M::KL;
     static_assert(NT == 2 || NT == 4, "two accumulator groups of NT / 2");
     // nq_dev != null: the grid was sized by CAPACITY and the query count lives on the device (the host did not wait for the
     // ORB stage's counts); blocks past the last query leave at once — before any barrier, the test is block-uniform
@@ -108,7 +176,7 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
     __shared__ uint4 lds[KT_RING][KT_ST_U4];
     __shared__ __attribute__((aligned(16))) uint32_t lds_side[KT_RING][KT_SIDE_U32];
     __shared__ uint32_t s_filled[KT_RING], s_done[KT_RING];           // waves that wrote / finished reading each slot (monotonic)
-    __shared__ float s_nq[KT_WAVES][NT][32];                          // |q| of every query of the block (read in the slow path and the flush only)
+    __shared__ Thr s_nq[KT_WAVES][NT][32];                            // |q| (Hamming) / |q'|^2 (L2) of every query of the block (read in the slow path and the flush only)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, ql = lane & 31;
     const int qbase = blockIdx.x * knn_qpb<NT>() + wave * 32 * NT;
@@ -116,49 +184,46 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
     const int n_st = nt_pad / KT_ST_ROWS;
     const int st0 = seg * st_per_seg, st1 = min(n_st, st0 + st_per_seg);
     const int nst = st1 - st0;
-    uint32_t* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KT_WAVES + wave) * knn_pend_words_per_wave<NT>();
-    auto pend = [&](int i) -> uint32_t* { return P0 + (size_t)i * KT_PEND_CAP * 64; };
+    Key* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KT_WAVES + wave) * knn_pend_words_per_wave<NT>();      // (in keys)
+    auto pend = [&](int i) -> Key* { return P0 + (size_t)i * KT_PEND_CAP * 64; };
 
     // B operands: lane l holds, of query (l & 31) of each tile, the 32 bits of packed dword 2s + (l >> 5) for k-step s
     // (register budget: the kernel must leave room for two waves of the other units' kernels per SIMD — at 2 waves of 224
     // registers only one 64-register wave fits beside it and the overlapped step lost 4 %; hence |q| in LDS and the four
     // pending counts packed into one register)
-    knn_v8i bq[NT][4];
+    typename M::Bop bq[NT][4];
     auto load_queries = [&]() {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const uint32_t* qp = q + (size_t)min(qbase + 32 * i + ql, nq - 1) * 8;
+            const uint8_t* qp = q + (size_t)min(qbase + 32 * i + ql, nq - 1) * M::QBYTES;
             int pc = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint32_t w = qp[2 * s + half];
-                pc += __popc(w);
-                bq[i][s] = knn_v8i{(int)fp4_bits8(w), (int)fp4_bits8(w >> 8), (int)fp4_bits8(w >> 16), (int)fp4_bits8(w >> 24), 0, 0, 0, 0};
-            }
+            for (int s = 0; s < 4; ++s) M::load_b(qp, s, half, bq[i][s], pc);
             const int tot = pc + __shfl_xor(pc, 32);                   // (all lanes: a shuffle under `if (half == 0)` would read inactive lanes)
-            if (half == 0) s_nq[wave][i][ql] = (float)tot;
+            if (half == 0) s_nq[wave][i][ql] = (Thr)tot;
         }
     };
     load_queries();
-    auto nq_of = [&](int i) -> float { return s_nq[wave][i][ql]; };     // (same wave wrote it: no barrier needed, the compiler waits for the DS write)
+    auto nq_of = [&](int i) -> Thr { return s_nq[wave][i][ql]; };     // (same wave wrote it: no barrier needed, the compiler waits for the DS write)
     // list p of this lane: wave-local query 64 p + lane, i.e. tile 2 p + half, column ql
-    auto list_of = [&](int p) -> uint4* { return reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qbase + 64 * p + lane, nq - 1)) * 32); };
+    auto list_of = [&](int p) -> uint4* { return reinterpret_cast<uint4*>(out + ((size_t)seg * nq + min(qbase + 64 * p + lane, nq - 1)) * KL); };
+    constexpr int LIST_U4 = KL * (int)sizeof(Key) / 16;               // uint4 per list
 #pragma unroll
     for (int p = 0; p < G; ++p)
         if (qbase + 64 * p + lane < nq) {
             uint4* l = list_of(p);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) l[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
+            for (int i = 0; i < LIST_U4; ++i) l[i] = make_uint4(~0u, ~0u, ~0u, ~0u);                    // (the empty key of either format)
         }
     // h = (|q| - B - 1) / 2 with B = the largest distance the query still accepts (512 = anything); a row qualifies iff
     // dot - |t| / 2 > h
-    float h[NT];
+    Thr h[NT];                                                         // (L2: the score threshold thr)
     uint32_t cntp = 0;                                                 // keys pending in this lane's private buffers, 8 bits per query tile
 #pragma unroll
-    for (int i = 0; i < NT; ++i) h[i] = (nq_of(i) - 513.f) * 0.5f;
+    for (int i = 0; i < NT; ++i) h[i] = M::open_thr(nq_of(i));
 #ifdef KT_EXPERIMENT_NOSLOW          // measurement only (tools/knn_experiments.sh): no row ever qualifies, the pure streaming rate
 #pragma unroll
-    for (int i = 0; i < NT; ++i) h[i] = 1e9f;
+    for (int i = 0; i < NT; ++i) h[i] = (Thr)1e9f;
 #endif
     auto cnt_of = [&](uint32_t packed, int i) -> uint32_t { return (packed >> (8 * i)) & 255u; };
 
@@ -169,42 +234,53 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
             const int A = 2 * p, B = 2 * p + 1;
             const uint32_t p_lo = __shfl(cntp, ql), p_hi = __shfl(cntp, ql + 32);
             const uint32_t c_lo = cnt_of(p_lo, half ? B : A), c_hi = cnt_of(p_hi, half ? B : A);
-            const uint32_t* PP = (half ? pend(B) : pend(A)) + ql;
+            const Key* PP = (half ? pend(B) : pend(A)) + ql;
             uint4* my_list = list_of(p);
             const bool owner_valid = qbase + 64 * p + lane < nq;
-            uint32_t lst[32];
+            Key lst[KL];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < LIST_U4; ++i) {
                 const uint4 v = my_list[i];
-                lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w;
+                if constexpr (M::hamming) { lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w; }
+                else { lst[2 * i] = ((Key)v.y << 32) | v.x; lst[2 * i + 1] = ((Key)v.w << 32) | v.z; }
             }
             // pending keys are fetched KT_FLUSH_BATCH at a time (their L2 latency is paid once per batch); a slot past a
-            // lane's count reads as KNN_EMPTY, whose insertion is a no-op
+            // lane's count reads as the empty key, whose insertion is a no-op
             for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_lo) != 0ull; base += KT_FLUSH_BATCH) {
-                uint32_t e[KT_FLUSH_BATCH];
+                Key e[KT_FLUSH_BATCH];
 #pragma unroll
-                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : KNN_EMPTY;
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_lo ? PP[(base + i) * 64] : (Key)~(Key)0;
 #pragma unroll
-                for (int i = 0; i < KT_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) M::insert(lst, e[i]);
             }
             for (uint32_t base = 0; __builtin_amdgcn_ballot_w64(base < c_hi) != 0ull; base += KT_FLUSH_BATCH) {
-                uint32_t e[KT_FLUSH_BATCH];
+                Key e[KT_FLUSH_BATCH];
 #pragma unroll
-                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : KNN_EMPTY;
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) e[i] = base + i < c_hi ? PP[(base + i) * 64 + 32] : (Key)~(Key)0;
 #pragma unroll
-                for (int i = 0; i < KT_FLUSH_BATCH; ++i) knn_insert<32>(lst, e[i]);
+                for (int i = 0; i < KT_FLUSH_BATCH; ++i) M::insert(lst, e[i]);
             }
             if (owner_valid) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
+                for (int i = 0; i < LIST_U4; ++i) {
+                    if constexpr (M::hamming) my_list[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
+                    else my_list[i] = make_uint4((uint32_t)lst[2 * i], (uint32_t)(lst[2 * i] >> 32), (uint32_t)lst[2 * i + 1], (uint32_t)(lst[2 * i + 1] >> 32));
+                }
             }
-            // new bound of the query this lane OWNS: the k-th distance (inclusive: see the header), and with prune_tol the
-            // vote's acceptance bound — a neighbour counts iff (float)d < (float)best * tol (f32, strict), best only
-            // decreases, so d <= ceil(best * tol) - 1 is necessary for ever counting
-            float bnd = lst[31] == KNN_EMPTY ? 512.f : (float)(lst[31] >> KNN_KEY_SHIFT);
-            if (prune_tol > 0.f) bnd = fminf(bnd, ceilf((float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol) - 1.f);     // (empty list: 511 * tol, no bound)
-            h[A] = (nq_of(A) - __shfl(bnd, ql) - 1.f) * 0.5f;
-            h[B] = (nq_of(B) - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
+            if constexpr (M::hamming) {
+                // new bound of the query this lane OWNS: the k-th distance (inclusive: see the header), and with prune_tol the
+                // vote's acceptance bound — a neighbour counts iff (float)d < (float)best * tol (f32, strict), best only
+                // decreases, so d <= ceil(best * tol) - 1 is necessary for ever counting
+                float bnd = lst[31] == KNN_EMPTY ? 512.f : (float)(lst[31] >> KNN_KEY_SHIFT);
+                if (prune_tol > 0.f) bnd = fminf(bnd, ceilf((float)(lst[0] >> KNN_KEY_SHIFT) * prune_tol) - 1.f);     // (empty list: 511 * tol, no bound)
+                h[A] = (nq_of(A) - __shfl(bnd, ql) - 1.f) * 0.5f;
+                h[B] = (nq_of(B) - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
+            } else {
+                // thr = |q'|^2 - (k-th d^2) of the query this lane owns (tile A for the lower half-wave, B for the upper)
+                const int t = lst[KL - 1] == KNL_EMPTY ? KNL_THR_OPEN : nq_of(half ? B : A) - (int)(lst[KL - 1] >> 32);
+                h[A] = __shfl(t, ql);
+                h[B] = __shfl(t, 32 + ql);
+            }
         }
         cntp = 0;
     };
@@ -252,70 +328,80 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
         }
         wait_ge(&s_filled[j % KT_RING], (uint32_t)KT_WAVES * (uint32_t)(j / KT_RING + 1));
     };
-    auto mfma = [&](knn_v16f acc, const uint4& f, const knn_v8i& b) {
-        const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
-        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-    };
+    auto mfma = [&](Acc acc, const uint4& f, const typename M::Bop& b) { return M::mfma(acc, f, b); };
     // maxima of the raw bit patterns: triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
     // (only the overall maximum is kept: the slow path recomputes the triple maxima it gates on — ten registers per skew group
     // that would otherwise stay live from the trees to the tests)
-    auto tree = [&](const knn_v16f& acc) -> int {
+    auto tree = [&](const Acc& acc) -> int {
         int tk[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            tk[k] = max(max(__float_as_int(acc[3 * k]), __float_as_int(acc[3 * k + 1])), __float_as_int(acc[3 * k + 2]));
-        return max(max(max(__float_as_int(acc[15]), tk[0]), tk[1]), max(max(tk[2], tk[3]), tk[4]));
+            tk[k] = max(max(M::raw(acc[3 * k]), M::raw(acc[3 * k + 1])), M::raw(acc[3 * k + 2]));
+        return max(max(max(M::raw(acc[15]), tk[0]), tk[1]), max(max(tk[2], tk[3]), tk[4]));
     };
     // Slow path (about one tile in twenty): exact per-row test with the rows' own norms; usually ONE value of ONE lane
     // qualifies, so every test is a wave-uniform "nobody" branch that falls through.  Register r of a lane is row
     // (r & 3) + 8 (r >> 2) + 4 half of the tile.
-    auto candidates = [&](const knn_v16f& acc, int thri, const uint32_t* sd, int tt, float& hh, int qt, uint32_t* P) {
+    auto candidates = [&](const Acc& acc, int thri, const uint32_t* sd, int tt, Thr& hh, int qt, Key* P) {
         float dbest = 1024.f;
-        const float nq_i = nq_of(qt);
+        const Thr nq_i = nq_of(qt);
         uint32_t c = cnt_of(cntp, qt);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int kk = k < 5 ? k : 0;
-            const bool gate = (k < 5 ? max(max(__float_as_int(acc[3 * kk]), __float_as_int(acc[3 * kk + 1])), __float_as_int(acc[3 * kk + 2]))
-                                     : __float_as_int(acc[15])) > thri;
+            const bool gate = (k < 5 ? max(max(M::raw(acc[3 * kk]), M::raw(acc[3 * kk + 1])), M::raw(acc[3 * kk + 2]))
+                                     : M::raw(acc[15])) > thri;
             if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
             // the norms of the triple's rows: three LDS reads in flight, one wait (row by row every test paid its own round trip)
-            float nrm3[3];
+            uint32_t nrm3[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int r = min(3 * k + u, 15);
-                nrm3[u] = __uint_as_float(sd[tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half]);
+                nrm3[u] = sd[tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
             }
 #pragma unroll
             for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
                 const int ro = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;           // row within the super-tile
-                const float nrm = nrm3[r - 3 * k];
-                const float v = acc[r];
-                const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;                  // exact: halves of small integers
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
-                    if (hit) {
-                        const float d = nq_i + nrm - 2.f * v;
-                        P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | sd[KT_ST_ROWS + ro];
-                        ++c;
-                        dbest = fminf(dbest, d);
+                if constexpr (M::hamming) {
+                    const float nrm = __uint_as_float(nrm3[r - 3 * k]);
+                    const float v = acc[r];
+                    const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;              // exact: halves of small integers
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
+                        if (hit) {
+                            const float d = nq_i + nrm - 2.f * v;
+                            P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | sd[KT_ST_ROWS + ro];
+                            ++c;
+                            dbest = fminf(dbest, d);
+                        }
+                    }
+                } else {
+                    const int sc = 2 * acc[r] + (int)nrm3[r - 3 * k];                 // s = 2 <q',t'> - |t'|^2 (the side array holds -|t'|^2)
+                    const bool hit = sc >= hh;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
+                        if (hit) {
+                            P[c * 64 + lane] = ((Key)(uint32_t)(nq_i - sc) << 32) | (Key)sd[KT_ST_ROWS + ro];
+                            ++c;
+                        }
                     }
                 }
             }
         }
         cntp = (cntp & ~(255u << (8 * qt))) | (c << (8 * qt));
-        if (prune_tol > 0.f) {
-            // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
-            // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
-            // valid, and so is the one its partner lane (the other 16 rows of the same query) derived.
-            float bn = ceilf(dbest * prune_tol) - 1.f;
-            bn = fminf(bn, __shfl_xor(bn, 32));
-            hh = fmaxf(hh, (nq_i - bn - 1.f) * 0.5f);
+        if constexpr (M::hamming) {
+            if (prune_tol > 0.f) {
+                // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the
+                // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
+                // valid, and so is the one its partner lane (the other 16 rows of the same query) derived.
+                float bn = ceilf(dbest * prune_tol) - 1.f;
+                bn = fminf(bn, __shfl_xor(bn, 32));
+                hh = fmaxf(hh, (nq_i - bn - 1.f) * 0.5f);
+            }
         }
     };
 
     if (nst > 0) {
-        const knn_v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        knn_v16f a[NT];
+        const Acc zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        Acc a[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) a[i] = zero;
         // G accumulator chains through the four k-steps of one A tile
@@ -331,7 +417,7 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
         // trees + thresholds of group GB for the tile whose half norm is nmh_; then the tests
 #define KT_TREES(GB, nmh_)                                                                                             \
         int mx_[G], ti_[G];                                                                                           \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) { mx_[g_] = tree(a[GB + g_]); ti_[g_] = __float_as_int(h[GB + g_] + (nmh_)); }
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) { mx_[g_] = tree(a[GB + g_]); ti_[g_] = M::tile_thr(h[GB + g_], (nmh_)); }
 #define KT_TEST(GB, sd_, tt_)                                                                                          \
         {                                                                                                             \
             bool any_ = false;                                                                                        \
@@ -349,7 +435,7 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
         {                                                                                                             \
             const uint4* Lx_ = (tt) == KT_TPS - 1 ? Ln : Lc + ((tt) + 1) * 256;                                       \
             n0 = Lx_[0]; n1 = Lx_[64];                                                                                \
-            const float nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                     \
+            const uint32_t nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                  \
             {                                                                                                         \
                 __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);                                                             \
                 KT_MFMAS(G, c0, c1, c2, c3)                                                                            \
@@ -380,7 +466,7 @@ __device__ __forceinline__ void knn_tile_body(const uint32_t* __restrict__ q, in
             const int slot = j % KT_RING;
             Lc = lds[slot] + lane;
             const uint32_t* sdc = lds_side[slot];
-            const float4 nm4 = nminh[st0 + j];                         // (wave-uniform address: scalar loads)
+            const uint4 nm4 = nminh[st0 + j];                          // (wave-uniform address: scalar loads; float / int bit patterns)
             // the tile after the segment's last is the last one again: recomputed into group A, never tested
             const uint4* Ln = j + 1 < nst ? lds[(j + 1) % KT_RING] + lane : Lc + (KT_TPS - 1) * 256;
             KT_TILE(0, x0, x1, x2, x3, y0, y1, y2, y3)
@@ -419,7 +505,8 @@ __global__ __attribute__((amdgpu_num_vgpr(KT4_VGPRS))) __launch_bounds__(KT_THRE
 void knn_tile4_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                       const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
-    knn_tile_body<4>(q, nq, tx, side, nminh, nt_pad, st_per_seg, out, pend_ws, prune_tol, nq_dev);
+    knn_tile_body<4, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
+                                prune_tol, nq_dev);
 }
 #ifdef KT2_VGPRS           /* experiments only (tools/knn_experiments.sh): a cap below the 128 that 4 waves per SIMD allow */
 __global__ __attribute__((amdgpu_num_vgpr(KT2_VGPRS))) __launch_bounds__(KT_THREADS, 4)
@@ -429,7 +516,8 @@ __global__ __launch_bounds__(KT_THREADS, 4)
 void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                       const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
-    knn_tile_body<2>(q, nq, tx, side, nminh, nt_pad, st_per_seg, out, pend_ws, prune_tol, nq_dev);
+    knn_tile_body<2, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
+                                prune_tol, nq_dev);
 }
 
 }  // namespace slideo

@@ -102,7 +102,7 @@ struct slideo_matcher {
     size_t ws_budget = (size_t)48 << 30;      // all slots together (SLIDEO_WS_GB); 288 GB of HBM per GPU
 
     DevBuf d_tables, d_rng, d_ictab;
-    struct L2Set { DevBuf d_tx, d_tn, d_perm, d_keys, d_pend; int nt = 0, nt_pad = 0; bool ready = false; } l2;   // cfg2: the L2 train set
+    struct L2Set { DevBuf d_tx, d_tn, d_side, d_perm, d_keys, d_pend; int nt = 0, nt_pad = 0; bool ready = false; } l2;   // cfg2: the L2 train set
     uint32_t rng_len = 0;
     int ic_shift = 0, ic_entries = 0;     // intensity-centroid weight table of describe_kernel (geom.h ic_weight_table)
     std::vector<std::unique_ptr<GeomEntry>> geoms;
@@ -1327,7 +1327,7 @@ void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
     const int nt_pad = knn_pad_rows(nt);
     DevBuf d_t, d_norm;
     d_t.reserve(std::max<size_t>((size_t)nt * 128, 64)); d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64));
-    L.d_tx.reserve((size_t)nt_pad * 128); L.d_tn.reserve((size_t)nt_pad * 4); L.d_perm.reserve((size_t)nt_pad * 4);
+    L.d_tx.reserve((size_t)nt_pad * 128); L.d_perm.reserve((size_t)nt_pad * 4);
     // norms on the device, the norm order on the host (a stable index sort), then the centred tile-major operand gathered in
     // that order
     std::vector<int32_t> h_norm((size_t)std::max(nt, 1)), h_perm((size_t)nt_pad, -1);
@@ -1354,30 +1354,42 @@ void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
             for (int r = 0; r < 32; ++r) shuffled[(size_t)p * 32 + r] = h_perm[(size_t)order[p] * 32 + r];
         h_perm.swap(shuffled);
     }
+    // the side array of the tile engine (knn_tile.hip.h): per super-tile 128 negated norms (as i32) and 128 original rows; and
+    // per tile the negated norm of its first row (the tile's bound: rows ascend inside a tile)
+    const int n_st = nt_pad / KT_ST_ROWS;
+    std::vector<uint32_t> side((size_t)n_st * KT_SIDE_U32), tnorm((size_t)n_st * 4);
+    for (int r = 0; r < nt_pad; ++r) {
+        const int32_t nn = h_perm[r] >= 0 ? -h_norm[h_perm[r]] : -KNL_PAD_NORM;
+        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + (r % KT_ST_ROWS)] = (uint32_t)nn;
+        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + KT_ST_ROWS + (r % KT_ST_ROWS)] = (uint32_t)h_perm[r];
+        if (r % 32 == 0) tnorm[r / 32] = (uint32_t)nn;
+    }
+    L.d_side.reserve(side.size() * 4 + 16); L.d_tn.reserve(tnorm.size() * 4 + 16);
+    HIP_CHECK(hipMemcpyAsync(L.d_side.p, side.data(), side.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(L.d_tn.p, tnorm.data(), tnorm.size() * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(L.d_perm.p, h_perm.data(), (size_t)nt_pad * 4, hipMemcpyHostToDevice, st));
-    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt, nt_pad, L.d_perm.as<int32_t>(), d_norm.as<int32_t>(),
-                                                                   L.d_tx.as<uint4>(), L.d_tn.as<int32_t>());
+    knl_expand_train_kernel<<<cdiv(nt_pad * 8, 256), 256, 0, st>>>(d_t.as<uint8_t>(), nt_pad, L.d_perm.as<int32_t>(), L.d_tx.as<uint4>());
     check_launch("knl_expand_train_kernel");
-    HIP_CHECK(hipStreamSynchronize(st));            // d_t / d_norm / h_perm go out of scope
+    HIP_CHECK(hipStreamSynchronize(st));            // d_t / d_norm / the host vectors go out of scope
     L.nt = nt; L.nt_pad = nt_pad; L.ready = true;
 }
 
 // queries on the device -> idx / dist on the device (m->d_tapidx / d_tapdist); kernel time between two events if asked for
 void l2_query(slideo_matcher* m, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed) {
     slideo_matcher::L2Set& L = m->l2;
-    const int qblocks = cdiv(nq, KNL_QPB);
-    L.d_keys.reserve((size_t)nq * KLIST * 8); L.d_pend.reserve((size_t)qblocks * KT_WAVES * KNL_PEND_WORDS_PER_WAVE * 4);
+    const int qblocks = cdiv(nq, knn_qpb<2>());
+    L.d_keys.reserve((size_t)nq * KLIST * 8); L.d_pend.reserve((size_t)qblocks * KT_WAVES * knn_pend_words_per_wave<2>() * 8);   // (u64 keys)
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
     if (timed) HIP_CHECK(hipEventRecord(S.ev[0], st));
     const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
-        knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+        knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
                                                           L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
     else if (kl == 16)
-        knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+        knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
                                                            L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
     else
-        knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_tn.as<int32_t>(), L.d_perm.as<int32_t>(), L.nt_pad,
+        knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
                                                               L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
     check_launch("knn_l2_kernel");
     knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(L.d_keys.as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
