@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 3
+#define SLIDEO_ABI_VERSION 4
 
 enum {
     SLIDEO_OK = 0,
@@ -113,6 +113,16 @@ typedef struct slideo_ocv_variants {
     int32_t lm;
     /* cv::RNG multiplier (RANSAC sample schedule [OCV A.9], BRIEF pattern [OCV A.7]); any value [hip] */
     uint32_t rng_mul;             /* 4164903690 */
+    /* verify_model 1 only: the homography of a point set, HomographyEstimatorCallback::runKernel of
+     * calib3d/src/fundam.cpp (recalled; no counterpart in the reference, which never fits a homography)
+     *   0 [hip] normalised DLT: centroid / mean-absolute-deviation normalisation, the 9x9 normal matrix L^T L
+     *           accumulated in f64, cv::eigen = the Jacobi sweep of core/src/lapack.cpp (JacobiImpl_, pivot =
+     *           largest off-diagonal element, its own hypot), H = the eigenvector of the smallest eigenvalue,
+     *           de-normalised and scaled by 1 / H[8]
+     *   1       minimal samples (4 pairs) only: the 8x8 system with h33 = 1 on the same normalised points by
+     *           Gaussian elimination with partial pivoting (definitional cross-check; point sets of more than
+     *           4 pairs still take form 0) */
+    int32_t hdlt;
 } slideo_ocv_variants;
 
 /* Every literal the reference hard-codes on the hot path, as one struct whose
@@ -151,6 +161,18 @@ typedef struct slideo_config {
      * a query votes for its nearest row iff it has a second neighbour and (float)d1 < r * (float)d2 (f32,
      * strict); needs knn_k >= 2. */
     float   ratio_test;           /* 0.0f */
+    /* Extension with no reference counterpart (BASELINE.json north_star "RANSAC homography verification",
+     * configs[4]): the geometric model of the verification step.
+     *   0 = the reference's estimateAffinePartial2D (4-DOF similarity, 2-point samples, mo/image_utils.rs:45-60)
+     *       followed by warpAffine (mo/lib.rs:339-347);
+     *   1 = an 8-DOF homography: what cv::findHomography(from, to, RANSAC, ransac_threshold, mask,
+     *       ransac_max_iters, ransac_confidence) computes (calib3d/src/fundam.cpp, recalled: 4-point samples drawn
+     *       by RANSACPointSetRegistrator::getSubset with HomographyEstimatorCallback::checkSubset, normalised DLT,
+     *       f32 re-projection error, the same cv::RNG(-1) schedule and sequential acceptance as the similarity
+     *       path, then — refine_iters > 0 and more than 4 pairs — a DLT over all inliers and refine_iters
+     *       Levenberg-Marquardt steps on the 8 parameters; the mask is not recomputed), followed by
+     *       warpPerspective(nearest, WARP_INVERSE_MAP) (imgproc/src/imgwarp.cpp) in the re-projection. */
+    int32_t verify_model;         /* 0 */
     /* which restatement of each OpenCV primitive to run (all 0 / 4164903690 by default) */
     slideo_ocv_variants ocv;
 } slideo_config;
@@ -357,7 +379,8 @@ typedef struct slideo_candidate {
     int32_t inliers;      /* rating (mo/lib.rs:310)                                    */
     int32_t survived;     /* passed the rating filter (mo/lib.rs:333)                  */
     float   similarity;   /* mo/lib.rs:351, 0 when not computed                        */
-    double  transform[6]; /* 2x3 row-major, slide -> frame (mo/image_utils.rs:52)      */
+    double  transform[9]; /* 3x3 row-major, slide -> frame; verify_model 0: rows 0-1 = the 2x3 of
+                             estimateAffinePartial2D (mo/image_utils.rs:52), row 2 = 0 0 1 (all 0 when no model was found) */
 } slideo_candidate;
 
 int32_t     slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_batch,

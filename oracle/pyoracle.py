@@ -16,7 +16,8 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 class OcvVariants(C.Structure):
     """slideo_ocv_variants (include/slideo_amd.h): which restatement of each OpenCV primitive runs."""
     _fields_ = [("gray", C.c_int32), ("blur", C.c_int32), ("resize", C.c_int32), ("atan", C.c_int32),
-                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32)]
+                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32),
+                ("hdlt", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -29,7 +30,7 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
-        ("ocv", OcvVariants),
+        ("verify_model", C.c_int32), ("ocv", OcvVariants),
     ]
 
 
@@ -39,7 +40,7 @@ VERDICT_DTYPE = np.dtype([("page_idx", "<i4"), ("similarity", "<f4"), ("inliers"
                           ("n_keypoints", "<i4")])
 CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers", "<i4"),
                             ("survived", "<i4"), ("similarity", "<f4"), ("_pad", "<i4"),
-                            ("transform", "<f8", (6,))])
+                            ("transform", "<f8", (9,))])
 
 
 def build(force=False):
@@ -220,6 +221,49 @@ def estimate_affine_partial(frm, to, cfg):
     found = lib().so_estimate_affine_partial(_p(frm), _p(to), n, C.byref(cfg), _p(M), _p(mask),
                                              C.byref(it))
     return bool(found), M.reshape(2, 3), mask[:n].copy(), it.value
+
+
+def find_homography(frm, to, cfg):
+    """cv::findHomography(RANSAC) restated (verify_model 1). Returns (found, H 3x3, mask, stats dict)."""
+    frm = np.ascontiguousarray(frm, np.float32).reshape(-1, 2)
+    to = np.ascontiguousarray(to, np.float32).reshape(-1, 2)
+    n = frm.shape[0]
+    H = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    st = np.zeros(4, np.int32)
+    found = lib().so_find_homography(_p(frm), _p(to), n, C.byref(cfg), _p(H), _p(mask), _p(st))
+    return bool(found), H.reshape(3, 3), mask[:n].copy(), dict(iters=int(st[0]), attempts=int(st[1]), rotations=int(st[2]), draws=int(st[3]))
+
+
+def homography_dlt(frm, to, variant=0):
+    frm = np.ascontiguousarray(frm, np.float32).reshape(-1, 2)
+    to = np.ascontiguousarray(to, np.float32).reshape(-1, 2)
+    H = np.zeros(9, np.float64)
+    n = lib().so_homography_dlt(_p(frm), _p(to), frm.shape[0], _p(H), variant)
+    return n, H.reshape(3, 3)
+
+
+def homography_check_subset(frm, to):
+    frm = np.ascontiguousarray(frm, np.float32).reshape(-1, 2)
+    to = np.ascontiguousarray(to, np.float32).reshape(-1, 2)
+    return bool(lib().so_homography_check_subset(_p(frm), _p(to), frm.shape[0]))
+
+
+def jacobi_eig(A):
+    """cv::eigen on a symmetric matrix (JacobiImpl_): (W descending, V rows = eigenvectors, rotations)."""
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    W = np.zeros(n); V = np.zeros((n, n))
+    rot = lib().so_jacobi_eig(_p(A), n, _p(W), _p(V))
+    return W, V, rot
+
+
+def warp_perspective_nn(src, H, dw, dh):
+    src = _img3(src)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    out = np.empty((dh, dw, 3), np.uint8)
+    lib().so_warp_perspective_nn_bgr8(_p(src), src.shape[1], src.shape[0], src.shape[1] * 3, _p(H), _p(out), dw, dh)
+    return out
 
 
 def warp_affine_nn(src, M, dw, dh):

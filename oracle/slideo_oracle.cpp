@@ -474,7 +474,8 @@ static bool config_supported(const slideo_config& c) {
            c.ratio_test >= 0.f && !(c.ratio_test > 0.f && c.knn_k < 2) &&
            c.ocv.gray >= 0 && c.ocv.gray <= 1 && c.ocv.blur >= 0 && c.ocv.blur <= 3 && c.ocv.resize >= 0 && c.ocv.resize <= 1 &&
            c.ocv.atan >= 0 && c.ocv.atan <= 1 && c.ocv.warp >= 0 && c.ocv.warp <= 1 && c.ocv.area >= 0 && c.ocv.area <= 1 &&
-           c.ocv.lm >= 0 && c.ocv.lm <= 1;
+           c.ocv.lm >= 0 && c.ocv.lm <= 1 && c.ocv.hdlt >= 0 && c.ocv.hdlt <= 1 &&
+           c.verify_model >= 0 && c.verify_model <= 1;
 }
 
 struct Pyramid {
@@ -780,15 +781,25 @@ static bool solve4(const double Ain[16], const double bin[4], double x[4]) {
     return true;
 }
 
-// ocv.lm 1: cv::solve(A, b, DECOMP_EIG) — core/src/lapack.cpp JacobiImpl_ (largest off-diagonal pivot, n*n*30 sweeps at most,
-// eigenvalues sorted descending) followed by SVBkSb: x = sum_i (e_i . b) / w_i * e_i over the w_i above 2 eps * sum(w).
-static void jacobi_eig4(double A[16], double W[4], double V[16]) {
-    const int n = 4;
+// core/src/lapack.cpp: the hypot OpenCV's Jacobi sweep uses (its own template, not libm's)
+static inline double hypot_cv(double a, double b) {
+    a = std::fabs(a); b = std::fabs(b);
+    if (a > b) { b /= a; return a * std::sqrt(1 + b * b); }
+    if (b > 0) { a /= b; return b * std::sqrt(1 + a * a); }
+    return 0;
+}
+
+// core/src/lapack.cpp JacobiImpl_<double> — what cv::eigen runs on a symmetric matrix and what cv::solve(DECOMP_EIG)
+// builds on: pivot = the largest off-diagonal element of the upper triangle (tracked per row / per column in
+// indR / indC), at most n*n*30 rotations, stop when |pivot| <= DBL_EPSILON, eigenvalues sorted descending with
+// their eigenvectors (the ROWS of V).  A (n x n, row-major) is destroyed; only its upper triangle is read.
+// Returns the number of rotations.
+static int jacobi_eig_n(double* A, int n, double* W, double* V) {
     const double eps = DBL_EPSILON;
-    int indR[4], indC[4];
+    int indR[16], indC[16];
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
     double mv = 0;
-    int i, k, m;
+    int i, k, m, iters = 0;
     for (k = 0; k < n; ++k) {
         W[k] = A[(n + 1) * k];
         if (k < n - 1) {
@@ -800,15 +811,15 @@ static void jacobi_eig4(double A[16], double W[4], double V[16]) {
             indC[k] = m;
         }
     }
-    for (int iters = 0; iters < n * n * 30; ++iters) {
+    if (n > 1) for (iters = 0; iters < n * n * 30; ++iters) {
         for (k = 0, mv = std::fabs(A[indR[0]]), i = 1; i < n - 1; ++i) { double v = std::fabs(A[n * i + indR[i]]); if (mv < v) mv = v, k = i; }
         int l = indR[k];
         for (i = 1; i < n; ++i) { double v = std::fabs(A[n * indC[i] + i]); if (mv < v) mv = v, k = indC[i], l = i; }
         double p = A[n * k + l];
         if (std::fabs(p) <= eps) break;
         double y = (W[l] - W[k]) * 0.5;
-        double t = std::fabs(y) + std::hypot(p, y);
-        double sn = std::hypot(p, t);
+        double t = std::fabs(y) + hypot_cv(p, y);
+        double sn = hypot_cv(p, t);
         double c = t / sn;
         sn = p / sn; t = (p / t) * p;
         if (y < 0) sn = -sn, t = -t;
@@ -838,25 +849,31 @@ static void jacobi_eig4(double A[16], double W[4], double V[16]) {
         for (i = k + 1; i < n; ++i) if (W[m] < W[i]) m = i;
         if (k != m) { std::swap(W[m], W[k]); for (i = 0; i < n; ++i) std::swap(V[n * m + i], V[n * k + i]); }
     }
+    return iters;
 }
 
-static bool solve4_eig(const double Ain[16], const double bin[4], double x[4]) {
-    double A[16], W[4], V[16];
+// ocv.lm 1: cv::solve(A, b, DECOMP_EIG) — the Jacobi sweep above followed by SVBkSb:
+// x = sum_i (e_i . b) / w_i * e_i over the w_i above 2 eps * sum(w).
+template <int N>
+static bool solve_eig_n(const double* Ain, const double* bin, double* x) {
+    double A[N * N], W[N], V[N * N];
     std::memcpy(A, Ain, sizeof(A));
-    jacobi_eig4(A, W, V);
+    jacobi_eig_n(A, N, W, V);
     double thr = 0;
-    for (int i = 0; i < 4; ++i) thr += W[i];
+    for (int i = 0; i < N; ++i) thr += W[i];
     thr *= DBL_EPSILON * 2;
-    x[0] = x[1] = x[2] = x[3] = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < N; ++j) x[j] = 0;
+    for (int i = 0; i < N; ++i) {
         if (std::fabs(W[i]) <= thr) continue;
         double sdot = 0;
-        for (int j = 0; j < 4; ++j) sdot += V[4 * i + j] * bin[j];
+        for (int j = 0; j < N; ++j) sdot += V[N * i + j] * bin[j];
         sdot *= 1 / W[i];
-        for (int j = 0; j < 4; ++j) x[j] = x[j] + sdot * V[4 * i + j];
+        for (int j = 0; j < N; ++j) x[j] = x[j] + sdot * V[N * i + j];
     }
     return true;
 }
+
+static bool solve4_eig(const double Ain[16], const double bin[4], double x[4]) { return solve_eig_n<4>(Ain, bin, x); }
 
 static bool solve4_v(const double A[16], const double b[4], double x[4], int lm_variant) {
     return lm_variant == 1 ? solve4_eig(A, b, x) : solve4(A, b, x);
@@ -994,6 +1011,311 @@ static bool estimate_affine_partial(const P2f* from, const P2f* to, int count,
 }
 
 // ---------------------------------------------------------------------------
+// verify_model 1 — cv::findHomography(from, to, RANSAC, thr, mask, maxIters, confidence), calib3d/src/fundam.cpp +
+// ptsetreg.cpp + levmarq.cpp of OpenCV 4.5.2, RECALLED (the reference never fits a homography — SURVEY F4 — so this
+// row of SURVEY 8(f) N4 has no reference counterpart and no call site to anchor on; the parity target of the HIP path
+// is this restatement).  H maps from (slide) -> to (frame), 3x3 row-major, H[8] = 1.
+// ---------------------------------------------------------------------------
+
+// HomographyEstimatorCallback::runKernel.  Returns the number of models (0 when a coordinate has no spread).
+// rotations (may be null) receives the Jacobi rotation count.
+static int homography_dlt(const P2f* M, const P2f* m, int count, double H[9], int* rotations = nullptr) {
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; ++i) { cmx += m[i].x; cmy += m[i].y; cMx += M[i].x; cMy += M[i].y; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; ++i) {
+        smx += std::fabs(m[i].x - cmx); smy += std::fabs(m[i].y - cmy);
+        sMx += std::fabs(M[i].x - cMx); sMy += std::fabs(M[i].y - cMy);
+    }
+    if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double LtL[81];
+    std::fill(LtL, LtL + 81, 0.0);
+    for (int i = 0; i < count; ++i) {
+        double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
+        double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
+        double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; ++j)
+            for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; ++j) for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];      // completeSymm
+    double W[9], V[81];
+    int rot = jacobi_eig_n(LtL, 9, W, V);
+    if (rotations) *rotations = rot;
+    const double* h = V + 72;                           // eigenvector of the smallest eigenvalue
+    // Htemp = invHnorm * H0, invHnorm = [1/sm.x 0 cm.x; 0 1/sm.y cm.y; 0 0 1]
+    const double ix = 1. / smx, iy = 1. / smy;
+    double T[9];
+    for (int j = 0; j < 3; ++j) { T[j] = ix * h[j] + cmx * h[6 + j]; T[3 + j] = iy * h[3 + j] + cmy * h[6 + j]; T[6 + j] = h[6 + j]; }
+    // H0 = Htemp * Hnorm2, Hnorm2 = [sM.x 0 -cM.x sM.x; 0 sM.y -cM.y sM.y; 0 0 1]
+    const double n2 = -cMx * sMx, n5 = -cMy * sMy;
+    double R[9];
+    for (int r = 0; r < 3; ++r) { R[3 * r] = T[3 * r] * sMx; R[3 * r + 1] = T[3 * r + 1] * sMy; R[3 * r + 2] = T[3 * r] * n2 + T[3 * r + 1] * n5 + T[3 * r + 2]; }
+    const double sc = 1. / R[8];                        // convertTo(model, type, 1 / H0(2,2))
+    for (int j = 0; j < 9; ++j) H[j] = R[j] * sc;
+    return 1;
+}
+
+// Gaussian elimination with partial pivoting, N x N (the LM solver's default form here, ocv.lm 0; hdlt 1)
+template <int N>
+static bool solve_gauss_n(const double* Ain, const double* bin, double* x) {
+    double A[N][N + 1];
+    for (int i = 0; i < N; ++i) { for (int j = 0; j < N; ++j) A[i][j] = Ain[i * N + j]; A[i][N] = bin[i]; }
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        for (int r = c + 1; r < N; ++r) if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
+        if (A[p][c] == 0.0) return false;
+        if (p != c) for (int j = 0; j <= N; ++j) std::swap(A[p][j], A[c][j]);
+        for (int r = c + 1; r < N; ++r) {
+            double f = A[r][c] / A[c][c];
+            for (int j = c; j <= N; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        double sm = A[i][N];
+        for (int j = i + 1; j < N; ++j) sm -= A[i][j] * x[j];
+        x[i] = sm / A[i][i];
+    }
+    return true;
+}
+
+// ocv.hdlt 1 (definitional cross-check, minimal samples only): the same normalisation, then the 8 equations
+// of 4 pairs with h33 = 1 solved directly.
+static int homography_4pt_direct(const P2f* M, const P2f* m, double H[9]) {
+    const int count = 4;
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; ++i) { cmx += m[i].x; cmy += m[i].y; cMx += M[i].x; cMy += M[i].y; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; ++i) {
+        smx += std::fabs(m[i].x - cmx); smy += std::fabs(m[i].y - cmy);
+        sMx += std::fabs(M[i].x - cMx); sMy += std::fabs(M[i].y - cMy);
+    }
+    if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double A[64], b[8], h[9];
+    for (int i = 0; i < 4; ++i) {
+        double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
+        double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
+        double r0[8] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y}, r1[8] = {0, 0, 0, X, Y, 1, -y * X, -y * Y};
+        std::memcpy(A + 16 * i, r0, sizeof(r0)); std::memcpy(A + 16 * i + 8, r1, sizeof(r1));
+        b[2 * i] = x; b[2 * i + 1] = y;
+    }
+    if (!solve_gauss_n<8>(A, b, h)) return 0;
+    h[8] = 1;
+    const double ix = 1. / smx, iy = 1. / smy;
+    double T[9];
+    for (int j = 0; j < 3; ++j) { T[j] = ix * h[j] + cmx * h[6 + j]; T[3 + j] = iy * h[3 + j] + cmy * h[6 + j]; T[6 + j] = h[6 + j]; }
+    const double n2 = -cMx * sMx, n5 = -cMy * sMy;
+    double R[9];
+    for (int r = 0; r < 3; ++r) { R[3 * r] = T[3 * r] * sMx; R[3 * r + 1] = T[3 * r + 1] * sMy; R[3 * r + 2] = T[3 * r] * n2 + T[3 * r + 1] * n5 + T[3 * r + 2]; }
+    const double sc = 1. / R[8];
+    for (int j = 0; j < 9; ++j) H[j] = R[j] * sc;
+    return 1;
+}
+
+// precomp.hpp haveCollinearPoints: only the LAST point of the subset is tested against the pairs before it
+static bool have_collinear_points(const P2f* p, int count) {
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        double dx1 = p[j].x - p[i].x, dy1 = p[j].y - p[i].y;        // f32 differences widened, as `double dx1 = ptr[j].x - ptr[i].x`
+        for (int k = 0; k < j; ++k) {
+            double dx2 = p[k].x - p[i].x, dy2 = p[k].y - p[i].y;
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+
+static inline double det3_rows(const P2f& a, const P2f& b, const P2f& c) {   // Matx33d(a.x, a.y, 1, b.x, b.y, 1, c.x, c.y, 1)
+    const double a00 = a.x, a01 = a.y, a02 = 1., a10 = b.x, a11 = b.y, a12 = 1., a20 = c.x, a21 = c.y, a22 = 1.;
+    return a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+}
+
+// HomographyEstimatorCallback::checkSubset (count == 4): no collinear / coincident triple through the last point in
+// either set, and the four triples keep or all flip their orientation (Marquez-Neila et al. 2013)
+static bool homography_check_subset(const P2f* ms1, const P2f* ms2, int count) {
+    if (have_collinear_points(ms1, count) || have_collinear_points(ms2, count)) return false;
+    if (count == 4) {
+        static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+        int negative = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int* t = tt[i];
+            negative += det3_rows(ms1[t[0]], ms1[t[1]], ms1[t[2]]) * det3_rows(ms2[t[0]], ms2[t[1]], ms2[t[2]]) < 0;
+        }
+        if (negative != 0 && negative != 4) return false;
+    }
+    return true;
+}
+
+// HomographyEstimatorCallback::computeError + findInliers: f32 re-projection error against (float)(thr * thr)
+static int homography_find_inliers(const P2f* M, const P2f* m, int n, const double H[9], float thr2, uint8_t* mask) {
+    const float Hf[8] = {(float)H[0], (float)H[1], (float)H[2], (float)H[3], (float)H[4], (float)H[5], (float)H[6], (float)H[7]};
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        float ww = 1.f / (Hf[6] * M[i].x + Hf[7] * M[i].y + 1.f);
+        float dx = (Hf[0] * M[i].x + Hf[1] * M[i].y + Hf[2]) * ww - m[i].x;
+        float dy = (Hf[3] * M[i].x + Hf[4] * M[i].y + Hf[5]) * ww - m[i].y;
+        float e = dx * dx + dy * dy;
+        int f = e <= thr2;
+        mask[i] = (uint8_t)f;
+        good += f;
+    }
+    return good;
+}
+
+// HomographyRefineCallback::compute: residuals and (optionally) J^T J, J^T r for h = H[0..7]; returns |r|^2
+static double lm8_eval(const P2f* M, const P2f* m, int n, const double h[8], double* A, double* v, double* rinf) {
+    double S = 0, ri = 0;
+    if (A) { std::fill(A, A + 64, 0.0); std::fill(v, v + 8, 0.0); }
+    for (int i = 0; i < n; ++i) {
+        double Mx = M[i].x, My = M[i].y;
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        double ex = xi - m[i].x, ey = yi - m[i].y;
+        S += ex * ex; S += ey * ey;
+        ri = std::max(ri, std::max(std::fabs(ex), std::fabs(ey)));
+        if (A) {
+            const double J0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            const double J1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            for (int a = 0; a < 8; ++a) {
+                for (int b = 0; b < 8; ++b) A[a * 8 + b] += J0[a] * J0[b] + J1[a] * J1[b];
+                v[a] += J0[a] * ex + J1[a] * ey;
+            }
+        }
+    }
+    if (rinf) *rinf = ri;
+    return S;
+}
+
+// calib3d/src/levmarq.cpp LMSolverImpl::run on the 8 parameters (the same loop as lm_refine above)
+static void lm8_refine(const P2f* M, const P2f* m, int n, double h[8], int max_iters, int lm_variant) {
+    const double eps = (double)FLT_EPSILON;
+    double x[8], xd[8], A[64], v[8], D[8], d[8], Ap[64], rinf = 0;
+    std::memcpy(x, h, sizeof(x));
+    auto solve = [&](const double* a, const double* b, double* o) { return lm_variant == 1 ? solve_eig_n<8>(a, b, o) : solve_gauss_n<8>(a, b, o); };
+    double S = lm8_eval(M, m, n, x, A, v, &rinf);
+    for (int i = 0; i < 8; ++i) D[i] = A[i * 8 + i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        std::memcpy(Ap, A, sizeof(A));
+        for (int i = 0; i < 8; ++i) Ap[i * 8 + i] += lambda * D[i];
+        if (!solve(Ap, v, d)) std::fill(d, d + 8, 0.0);
+        for (int i = 0; i < 8; ++i) xd[i] = x[i] - d[i];
+        double Sd = lm8_eval(M, m, n, xd, nullptr, nullptr, nullptr);
+        double dS = 0;
+        for (int i = 0; i < 8; ++i) {
+            double t = 2 * v[i];
+            for (int j = 0; j < 8; ++j) t -= A[i * 8 + j] * d[j];
+            dS += d[i] * t;
+        }
+        double R = (S - Sd) / (std::fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            double t = 0;
+            for (int i = 0; i < 8; ++i) t += d[i] * v[i];
+            double nu = (Sd - S) / (std::fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = std::min(std::max(nu, 2.), 10.);
+            if (lambda == 0) {
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < 8; ++i) {
+                    double e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, col[8];
+                    e[i] = 1;
+                    if (solve(A, e, col)) maxval = std::max(maxval, std::fabs(col[i]));
+                }
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            std::memcpy(x, xd, sizeof(x));
+            lm8_eval(M, m, n, x, A, v, &rinf);
+        }
+        iter++;
+        double dinf = 0;
+        for (int i = 0; i < 8; ++i) dinf = std::max(dinf, std::fabs(d[i]));
+        if (!(iter < max_iters && dinf >= eps && rinf >= eps)) break;
+    }
+    std::memcpy(h, x, sizeof(x));
+}
+
+struct HomographyStats { int iters = 0, attempts = 0, rotations = 0, draws = 0; };
+
+// findHomography(RANSAC) = RANSACPointSetRegistrator::run with modelPoints 4 + the refinement of fundam.cpp.
+static bool find_homography(const P2f* from, const P2f* to, int count, const slideo_config& c, double H[9], uint8_t* mask,
+                            HomographyStats* st = nullptr) {
+    const int model_points = 4;
+    std::fill(H, H + 9, 0.0);
+    std::fill(mask, mask + count, (uint8_t)0);
+    if (count < model_points) return false;
+    bool result = false;
+    if (count == model_points) {                                        // `method == 0 || npoints == 4`: the kernel alone
+        result = homography_dlt(from, to, count, H) > 0;
+        if (result) std::fill(mask, mask + count, (uint8_t)1);
+        else std::fill(H, H + 9, 0.0);
+        return result;
+    }
+    const float thr2 = (float)(c.ransac_threshold * c.ransac_threshold);
+    int niters = std::max(c.ransac_max_iters, 1), max_good = 0, iter;
+    CvRng rng((uint64_t)-1, c.ocv.rng_mul);
+    std::vector<uint8_t> cur(count);
+    double Hi[9];
+    for (iter = 0; iter < niters; ++iter) {
+        // getSubset(m1, m2, ms1, ms2, rng, 10000): 4 distinct indices (a duplicate is redrawn), the whole subset
+        // redrawn while checkSubset rejects it, at most 10000 attempts
+        P2f f[4], t[4];
+        bool found = false;
+        for (int attempt = 0; attempt < 10000; ++attempt) {
+            int idx[4];
+            for (int i = 0; i < model_points; ++i) {
+                int idx_i;
+                for (idx_i = rng.uniform(0, count); std::find(idx, idx + i, idx_i) != idx + i; idx_i = rng.uniform(0, count)) { if (st) st->draws++; }
+                if (st) st->draws++;
+                idx[i] = idx_i;
+                f[i] = from[idx_i]; t[i] = to[idx_i];
+            }
+            if (st) st->attempts++;
+            if (homography_check_subset(f, t, model_points)) { found = true; break; }
+        }
+        if (!found) {
+            if (iter == 0) { std::fill(H, H + 9, 0.0); return false; }
+            break;
+        }
+        int rot = 0;
+        int nmodels = c.ocv.hdlt == 1 ? homography_4pt_direct(f, t, Hi) : homography_dlt(f, t, model_points, Hi, &rot);
+        if (st) st->rotations += rot;
+        if (nmodels <= 0) continue;
+        int good = homography_find_inliers(from, to, count, Hi, thr2, cur.data());
+        if (good > std::max(max_good, model_points - 1)) {
+            std::memcpy(mask, cur.data(), count);
+            std::memcpy(H, Hi, sizeof(Hi));
+            max_good = good;
+            niters = ransac_update_iters(c.ransac_confidence, (double)(count - good) / count, model_points, niters);
+        }
+    }
+    if (st) st->iters = iter;
+    result = max_good > 0;
+    if (!result) { std::fill(H, H + 9, 0.0); std::fill(mask, mask + count, (uint8_t)0); return false; }
+    if (c.refine_iters > 0) {                                           // `result && npoints > 4`: DLT over the inliers, then LM
+        std::vector<P2f> s, d;
+        for (int i = 0; i < count; ++i) if (mask[i]) { s.push_back(from[i]); d.push_back(to[i]); }
+        if (!s.empty()) {
+            homography_dlt(s.data(), d.data(), (int)s.size(), H);       // (return value ignored, as fundam.cpp does)
+            lm8_refine(s.data(), d.data(), (int)s.size(), H, c.refine_iters, c.ocv.lm);
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // [OCV A.10] warpAffine, nearest, WARP_INVERSE_MAP, BORDER_CONSTANT(0)
 // imgproc/src/imgwarp.cpp (mo/lib.rs:338-348).  M maps dst (slide) -> src (frame).
 // ---------------------------------------------------------------------------
@@ -1005,9 +1327,26 @@ static inline int sat_int(double v) {
 static inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
 struct WarpSampler {  // source coordinate of destination pixel (x, y)
-    double M[6];
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
     int variant = 0;      // ocv.warp: 0 = imgwarp.cpp's 10-bit fixed point, 1 = cvRound of the f64 coordinate
+    int persp = 0;        // verify_model 1: warpPerspective (M is 3x3), else warpAffine (M[0..5])
+    int bw0 = 64;         // warpPerspective walks the destination in blocks of bw0 columns (set_dst_size)
+    // WarpPerspectiveInvoker: BLOCK_SZ 32, bh0 = min(16, h), bw0 = min(1024 / bh0, w) — the block origin enters the
+    // floating-point association of the coordinates
+    void set_dst_size(int dw, int dh) { int bh0 = std::min(16, dh); bw0 = std::max(1, std::min(32 * 32 / std::max(bh0, 1), dw)); }
     inline void src_xy(int x, int y, int& sx, int& sy) const {
+        if (persp) {
+            // imgproc/src/imgwarp.cpp WarpPerspectiveInvoker, INTER_NEAREST (recalled): per destination row of a block
+            // X0 = M0 x_blk + M1 y + M2 ..., per pixel W = W0 + M6 x1; W = W ? 1/W : 0; fX = clamp((X0 + M0 x1) W)
+            const int xb = (x / bw0) * bw0, x1 = x - xb;
+            const double X0 = M[0] * xb + M[1] * y + M[2], Y0 = M[3] * xb + M[4] * y + M[5], W0 = M[6] * xb + M[7] * y + M[8];
+            double W = W0 + M[6] * x1;
+            W = W ? 1. / W : 0;
+            const double fX = std::max((double)INT32_MIN, std::min((double)INT32_MAX, (X0 + M[0] * x1) * W));
+            const double fY = std::max((double)INT32_MIN, std::min((double)INT32_MAX, (Y0 + M[3] * x1) * W));
+            sx = sat_short(sat_int(fX)); sy = sat_short(sat_int(fY));
+            return;
+        }
         if (variant == 1) {
             sx = sat_short(sat_int(M[0] * x + M[1] * y + M[2])); sy = sat_short(sat_int(M[3] * x + M[4] * y + M[5]));
             return;
@@ -1026,7 +1365,7 @@ struct WarpSampler {  // source coordinate of destination pixel (x, y)
 static void warp_affine_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride, const double M[6],
                                 uint8_t* dst, int dw, int dh, int variant = 0) {
     WarpSampler ws;
-    std::memcpy(ws.M, M, sizeof(ws.M));
+    std::memcpy(ws.M, M, 6 * sizeof(double));
     ws.variant = variant;
     for (int y = 0; y < dh; ++y) {
         uint8_t* d = dst + (size_t)y * dw * 3;
@@ -1036,6 +1375,27 @@ static void warp_affine_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride,
             if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) {
                 const uint8_t* s = src + (size_t)sy * sstride + 3 * sx;
                 d[3 * x] = s[0]; d[3 * x + 1] = s[1]; d[3 * x + 2] = s[2];
+            } else {
+                d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = 0;
+            }
+        }
+    }
+}
+
+// warpPerspective(src, H, dsize, WARP_INVERSE_MAP [nearest], BORDER_CONSTANT 0): H maps dst -> src
+static void warp_perspective_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride, const double H[9],
+                                     uint8_t* dst, int dw, int dh) {
+    WarpSampler ws;
+    std::memcpy(ws.M, H, 9 * sizeof(double));
+    ws.persp = 1; ws.set_dst_size(dw, dh);
+    for (int y = 0; y < dh; ++y) {
+        uint8_t* d = dst + (size_t)y * dw * 3;
+        for (int x = 0; x < dw; ++x) {
+            int sx, sy;
+            ws.src_xy(x, y, sx, sy);
+            if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) {
+                const uint8_t* sp = src + (size_t)sy * sstride + 3 * sx;
+                d[3 * x] = sp[0]; d[3 * x + 1] = sp[1]; d[3 * x + 2] = sp[2];
             } else {
                 d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = 0;
             }
@@ -1249,7 +1609,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
                      [&](int a, int b) { return votes[a].size() > votes[b].size(); });
     if ((int)cand.size() > c.max_candidate_pages) cand.resize(c.max_candidate_pages);
 
-    struct Rated { int page; int nvotes; double rating; double M[6]; bool found; float sim; bool survived; };
+    struct Rated { int page; int nvotes; double rating; double M[9]; bool found; float sim; bool survived; };
     std::vector<Rated> rated;
     for (int p : cand) {                                       // mo/lib.rs:296-313
         const std::vector<Vote>& v = votes[p];
@@ -1261,7 +1621,12 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
         }
         Rated r; r.page = p; r.nvotes = (int)v.size(); r.sim = 0; r.survived = false;
         std::vector<uint8_t> mask(v.size());
-        r.found = estimate_affine_partial(from.data(), to.data(), (int)v.size(), c, r.M, mask.data(), nullptr);
+        std::fill(r.M, r.M + 9, 0.0);
+        if (c.verify_model == 1) r.found = find_homography(from.data(), to.data(), (int)v.size(), c, r.M, mask.data());
+        else {
+            r.found = estimate_affine_partial(from.data(), to.data(), (int)v.size(), c, r.M, mask.data(), nullptr);
+            if (r.found) r.M[8] = 1.0;                               // the 2x3 as a 3x3 (trace only)
+        }
         int inl = 0; for (uint8_t m : mask) inl += m;
         r.rating = (double)inl;
         rated.push_back(r);
@@ -1277,6 +1642,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
         const Page& pg = db.pages[r.page];
         std::vector<uint8_t> proj_small((size_t)pg.sw * pg.sh * 3);
         WarpSampler ws; std::memcpy(ws.M, r.M, sizeof(ws.M)); ws.variant = c.ocv.warp;
+        if (c.verify_model == 1) { ws.persp = 1; ws.set_dst_size(pg.w, pg.h); }
         // warp to the slide's size, then to_small_image of that (fused; identical arithmetic)
         int sw, sh; small_size(pg.w, pg.h, c.small_area, sw, sh);
         bool ok = resize_area_generic(pg.w, pg.h, sw, sh, proj_small.data(), [&](int x, int y, uint8_t* p) {
@@ -1328,6 +1694,7 @@ void so_config_default(slideo_config* c) {
     c->small_area = 300 * 400;                                     // mo/image_utils.rs:11
     c->changed_similarity = 0.98f;                                 // mo/video_capture.rs:98
     c->ratio_test = 0.0f;                                          // extension, off
+    c->verify_model = 0;                                           // the reference's estimateAffinePartial2D
     std::memset(&c->ocv, 0, sizeof(c->ocv));                       // every OpenCV-variant switch at its default (0)
     c->ocv.rng_mul = 4164903690u;                                  // CV_RNG_COEFF
 }
@@ -1471,6 +1838,30 @@ int so_estimate_affine_partial(const float* from_xy, const float* to_xy, int n, 
     bool f = estimate_affine_partial((const P2f*)from_xy, (const P2f*)to_xy, n, *c, M6, mask, &it);
     if (iters_run) *iters_run = it;
     return f ? 1 : 0;
+}
+
+// verify_model 1 primitives (tests/test_oracle_homography.py)
+int so_find_homography(const float* from_xy, const float* to_xy, int n, const slideo_config* c, double* H9, uint8_t* mask,
+                       int32_t* stats4 /* iterations, subset attempts, Jacobi rotations, RNG draws; may be null */) {
+    HomographyStats st;
+    bool f = find_homography((const P2f*)from_xy, (const P2f*)to_xy, n, *c, H9, mask, &st);
+    if (stats4) { stats4[0] = st.iters; stats4[1] = st.attempts; stats4[2] = st.rotations; stats4[3] = st.draws; }
+    return f ? 1 : 0;
+}
+int so_homography_dlt(const float* from_xy, const float* to_xy, int n, double* H9, int variant) {
+    if (variant == 1 && n == 4) return homography_4pt_direct((const P2f*)from_xy, (const P2f*)to_xy, H9);
+    return homography_dlt((const P2f*)from_xy, (const P2f*)to_xy, n, H9);
+}
+int so_homography_check_subset(const float* from_xy, const float* to_xy, int n) {
+    return homography_check_subset((const P2f*)from_xy, (const P2f*)to_xy, n) ? 1 : 0;
+}
+int so_jacobi_eig(const double* A, int n, double* W, double* V) {
+    if (n < 1 || n > 16) return -1;
+    std::vector<double> a(A, A + n * n);
+    return jacobi_eig_n(a.data(), n, W, V);
+}
+void so_warp_perspective_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride, const double* H9, uint8_t* dst, int dw, int dh) {
+    warp_perspective_nn_bgr8(src, sw, sh, sstride, H9, dst, dw, dh);
 }
 
 void so_warp_affine_nn_bgr8(const uint8_t* src, int sw, int sh, int sstride, const double* M6,

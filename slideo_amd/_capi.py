@@ -18,7 +18,8 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "NO_DEVICE", 3: "HIP", 4: "STATE", 5: "UNSUPPO
 class OcvVariants(C.Structure):
     """slideo_ocv_variants (include/slideo_amd.h): which restatement of each OpenCV primitive runs."""
     _fields_ = [("gray", C.c_int32), ("blur", C.c_int32), ("resize", C.c_int32), ("atan", C.c_int32),
-                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32)]
+                ("warp", C.c_int32), ("area", C.c_int32), ("lm", C.c_int32), ("rng_mul", C.c_uint32),
+                ("hdlt", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -31,6 +32,7 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
+        ("verify_model", C.c_int32),
         ("ocv", OcvVariants),
     ]
 
@@ -41,7 +43,7 @@ VERDICT_DTYPE = np.dtype([("page_idx", "<i4"), ("similarity", "<f4"), ("inliers"
                           ("n_keypoints", "<i4")])
 CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers", "<i4"),
                             ("survived", "<i4"), ("similarity", "<f4"), ("_pad", "<i4"),
-                            ("transform", "<f8", (6,))])
+                            ("transform", "<f8", (9,))])
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p)
 

@@ -1,0 +1,672 @@
+// homography.hip.h — verify_model 1: the geometric check as an 8-DOF homography.
+//
+// The reference verifies with estimateAffinePartial2D (crates/matching-opencv/src/image_utils.rs:45-60; verify.hip.h
+// ransac_kernel).  BASELINE.json's north_star / configs[4] ask for "RANSAC homography verification", which has no counterpart
+// in the reference: this file restates what cv::findHomography(from, to, RANSAC, thr, mask,
+// maxIters, confidence) of OpenCV 4.5.2 computes (calib3d/src/fundam.cpp, ptsetreg.cpp, levmarq.cpp; core/src/lapack.cpp —
+// recalled, like the oracle's find_homography which is this kernel's parity target):
+//   ransac_h_kernel   RANSACPointSetRegistrator::run with 4-point samples: getSubset on the cv::RNG(-1) stream (duplicates
+//                     redrawn, the subset redrawn while HomographyEstimatorCallback::checkSubset rejects it, 10000 attempts),
+//                     runKernel = normalised DLT (9x9 L^T L in f64, cv::eigen = Jacobi sweep, smallest eigenvector), f32
+//                     re-projection error, sequential acceptance with the adaptive iteration count; then the DLT over all
+//                     inliers and LMSolver on the 8 parameters (mask not recomputed), every sum in the oracle's order.
+// One wave per (candidate page, frame), as in ransac_kernel: lane = RANSAC iteration.  What differs is the cost of a model:
+// a 9x9 symmetric eigenproblem per sample.  Each lane runs OpenCV's Jacobi sweep (pivot = largest off-diagonal element,
+// tracked per row / column; its own hypot) on its own slice of LDS — upper triangle 36 + eigenvectors 81 + diagonal 9
+// doubles, element e of lane L at e * 64 + L, so every access is conflict free whatever pivot a lane is at — in exactly the
+// oracle's operation order: the per-sample model, and with it every inlier count, is bit-identical to the CPU restatement.
+// The sample schedule is a pure function of the RNG stream and the points, so it is produced 64 attempts at a time (start
+// positions by the same prefix-sum fixed point as ransac_kernel, from an LDS window of the stream), valid subsets queue up,
+// and a Jacobi phase always runs on a full wave of samples.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "verify.hip.h"
+
+namespace slideo {
+
+constexpr int HJ = 64;                      // lanes = Jacobi slices per block
+constexpr int HJ_TRI = 36, HJ_V = 81, HJ_W = 9;
+constexpr int HJ_SLICE = HJ_TRI + HJ_V + HJ_W;       // doubles per lane
+constexpr int H_WIN = 1024;                 // RNG stream entries staged in LDS per sampling round
+constexpr int H_QUEUE = 128;                // valid subsets waiting for a Jacobi phase
+constexpr int H_MAX_ATTEMPTS = 10000;       // getSubset(..., maxAttempts) as RANSACPointSetRegistrator::run passes it
+
+__host__ __device__ constexpr size_t ransac_h_lds_bytes(int lds_pts) {
+    return (size_t)HJ_SLICE * HJ * 8 + (size_t)lds_pts * 16 + (size_t)lds_pts + (size_t)H_WIN * 4 + (size_t)H_QUEUE * 8 + 64;
+}
+
+__device__ __forceinline__ int tri9(int i, int j) { return ((i * (17 - i)) >> 1) + (j - i - 1); }   // i < j, upper triangle of 9x9
+__device__ __forceinline__ int tri9u(int a, int b) { return a < b ? tri9(a, b) : tri9(b, a); }
+
+// core/src/lapack.cpp hypot (OpenCV's own template)
+__device__ __forceinline__ double hypot_cv(double a, double b) {
+    a = fabs(a); b = fabs(b);
+    if (a > b) { b /= a; return a * sqrt(1 + b * b); }
+    if (b > 0) { a /= b; return b * sqrt(1 + a * a); }
+    return 0;
+}
+
+struct HNorm { double cmx, cmy, cMx, cMy, smx, smy, sMx, sMy; };
+
+// Adds one correspondence (from (X0, Y0) -> to (x0, y0), already normalised) to the upper triangle of L^T L, in the operation
+// order of fundam.cpp's loop (products with the structural zeros of Lx / Ly included: not foldable, and they keep the bits).
+__device__ __forceinline__ void ltl_add(double (&LtL)[45], double X, double Y, double x, double y) {
+    const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+    const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int k = j; k < 9; ++k) { LtL[e] += Lx[j] * Lx[k] + Ly[j] * Ly[k]; ++e; }
+}
+
+// JacobiImpl_<double> (core/src/lapack.cpp) on the lane's LDS slice, then the eigenvector of the smallest eigenvalue.
+// LtL: upper triangle incl. diagonal, row-major (45).  `active` lanes without a problem idle; the loop is wave-uniform.
+__device__ __noinline__ void jacobi9_smallest(double* __restrict__ A, double* __restrict__ V, double* __restrict__ W,
+                                              const double (&LtL)[45], bool active, double (&h)[9]) {
+    // initial state: V = I, W = diagonal, A = strict upper triangle; indR / indC as packed nibbles
+    uint64_t indR = 0, indC = 0;
+    if (active) {
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int k = j; k < 9; ++k) {
+                if (k == j) W[j * HJ] = LtL[e]; else A[tri9(j, k) * HJ] = LtL[e];
+                ++e;
+            }
+#pragma unroll
+        for (int i = 0; i < 81; ++i) V[i * HJ] = (i % 10 == 0) ? 1.0 : 0.0;
+        auto at = [&](int j, int k) -> double {           // static indices: j < k
+            return LtL[j * 9 - (j * (j - 1)) / 2 + (k - j)];
+        };
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k < 8) {
+                int m = k + 1; double mv = fabs(at(k, k + 1));
+#pragma unroll
+                for (int i = k + 2; i < 9; ++i) { const double v = fabs(at(k, i)); if (mv < v) { mv = v; m = i; } }
+                indR |= (uint64_t)m << (4 * k);
+            }
+            if (k > 0) {
+                int m = 0; double mv = fabs(at(0, k));
+#pragma unroll
+                for (int i = 1; i < k; ++i) { const double v = fabs(at(i, k)); if (mv < v) { mv = v; m = i; } }
+                indC |= (uint64_t)m << (4 * k);
+            }
+        }
+    }
+    bool run = active;
+    int iters = 0;
+    while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+        if (run) {
+            // pivot: the largest of the row maxima, then of the column maxima (strict >, first wins)
+            double rv[8]; int rc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { rc[i] = (int)((indR >> (4 * i)) & 15); rv[i] = A[tri9(i, rc[i]) * HJ]; }
+            double cv[8]; int cr[8];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) { cr[i - 1] = (int)((indC >> (4 * i)) & 15); cv[i - 1] = A[tri9(cr[i - 1], i) * HJ]; }
+            int k = 0, l = rc[0]; double p = rv[0], mv = fabs(rv[0]);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) { const double v = fabs(rv[i]); if (mv < v) { mv = v; k = i; l = rc[i]; p = rv[i]; } }
+#pragma unroll
+            for (int i = 1; i < 9; ++i) { const double v = fabs(cv[i - 1]); if (mv < v) { mv = v; k = cr[i - 1]; l = i; p = cv[i - 1]; } }
+            if (fabs(p) <= DBL_EPSILON) run = false;
+            else {
+                const double wk = W[k * HJ], wl = W[l * HJ];
+                const double y = (wl - wk) * 0.5;
+                double t = fabs(y) + hypot_cv(p, y);
+                double s = hypot_cv(p, t);
+                const double c = t / s;
+                s = p / s; t = (p / t) * p;
+                if (y < 0) { s = -s; t = -t; }
+                A[tri9(k, l) * HJ] = 0;
+                W[k * HJ] = wk - t; W[l * HJ] = wl + t;
+                // rows and columns k and l
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i != k && i != l) {
+                        const int ik = tri9u(i, k) * HJ, il = tri9u(i, l) * HJ;
+                        const double a0 = A[ik], b0 = A[il];
+                        A[ik] = a0 * c - b0 * s; A[il] = a0 * s + b0 * c;
+                    }
+                // eigenvectors
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int vk = (k * 9 + i) * HJ, vl = (l * 9 + i) * HJ;
+                    const double a0 = V[vk], b0 = V[vl];
+                    V[vk] = a0 * c - b0 * s; V[vl] = a0 * s + b0 * c;
+                }
+                // refresh the tracked maxima of rows / columns k and l only (as OpenCV does)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int idx = j == 0 ? k : l;
+                    int mr = idx + 1, mc = 0; double mvr = -1.0, mvc = -1.0;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i)
+                        if (i != idx) {
+                            const double v = fabs(A[tri9u(i, idx) * HJ]);
+                            if (i > idx) { if (mvr < v) { mvr = v; mr = i; } }
+                            else { if (mvc < v) { mvc = v; mc = i; } }
+                        }
+                    if (idx < 8) indR = (indR & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mr << (4 * idx));
+                    if (idx > 0) indC = (indC & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mc << (4 * idx));
+                }
+                if (++iters >= 9 * 9 * 30) run = false;
+            }
+        }
+    }
+    // descending selection sort of the eigenvalues, rows of V following: only the row that ends last is needed
+#pragma unroll
+    for (int j = 0; j < 9; ++j) h[j] = 0;
+    if (active) {
+        double w[9]; int id[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { w[i] = W[i * HJ]; id[i] = i; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int m = k, im = id[k]; double wm = w[k];
+#pragma unroll
+            for (int i = k + 1; i < 9; ++i) if (wm < w[i]) { m = i; wm = w[i]; im = id[i]; }
+#pragma unroll
+            for (int i = k + 1; i < 9; ++i) if (i == m) { w[i] = w[k]; id[i] = id[k]; }
+            w[k] = wm; id[k] = im;
+        }
+        const int row = id[8];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) h[j] = V[(row * 9 + j) * HJ];
+    }
+}
+
+// H = (invHnorm * H0 * Hnorm2) / its (2,2) entry, fundam.cpp's order of products
+__device__ __forceinline__ void h_denormalise(const double (&h)[9], const HNorm& n, double (&H)[9]) {
+    const double ix = 1. / n.smx, iy = 1. / n.smy;
+    double T[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { T[j] = ix * h[j] + n.cmx * h[6 + j]; T[3 + j] = iy * h[3 + j] + n.cmy * h[6 + j]; T[6 + j] = h[6 + j]; }
+    const double n2 = -n.cMx * n.sMx, n5 = -n.cMy * n.sMy;
+    double R[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { R[3 * r] = T[3 * r] * n.sMx; R[3 * r + 1] = T[3 * r + 1] * n.sMy; R[3 * r + 2] = T[3 * r] * n2 + T[3 * r + 1] * n5 + T[3 * r + 2]; }
+    const double sc = 1. / R[8];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) H[j] = R[j] * sc;
+}
+
+// HomographyEstimatorCallback::runKernel on 4 pairs p[i] = (from.x, from.y, to.x, to.y); returns 1 model or 0
+__device__ __forceinline__ int dlt4(const float4 (&p)[4], double* A, double* V, double* W, bool active, double (&H)[9]) {
+    HNorm n{};
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cmx += p[i].z; cmy += p[i].w; cMx += p[i].x; cMy += p[i].y; }
+    cmx /= 4; cmy /= 4; cMx /= 4; cMy /= 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        smx += fabs(p[i].z - cmx); smy += fabs(p[i].w - cmy);
+        sMx += fabs(p[i].x - cMx); sMy += fabs(p[i].y - cMy);
+    }
+    const bool ok = active && !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON);
+    smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
+    n.cmx = cmx; n.cmy = cmy; n.cMx = cMx; n.cMy = cMy; n.smx = smx; n.smy = smy; n.sMx = sMx; n.sMy = sMy;
+    double LtL[45];
+#pragma unroll
+    for (int e = 0; e < 45; ++e) LtL[e] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        ltl_add(LtL, (p[i].x - cMx) * sMx, (p[i].y - cMy) * sMy, (p[i].z - cmx) * smx, (p[i].w - cmy) * smy);
+    double h[9];
+    jacobi9_smallest(A, V, W, LtL, ok, h);
+    if (ok) h_denormalise(h, n, H);
+    return ok ? 1 : 0;
+}
+
+// precomp.hpp haveCollinearPoints on 4 points (only the last point is tested against the pairs before it)
+__device__ __forceinline__ bool collinear4(float x0, float y0, float x1, float y1, float x2, float y2, float x3, float y3) {
+    const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double dx1 = (double)(px[j] - x3), dy1 = (double)(py[j] - y3);
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = (double)(px[k] - x3), dy2 = (double)(py[k] - y3);
+            bad = bad || (fabs(dx2 * dy1 - dy2 * dx1) <= (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)));
+        }
+    }
+    return bad;
+}
+__device__ __forceinline__ double det3_rows(float ax, float ay, float bx, float by, float cx, float cy) {
+    const double a00 = ax, a01 = ay, a02 = 1., a10 = bx, a11 = by, a12 = 1., a20 = cx, a21 = cy, a22 = 1.;
+    return a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+}
+// HomographyEstimatorCallback::checkSubset, count == 4
+__device__ __forceinline__ bool check_subset4(const float4 (&p)[4]) {
+    if (collinear4(p[0].x, p[0].y, p[1].x, p[1].y, p[2].x, p[2].y, p[3].x, p[3].y)) return false;
+    if (collinear4(p[0].z, p[0].w, p[1].z, p[1].w, p[2].z, p[2].w, p[3].z, p[3].w)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = p[tt[i][0]], b = p[tt[i][1]], c = p[tt[i][2]];
+        negative += (det3_rows(a.x, a.y, b.x, b.y, c.x, c.y) * det3_rows(a.z, a.w, b.z, b.w, c.z, c.w) < 0) ? 1 : 0;
+    }
+    return negative == 0 || negative == 4;
+}
+
+__device__ __forceinline__ float h_error(const float (&Hf)[8], float4 p) {
+    const float ww = 1.f / (Hf[6] * p.x + Hf[7] * p.y + 1.f);
+    const float dx = (Hf[0] * p.x + Hf[1] * p.y + Hf[2]) * ww - p.z;
+    const float dy = (Hf[3] * p.x + Hf[4] * p.y + Hf[5]) * ww - p.w;
+    return dx * dx + dy * dy;
+}
+
+__device__ __forceinline__ int ransac_update_iters4(double p, double ep, int max_iters) {
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, 4.0);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__device__ __forceinline__ double sel8(const double (&a)[8], int i) {
+    double r = a[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r = i == j ? a[j] : r;
+    return r;
+}
+__device__ __forceinline__ double sel9(const double (&a)[9], int i) {
+    double r = a[0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) r = i == j ? a[j] : r;
+    return r;
+}
+
+// HomographyRefineCallback::compute over the inliers: |r|^2, max |r|, and (want_j) the upper triangle of J^T J (36) and
+// J^T r (8).  The sums run over the inliers IN POINT ORDER, as the CPU restatement's loops do — floating-point sums in any
+// other order would make the refined matrix differ by an amount that the conditioning of the inlier set amplifies (a
+// nearly degenerate set: 1e-4 relative).  Parallelism is across the 44 accumulators instead of across the points: lane e
+// owns entry e (0..35: J^T J, 36..43: J^T r), every lane evaluates the (wave-uniform) residual and Jacobian rows of the
+// point and picks its two factors; the totals are exchanged at the end.  Every lane returns the same values.
+__device__ __noinline__ double lm8_eval(const float4* pts, const uint8_t* mask, int n, int lane, const double (&h)[8], bool want_j,
+                                        double (&AU)[36], double (&v)[8], double* rinf) {
+    double S = 0, ri = 0, acc = 0;
+    int ra = 0, rb = 0;                                   // this lane's entry: (ra, rb) of J^T J, or ra of J^T r
+    if (lane < 36) { int e = lane; while (e >= 8 - ra) { e -= 8 - ra; ++ra; } rb = ra + e; }
+    else ra = rb = min(lane - 36, 7);
+    const bool is_v = lane >= 36;
+    for (int i = 0; i < n; ++i) {
+        if (!mask[i]) continue;
+        const float4 p = pts[i];
+        const double Mx = p.x, My = p.y;
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        const double ex = xi - (double)p.z, ey = yi - (double)p.w;
+        S += ex * ex; S += ey * ey;
+        ri = fmax(ri, fmax(fabs(ex), fabs(ey)));
+        if (want_j) {
+            const double J0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            const double J1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            const double ja = sel8(J0, ra), ka = sel8(J1, ra);
+            const double fb = is_v ? ex : sel8(J0, rb), gb = is_v ? ey : sel8(J1, rb);
+            acc += ja * fb + ka * gb;
+        }
+    }
+    if (want_j) {
+#pragma unroll
+        for (int e = 0; e < 36; ++e) AU[e] = __shfl(acc, e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __shfl(acc, 36 + e);
+    }
+    if (rinf) *rinf = ri;
+    return S;
+}
+
+// 8x8 Gaussian elimination with partial pivoting (ocv.lm 0) on the lane's LDS slice (every lane solves the same system:
+// no broadcast, no divergence); sc: >= 72 doubles at stride HJ.  AU: upper triangle of the symmetric matrix, dl: added to
+// the diagonal (lambda * D).
+__device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], const double (&dl)[8], const double (&b)[8], double (&x)[8]) {
+    {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = i; j < 8; ++j) {
+                const double a = AU[e] + (i == j ? dl[i] : 0.0);
+                sc[(i * 9 + j) * HJ] = a;
+                if (j != i) sc[(j * 9 + i) * HJ] = AU[e];
+                ++e;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sc[(i * 9 + 8) * HJ] = b[i];
+    }
+    bool ok = true;
+    for (int c = 0; c < 8 && ok; ++c) {
+        int p = c;
+        double best = fabs(sc[(c * 9 + c) * HJ]);
+        for (int r = c + 1; r < 8; ++r) { const double v = fabs(sc[(r * 9 + c) * HJ]); if (v > best) { best = v; p = r; } }
+        if (sc[(p * 9 + c) * HJ] == 0.0) { ok = false; break; }
+        if (p != c)
+            for (int j = 0; j < 9; ++j) { const double t = sc[(p * 9 + j) * HJ]; sc[(p * 9 + j) * HJ] = sc[(c * 9 + j) * HJ]; sc[(c * 9 + j) * HJ] = t; }
+        const double piv = sc[(c * 9 + c) * HJ];
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = sc[(r * 9 + c) * HJ] / piv;
+            for (int j = c; j < 9; ++j) sc[(r * 9 + j) * HJ] -= f * sc[(c * 9 + j) * HJ];
+        }
+    }
+    if (!ok) return false;
+    double xs[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double s = sc[(i * 9 + 8) * HJ];
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) s -= sc[(i * 9 + j) * HJ] * xs[j];
+        xs[i] = s / sc[(i * 9 + i) * HJ];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xs[i];
+    return true;
+}
+
+// Two instances share the grid, as ransac_kernel's: <RANSAC_SMALL_PTS, 0> and <RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1>.
+// Dynamic LDS: ransac_h_lds_bytes(LDS_PTS).
+template <int LDS_PTS, int MIN_COUNT>
+__global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+                                                      const slideo_keypoint* __restrict__ frame_kp,
+                                                      const float2* __restrict__ page_xy,
+                                                      const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
+                                                      FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
+                                                      uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
+    double* jbuf = reinterpret_cast<double*>(hsm);
+    float4* lpts = reinterpret_cast<float4*>(hsm + (size_t)HJ_SLICE * HJ * 8);
+    uint8_t* lmask = reinterpret_cast<uint8_t*>(lpts + LDS_PTS);
+    uint32_t* win = reinterpret_cast<uint32_t*>(hsm + (size_t)HJ_SLICE * HJ * 8 + (size_t)LDS_PTS * 16 + (((size_t)LDS_PTS + 15) & ~(size_t)15));
+    uint2* queue = reinterpret_cast<uint2*>(win + H_WIN);
+
+    const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    FrameCands& fc = fcs[f];
+    if (r >= fc.ncand) return;
+    const int count = fc.count[r];
+    if (count < MIN_COUNT || (MIN_COUNT == 0 && count > LDS_PTS)) return;      // the other instance's candidate
+    const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
+    const uint2* vt = votes + vbase;
+    float4* pts = count <= LDS_PTS ? lpts : gpts + vbase;
+    uint8_t* mask = count <= LDS_PTS ? lmask : gmask + vbase;
+    double* A = jbuf + lane; double* V = A + HJ_TRI * HJ; double* W = V + HJ_V * HJ;
+    const uint32_t qbase_f = qofs[f];
+    for (int i0 = lane; i0 < count; i0 += 256) {
+        uint2 v[4]; float2 s[4]; float2 kq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = vt[min(i0 + 64 * u, count - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u] = page_xy[v[u].y];
+            const slideo_keypoint* kp = frame_kp + qbase_f + v[u].x;
+            kq[u] = *reinterpret_cast<const float2*>(&kp->x);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 64 * u < count) pts[i0 + 64 * u] = make_float4(s[u].x, s[u].y, kq[u].x, kq[u].y);   // from = slide pt, to = frame pt
+    }
+    __syncthreads();
+    double bestH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int found = 0, inl = 0;
+    const float thr2 = (float)(vp.thr * vp.thr);
+    if (count == 4) {
+        // `npoints == 4`: the kernel alone, every pair an inlier, no refinement
+        const float4 p4[4] = {pts[0], pts[1], pts[2], pts[3]};
+        found = dlt4(p4, A, V, W, true, bestH);
+        inl = found ? 4 : 0;
+        if (!found) { for (int j = 0; j < 9; ++j) bestH[j] = 0; }
+    } else if (count > 4) {
+        int niters = max(vp.max_iters, 1), max_good = 0, base = 0;
+        uint32_t pos = 0;                  // stream position of the next attempt
+        int nq = 0;                        // queued valid subsets
+        int fail_run = 0;                  // consecutive rejected attempts since the last valid subset
+        bool sched_end = false;            // getSubset gave up (10000 attempts): no further iteration exists
+        bool overflow = false;
+        while (base < niters) {
+            // ---- sampling rounds until a full wave of subsets is queued (or as many as the loop can still use) ----
+            const int need = min(64, niters - base);
+            while (nq < need && !sched_end) {
+                if (pos + H_WIN + 64 > vp.rng_len) { overflow = true; break; }
+                __syncthreads();
+                for (int i = lane; i < H_WIN; i += 64) win[i] = rng_tab[pos + i] % (uint32_t)count;
+                __syncthreads();
+                auto draw = [&](uint32_t p) -> uint32_t {
+                    return p - pos < (uint32_t)H_WIN ? win[p - pos] : rng_tab[min(p, vp.rng_len - 1)] % (uint32_t)count;
+                };
+                uint32_t shift = 0, total = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                for (;;) {
+                    uint32_t p = pos + 4 * lane + shift;
+                    const uint32_t p0 = p;
+                    const uint32_t lim = vp.rng_len - 1;
+                    i0 = draw(p); ++p;
+                    for (;;) { i1 = draw(p); ++p; if (i1 != i0 || p >= lim) break; }
+                    for (;;) { i2 = draw(p); ++p; if ((i2 != i0 && i2 != i1) || p >= lim) break; }
+                    for (;;) { i3 = draw(p); ++p; if ((i3 != i0 && i3 != i1 && i3 != i2) || p >= lim) break; }
+                    const uint32_t e = p - p0 - 4;
+                    uint32_t inc = e;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+                    const uint32_t nshift = inc - e;
+                    const bool changed = nshift != shift;
+                    shift = nshift;
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0ull) { total = __shfl(inc, 63); break; }
+                }
+                pos += 256 + total;
+                if (pos >= vp.rng_len) { overflow = true; break; }
+                const float4 p4[4] = {pts[i0], pts[i1], pts[i2], pts[i3]};
+                const bool valid = check_subset4(p4);
+                const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
+                if (vb == 0ull) {
+                    fail_run += 64;
+                    if (fail_run >= H_MAX_ATTEMPTS) sched_end = true;
+                    continue;
+                }
+                const int first = __builtin_ctzll(vb);
+                if (fail_run + first >= H_MAX_ATTEMPTS) { sched_end = true; continue; }
+                const int rank = __builtin_popcountll(vb & ((1ull << lane) - 1ull));
+                if (valid && nq + rank < H_QUEUE) queue[nq + rank] = make_uint2(i0 | (i1 << 16), i2 | (i3 << 16));
+                nq = min(nq + __builtin_popcountll(vb), H_QUEUE);     // (nq < 64 on entry and <= 64 arrive: never clipped)
+                fail_run = __builtin_clzll(vb);                       // rejected attempts after the round's last valid one
+            }
+            if (overflow) break;
+            __syncthreads();
+            const int nrun = min(min(nq, 64), niters - base);          // iterations this phase scores
+            if (nrun <= 0) break;                                      // schedule exhausted
+            // ---- model + inlier count, one iteration per lane ----
+            const bool mine = lane < nrun;
+            const uint2 qs = queue[min(lane, H_QUEUE - 1)];
+            float4 p4[4];
+            p4[0] = pts[mine ? (qs.x & 0xFFFFu) : 0]; p4[1] = pts[mine ? (qs.x >> 16) : 0];
+            p4[2] = pts[mine ? (qs.y & 0xFFFFu) : 0]; p4[3] = pts[mine ? (qs.y >> 16) : 0];
+            double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const int nmodels = dlt4(p4, A, V, W, mine, Hm);
+            int good = -1;
+            if (mine && nmodels > 0) {
+                float Hf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Hf[j] = (float)Hm[j];
+                good = 0;
+                for (int i = 0; i < count; ++i) good += (h_error(Hf, pts[i]) <= thr2) ? 1 : 0;
+            }
+            // ---- sequential acceptance over the phase's iterations ----
+            int used = nrun;
+            if (__builtin_amdgcn_ballot_w64(mine && good > max(max_good, 3)) != 0ull) {
+                for (int i = 0; i < nrun; ++i) {
+                    if (base + i >= niters) { used = i; break; }
+                    const int g = __shfl(good, i);
+                    if (g > max(max_good, 3)) {
+                        max_good = g;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) bestH[j] = __shfl(Hm[j], i);
+                        niters = ransac_update_iters4(vp.conf, (double)(count - g) / count, niters);
+                    }
+                }
+            }
+            base += used;
+            // drop the consumed subsets
+            __syncthreads();
+            const uint2 a = queue[min(lane + nrun, H_QUEUE - 1)];
+            __syncthreads();
+            if (lane + nrun < nq) queue[lane] = a;
+            nq -= nrun;
+            if (sched_end && nq == 0) break;
+        }
+        if (overflow) { if (lane == 0) atomicOr(flags, 4u); }
+        found = max_good > 0;
+        if (found) {
+            float Hf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Hf[j] = (float)bestH[j];
+            int c = 0;
+            for (int i = lane; i < count; i += 64) {
+                const uint8_t m = h_error(Hf, pts[i]) <= thr2;
+                mask[i] = m; c += m;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+            inl = c;
+            __syncthreads();
+            if (vp.refine_iters > 0 && inl > 0) {
+                // fundam.cpp: runKernel over the inliers, then LMSolver on H[0..7].  All sums in point order (see lm8_eval):
+                // lanes 0..3 own the four centroid / deviation sums, lanes 0..44 the 45 entries of L^T L.
+                HNorm n{};
+                const double cnt = (double)inl;
+                {
+                    double acc = 0;
+                    for (int i = 0; i < count; ++i) {
+                        if (!mask[i]) continue;
+                        const float4 p = pts[i];
+                        acc += (double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y)));
+                    }
+                    n.cmx = __shfl(acc, 0) / cnt; n.cmy = __shfl(acc, 1) / cnt; n.cMx = __shfl(acc, 2) / cnt; n.cMy = __shfl(acc, 3) / cnt;
+                    const double cen = lane == 0 ? n.cmx : (lane == 1 ? n.cmy : (lane == 2 ? n.cMx : n.cMy));
+                    acc = 0;
+                    for (int i = 0; i < count; ++i) {
+                        if (!mask[i]) continue;
+                        const float4 p = pts[i];
+                        acc += fabs((double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y))) - cen);
+                    }
+                    n.smx = __shfl(acc, 0); n.smy = __shfl(acc, 1); n.sMx = __shfl(acc, 2); n.sMy = __shfl(acc, 3);
+                }
+                const bool ok = !(fabs(n.smx) < DBL_EPSILON || fabs(n.smy) < DBL_EPSILON || fabs(n.sMx) < DBL_EPSILON || fabs(n.sMy) < DBL_EPSILON);
+                if (ok) {                                               // (runKernel returning 0 leaves H as RANSAC found it)
+                    n.smx = cnt / n.smx; n.smy = cnt / n.smy; n.sMx = cnt / n.sMx; n.sMy = cnt / n.sMy;
+                    int rj = 0, rk = 0;
+                    { int e = min(lane, 44); while (e >= 9 - rj) { e -= 9 - rj; ++rj; } rk = rj + e; }
+                    double acc = 0;
+                    for (int i = 0; i < count; ++i) {
+                        if (!mask[i]) continue;
+                        const float4 p = pts[i];
+                        const double x = (p.z - n.cmx) * n.smx, y = (p.w - n.cmy) * n.smy;
+                        const double X = (p.x - n.cMx) * n.sMx, Y = (p.y - n.cMy) * n.sMy;
+                        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+                        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+                        acc += sel9(Lx, rj) * sel9(Lx, rk) + sel9(Ly, rj) * sel9(Ly, rk);
+                    }
+                    double LtL[45];
+#pragma unroll
+                    for (int e = 0; e < 45; ++e) LtL[e] = __shfl(acc, e);
+                    double h[9];
+                    jacobi9_smallest(A, V, W, LtL, true, h);            // every lane the same problem
+                    h_denormalise(h, n, bestH);
+                }
+                // LMSolverImpl::run, 8 parameters
+                const double eps = (double)FLT_EPSILON;
+                double x[8], xd[8], AU[36], v[8], D[8], d[8], dl[8], rinf = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = bestH[i];
+                double S = lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
+                {
+                    int e = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { D[i] = AU[e]; e += 8 - i; }
+                }
+                const double Rlo = 0.25, Rhi = 0.75;
+                double lambda = 1, lc = 0.75;
+                int iter = 0;
+                for (;;) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dl[i] = lambda * D[i];
+                    if (!solve8_lds(A, AU, dl, v, d)) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) d[i] = 0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xd[i] = x[i] - d[i];
+                    double dummyA[36], dummyv[8];
+                    const double Sd = lm8_eval(pts, mask, count, lane, xd, false, dummyA, dummyv, nullptr);
+                    double dS = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        double t = 2 * v[i];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int a = i < j ? i : j, b = i < j ? j : i;
+                            t -= AU[a * 8 - (a * (a - 1)) / 2 + (b - a)] * d[j];
+                        }
+                        dS += d[i] * t;
+                    }
+                    const double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                    if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+                    else if (R < Rlo) {
+                        double t = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) t += d[i] * v[i];
+                        double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+                        nu = fmin(fmax(nu, 2.), 10.);
+                        if (lambda == 0) {
+                            double maxval = DBL_EPSILON;
+                            const double zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            for (int i = 0; i < 8; ++i) {
+                                double e8[8], col[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) e8[j] = j == i ? 1.0 : 0.0;
+                                if (solve8_lds(A, AU, zero8, e8, col)) {
+                                    double ci = 0;
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) ci = j == i ? col[j] : ci;
+                                    maxval = fmax(maxval, fabs(ci));
+                                }
+                            }
+                            lambda = lc = 1. / maxval;
+                            nu *= 0.5;
+                        }
+                        lambda *= nu;
+                    }
+                    if (Sd < S) {
+                        S = Sd;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] = xd[i];
+                        lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
+                    }
+                    iter++;
+                    double dinf = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dinf = fmax(dinf, fabs(d[i]));
+                    if (!(iter < vp.refine_iters && dinf >= eps && rinf >= eps)) break;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bestH[i] = x[i];
+            }
+        } else {
+            for (int j = 0; j < 9; ++j) bestH[j] = 0;
+        }
+    }
+    if (lane == 0) {
+        fc.found[r] = found; fc.inliers[r] = inl;
+        for (int j = 0; j < 9; ++j) fc.M[r][j] = bestH[j];
+    }
+}
+
+}  // namespace slideo

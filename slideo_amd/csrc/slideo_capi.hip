@@ -21,6 +21,7 @@
 #include "orb.hip.h"
 #include "slideo_amd.h"
 #include "verify.hip.h"
+#include "homography.hip.h"
 
 using namespace slideo;
 
@@ -160,6 +161,7 @@ VerifyParams make_vp(const slideo_config& c) {
     v.tol = c.vote_tolerance; v.min_similarity = c.min_similarity; v.ratio = c.ratio_test;
     v.thr = c.ransac_threshold; v.conf = c.ransac_confidence; v.min_rating = c.min_rating;
     v.min_rating_ratio = c.min_rating_ratio; v.max_iters = c.ransac_max_iters; v.refine_iters = c.refine_iters;
+    v.model = c.verify_model;
     return v;
 }
 
@@ -666,6 +668,16 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
         check_launch("vote_kernel");
+        if (c.verify_model == 1) {
+            ransac_h_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_SMALL_PTS), st>>>(
+                vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+            check_launch("ransac_h_kernel (small)");
+            ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1><<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_LDS_PTS), st>>>(
+                vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+            check_launch("ransac_h_kernel (large)");
+        } else {
         ransac_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
             vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
             m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
@@ -674,6 +686,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
             vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
             m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
         check_launch("ransac_kernel (large)");
+        }
         uint32_t* pair_count = S.d_pairs.as<uint32_t>();
         PairDesc* pair_list = reinterpret_cast<PairDesc*>(S.d_pairs.as<uint8_t>() + 64);
         HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));
@@ -681,10 +694,16 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         check_launch("rate_kernel");
         int max_tile_rows = 0;
         for (const AreaGeom& ag : m->area_geoms) max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));
-        reproject_kernel<<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
-                                                                                  m->d_area_idx.as<int32_t>(),
-                                                                                  m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
-                                                                                  stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
+        if (c.verify_model == 1)
+            reproject_kernel<true><<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
+                                                                                            m->d_area_idx.as<int32_t>(),
+                                                                                            m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
+                                                                                            stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
+        else
+            reproject_kernel<false><<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
+                                                                                             m->d_area_idx.as<int32_t>(),
+                                                                                             m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
+                                                                                             stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
         check_launch("reproject_kernel");
     }
     verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), S.d_fcs.as<FrameCands>(),
@@ -837,6 +856,7 @@ void slideo_config_default(slideo_config* c) {
     c->max_rated = 10; c->min_rating = 50.0; c->min_rating_ratio = 0.2;
     c->min_similarity = 0.5f; c->small_area = 300 * 400; c->changed_similarity = 0.98f;
     c->ratio_test = 0.0f;
+    c->verify_model = 0;                             // the reference's estimateAffinePartial2D
     std::memset(&c->ocv, 0, sizeof(c->ocv));         // every OpenCV-variant switch at its default
     c->ocv.rng_mul = 4164903690u;                    // CV_RNG_COEFF
 }
@@ -893,13 +913,18 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         HIP_CHECK(hipMemcpy(mm->d_ictab.p, ict.data(), ict.size() * 4, hipMemcpyHostToDevice));
     }
     {
-        int64_t len = std::max<int64_t>(RNG_TABLE_MIN, 4ll * std::max(cfg->ransac_max_iters, 1) + 1024);
+        // similarity: 2 draws per iteration + redraws; homography: 4 per attempt, several attempts per accepted subset
+        int64_t len = std::max<int64_t>(RNG_TABLE_MIN, (cfg->verify_model == 1 ? 64ll : 4ll) * std::max(cfg->ransac_max_iters, 1) + 2048);
         if (const char* e = getenv("SLIDEO_RNG_STREAM_LEN")) len = std::max<int64_t>(512, atoll(e));     // tests: force the growth path
         upload_rng_stream(mm.get(), (uint32_t)std::min<int64_t>(len, 1ll << 26));
     }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   describe_window(cfg->patch_size / 2).dwords * 16));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_SMALL_PTS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_LDS_PTS)));
     m = mm.release();
     *out = m;
     API_CATCH(nullptr)
@@ -1187,7 +1212,11 @@ int32_t slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_b
     for (int i = 0; i < fc.ncand; ++i) {
         slideo_candidate& c = out[i];
         c.page_idx = fc.page[i]; c.n_votes = fc.count[i]; c.inliers = fc.inliers[i]; c.survived = 0; c.similarity = 0.f;
-        for (int j = 0; j < 6; ++j) c.transform[j] = fc.M[i][j];
+        if (m->cfg.verify_model == 1) { for (int j = 0; j < 9; ++j) c.transform[j] = fc.M[i][j]; }
+        else {
+            for (int j = 0; j < 6; ++j) c.transform[j] = fc.M[i][j];
+            c.transform[6] = c.transform[7] = 0.0; c.transform[8] = fc.found[i] ? 1.0 : 0.0;
+        }
         for (int s = 0; s < fc.nsurv; ++s) if (fc.surv[s] == i) { c.survived = 1; c.similarity = fc.sim[s]; }
     }
     return SLIDEO_OK;

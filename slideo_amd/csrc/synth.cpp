@@ -15,6 +15,10 @@
  * U[0.85,1], rotation U[-1,1] deg, slide kept >= 90 % visible), bilinear
  * sampled, optional occluder (<= 10 % area), additive noise sigma ~ 2 and a
  * per-8x8-block offset that mimics codec quantisation.
+ * Perspective frames (slideo_synth_frames_persp, persp > 0; BASELINE configs[4] "RANSAC homography
+ * verify"): the slide is first seen through a projective map w = 1 + g u / pw + h v / ph in
+ * centred slide coordinates, g, h ~ U[-persp, persp] (a keystone of about persp / 2 across the
+ * slide), then the similarity above; the ground truth is the 3x3 slide -> frame homography.
  */
 #include <algorithm>
 #include <cmath>
@@ -148,15 +152,15 @@ static void render_page(const Layout& L, int page_nr, int W, int H, uint8_t* img
         if ((page_nr + 1) >> b & 1) fill(img, W, H, x + (11 - b) * (cw + 2), y, cw, ch, 30, 30, 30);
 }
 
-struct FrameTruth { int32_t page; double M[6]; };  // M: slide -> frame (2x3)
+struct FrameTruth { int32_t page; double M[9]; };  // M: slide -> frame (3x3; rows 0-1 = the 2x3 of a similarity frame)
 
 static void render_frame(uint64_t seed, int64_t frame_idx, const uint8_t* pages, int n_pages, int pw, int ph,
-                         int fw, int fh, uint8_t* out, FrameTruth* truth) {
+                         int fw, int fh, uint8_t* out, FrameTruth* truth, double persp = 0.0) {
     Rng rng(seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(frame_idx + 1)));
     bool none = n_pages == 0 || rng.unit() < 0.1;
     int page = none ? -1 : rng.range(0, n_pages - 1);
     truth->page = page;
-    std::fill(truth->M, truth->M + 6, 0.0);
+    std::fill(truth->M, truth->M + 9, 0.0);
     if (none) {   // dark noisy scene (speaker shot): smooth blobs + noise
         int cell = 64;
         int gw = fw / cell + 2, gh = fh / cell + 2;
@@ -183,15 +187,32 @@ static void render_frame(uint64_t seed, int64_t frame_idx, const uint8_t* pages,
         double cxp = pw * 0.5, cyp = ph * 0.5;
         double M0 = ca, M1 = -sa, M2 = tx0 - (ca * cxp - sa * cyp);
         double M3 = sa, M4 = ca, M5 = ty0 - (sa * cxp + ca * cyp);
-        truth->M[0] = M0; truth->M[1] = M1; truth->M[2] = M2; truth->M[3] = M3; truth->M[4] = M4; truth->M[5] = M5;
-        // inverse: frame -> slide
-        double det = M0 * M4 - M1 * M3;
-        double I0 = M4 / det, I1 = -M1 / det, I3 = -M3 / det, I4 = M0 / det;
-        double I2 = -(I0 * M2 + I1 * M5), I5 = -(I3 * M2 + I4 * M5);
+        // (persp == 0 keeps the similarity frames of earlier rounds bit for bit: no extra draw)
+        const double g = persp > 0 ? (rng.unit() * 2 - 1) * persp / pw : 0.0, hh = persp > 0 ? (rng.unit() * 2 - 1) * persp / ph : 0.0;
+        // H = [M0 M1 M2; M3 M4 M5; 0 0 1] * P^-1-free form: centred projective P = [1 0 -cx; 0 1 -cy; g h 1 - g cx - h cy],
+        // S = [ca -sa tx0; sa ca ty0; 0 0 1] on centred coordinates
+        double H[9] = {ca + tx0 * g, -sa + tx0 * hh, -ca * cxp + sa * cyp + tx0 * (1 - g * cxp - hh * cyp),
+                       sa + ty0 * g, ca + ty0 * hh, -sa * cxp - ca * cyp + ty0 * (1 - g * cxp - hh * cyp),
+                       g, hh, 1 - g * cxp - hh * cyp};
+        if (persp > 0) { for (int i = 0; i < 9; ++i) H[i] /= H[8]; }
+        else { H[0] = M0; H[1] = M1; H[2] = M2; H[3] = M3; H[4] = M4; H[5] = M5; H[6] = 0; H[7] = 0; H[8] = 1; }
+        std::memcpy(truth->M, H, sizeof(H));
+        // inverse: frame -> slide (adjugate; for a similarity frame the projective row is 0 0 1 and W == 1)
+        double I0, I1, I2, I3, I4, I5, I6 = 0, I7 = 0, I8 = 1;
+        if (persp > 0) {
+            I0 = H[4] * H[8] - H[5] * H[7]; I1 = H[2] * H[7] - H[1] * H[8]; I2 = H[1] * H[5] - H[2] * H[4];
+            I3 = H[5] * H[6] - H[3] * H[8]; I4 = H[0] * H[8] - H[2] * H[6]; I5 = H[2] * H[3] - H[0] * H[5];
+            I6 = H[3] * H[7] - H[4] * H[6]; I7 = H[1] * H[6] - H[0] * H[7]; I8 = H[0] * H[4] - H[1] * H[3];
+        } else {
+            double det = M0 * M4 - M1 * M3;
+            I0 = M4 / det; I1 = -M1 / det; I3 = -M3 / det; I4 = M0 / det;
+            I2 = -(I0 * M2 + I1 * M5); I5 = -(I3 * M2 + I4 * M5);
+        }
         uint8_t bg = (uint8_t)rng.range(15, 45);
         for (int y = 0; y < fh; ++y) {
             for (int x = 0; x < fw; ++x) {
                 double sx = I0 * x + I1 * y + I2, sy = I3 * x + I4 * y + I5;
+                if (persp > 0) { const double w = I6 * x + I7 * y + I8; sx /= w; sy /= w; }
                 uint8_t* o = out + ((size_t)y * fw + x) * 3;
                 int ix = (int)std::floor(sx), iy = (int)std::floor(sy);
                 if (ix < 0 || iy < 0 || ix >= pw - 1 || iy >= ph - 1) { o[0] = o[1] = o[2] = bg; continue; }
@@ -253,7 +274,25 @@ void slideo_synth_frames(uint64_t seed, int64_t first, int n, const uint8_t* pag
             FrameTruth tr;
             render_frame(seed, first + i, pages, n_pages, pw, ph, fw, fh, out + (size_t)i * fw * fh * 3, &tr);
             if (truth_page) truth_page[i] = tr.page;
-            if (truth_M) std::memcpy(truth_M + (size_t)i * 6, tr.M, sizeof(tr.M));
+            if (truth_M) std::memcpy(truth_M + (size_t)i * 6, tr.M, 6 * sizeof(double));
+        }
+    };
+    if (threads == 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+}
+
+// The same with a projective component (persp > 0, see the header comment); truth_H[n][9] (slide -> frame, 3x3).
+void slideo_synth_frames_persp(uint64_t seed, int64_t first, int n, const uint8_t* pages, int n_pages, int pw, int ph,
+                               int fw, int fh, double persp, uint8_t* out, int32_t* truth_page, double* truth_H, int threads) {
+    threads = std::max(1, std::min(threads, n));
+    auto work = [=](int t) {
+        for (int i = t; i < n; i += threads) {
+            FrameTruth tr;
+            render_frame(seed, first + i, pages, n_pages, pw, ph, fw, fh, out + (size_t)i * fw * fh * 3, &tr, persp);
+            if (truth_page) truth_page[i] = tr.page;
+            if (truth_H) std::memcpy(truth_H + (size_t)i * 9, tr.M, sizeof(tr.M));
         }
     };
     if (threads == 1) { work(0); return; }

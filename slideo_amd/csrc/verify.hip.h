@@ -37,7 +37,7 @@ struct FrameCands {            // one per frame of the batch, device resident
     int32_t ncand, nsurv;
     int32_t page[MAXC], count[MAXC], ofs[MAXC];
     int32_t inliers[MAXC], found[MAXC];
-    double M[MAXC][6];         // slide -> frame
+    double M[MAXC][9];         // slide -> frame: 2x3 (verify_model 0, entries 6-8 unused) or 3x3 homography (verify_model 1)
     int32_t surv[MAXR];        // candidate slot of each survivor
     float sim[MAXR];
     unsigned long long ssd[MAXR];
@@ -55,7 +55,7 @@ struct PageInfo {              // per page, device resident
 struct PairDesc {              // one (frame, survivor) unit of re-projection work, written by rate_kernel
     int32_t f, s, area_idx, _pad;
     int64_t small_ofs;
-    double M[6];
+    double M[9];
 };
 
 struct VerifyParams {
@@ -64,6 +64,7 @@ struct VerifyParams {
     double thr, conf, min_rating, min_rating_ratio;
     int32_t max_iters, refine_iters;
     uint32_t rng_len;                       // entries of the pre-drawn cv::RNG stream (grown on demand by the host)
+    int32_t model;                          // slideo_config.verify_model: 0 similarity (2x3), 1 homography (3x3)
 };
 
 // ---------------------------------------------------------------------------
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(64) void rate_kernel(VerifyParams vp, int nframes, 
         PairDesc d;
         d.f = f; d.s = rank; d.area_idx = pg.area_idx; d._pad = 0; d.small_ofs = pg.small_ofs;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) d.M[j] = fc.M[lane][j];
+        for (int j = 0; j < 9; ++j) d.M[j] = fc.M[lane][j];
         pair_list[base + rank] = d;
     }
 }
@@ -664,11 +665,32 @@ constexpr int RP_SPAN_X = 512, RP_SPAN_Y = 160;
 constexpr int RP_WIN_BYTES = 32 * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
 constexpr int RP_PRE = 6;                    // window groups (of 4 pixels) per thread that are fetched one tile ahead
 constexpr int RP_MAX_TILES = 64;             // tiles per strip with a precomputed descriptor (small images up to 2048 px wide)
+constexpr int RP_XY_MAX = 6144;              // PERSP: source pixels of a tile whose warped coordinates are tabled in LDS (141 x 37 for 2001 -> 461)
 struct RpTile { int sx_lo, sx_hi, tabled, windowed, all_in, wx0, wy0, wpitch, npx4, nrows; };
+
+// warpPerspective(nearest, WARP_INVERSE_MAP), imgproc/src/imgwarp.cpp WarpPerspectiveInvoker (recalled; the oracle's
+// WarpSampler::src_xy, persp form): the destination is walked in blocks of bw0 columns and the block origin enters the
+// floating-point association: X0 = M0 xb + M1 y + M2, W = W0 + M6 x1, W = W ? 1/W : 0, X = saturate(clamp((X0 + M0 x1) W)).
+__device__ __forceinline__ void persp_src(const double (&M)[9], int bw0, int x, int y, int& X, int& Y) {
+    const int xb = (x / bw0) * bw0, x1 = x - xb;
+    const double X0 = M[0] * xb + M[1] * y + M[2], Y0 = M[3] * xb + M[4] * y + M[5], W0 = M[6] * xb + M[7] * y + M[8];
+    double W = W0 + M[6] * x1;
+    W = W != 0.0 ? 1. / W : 0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * W));
+    int Xi = (int)rint(fX), Yi = (int)rint(fY);
+    X = Xi < -32768 ? -32768 : (Xi > 32767 ? 32767 : Xi);
+    Y = Yi < -32768 ? -32768 : (Yi > 32767 ? 32767 : Yi);
+}
 
 // grid (max tile rows, min(B, 65535)), block 256.  Block (ty, y) walks the pairs y, y + gridDim.y, ... of the compact
 // list built by rate_kernel and, for each, the whole row `ty` of 32x8 output tiles: the per-pair constants are
 // fetched once (one flat descriptor instead of a chain of dependent loads) and amortised over the strip.
+// PERSP (verify_model 1): the pair's transform is a 3x3 homography and the warp is warpPerspective.  The separable tables
+// (adelta / bdelta per column, X0 / Y0 per row) do not exist for a projective map; instead the warped coordinate of EVERY
+// source pixel of the tile's span is computed once (one f64 division each) into an LDS table of packed shorts, which the
+// taps index — a source pixel is a tap of up to four output pixels.  Window, prefetch and strip structure are shared.
+template <bool PERSP>
 __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
                                                         const int32_t* __restrict__ idx,
                                                         const uint8_t* __restrict__ page_small,
@@ -676,7 +698,9 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                                                         int fw, int fh, FrameCands* __restrict__ fcs,
                                                         const PairDesc* __restrict__ pair_list, const uint32_t* __restrict__ pair_count) {
     __shared__ unsigned long long red[4];
-    __shared__ int s_ad[RP_SPAN_X], s_bd[RP_SPAN_X], s_x0[RP_SPAN_Y], s_y0[RP_SPAN_Y];
+    __shared__ int s_tab[PERSP ? RP_XY_MAX : 2 * RP_SPAN_X + 2 * RP_SPAN_Y];
+    int* const s_ad = s_tab; int* const s_bd = s_tab + RP_SPAN_X; int* const s_x0 = s_tab + 2 * RP_SPAN_X; int* const s_y0 = s_tab + 2 * RP_SPAN_X + RP_SPAN_Y;
+    uint32_t* const s_xy = reinterpret_cast<uint32_t*>(s_tab);       // PERSP: (X & 0xFFFF) | Y << 16 per source pixel of the tile span
     __shared__ __attribute__((aligned(16))) uint8_t win[RP_WIN_BYTES + 16];   // + a zero pixel at RP_WIN_BYTES
     __shared__ RpTile s_tile[RP_MAX_TILES];
     const uint32_t npairs = *pair_count;
@@ -689,18 +713,20 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
         const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
         const int ty = blockIdx.x;
         if (ty >= tiles_y) continue;                                  // uniform per block
-        double M[6];
+        double M[PERSP ? 9 : 6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) M[j] = pd.M[j];
+        for (int j = 0; j < (PERSP ? 9 : 6); ++j) M[j] = pd.M[j];
+        [[maybe_unused]] const int bw0 = max(1, min(1024 / max(min(16, ag.sh), 1), ag.sw));   // PERSP: WarpPerspectiveInvoker's block width
         const uint8_t* frame = frames + (int64_t)f * frame_stride;
         const int dy = ty * SM_TH + (threadIdx.x / SM_TW);
         const int dya = ty * SM_TH, dyb = min(ag.dh, dya + SM_TH) - 1;
         int sy_lo, sy_hi;
         if (ag.fast) { sy_lo = dya * ag.iscale_y; sy_hi = min((dyb + 1) * ag.iscale_y - 1, ag.sh - 1); }
         else { sy_lo = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dya]].si; sy_hi = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dyb + 1] - 1].si; }
-        const bool tabled_y = (sy_hi - sy_lo) < RP_SPAN_Y;
+        const bool tabled_y = PERSP ? true : (sy_hi - sy_lo) < RP_SPAN_Y;
+        [[maybe_unused]] const int sph = sy_hi - sy_lo + 1;
         __syncthreads();                                              // previous pair's readers of the LDS tables are done
-        if (tabled_y)
+        if (!PERSP && tabled_y)
             for (int i = threadIdx.x; i <= sy_hi - sy_lo; i += 256) {
                 const int y = sy_lo + i;
                 s_x0[i] = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
@@ -716,6 +742,31 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
             const int dxa = tx * SM_TW, dxb = min(ag.dw, dxa + SM_TW) - 1;
             if (ag.fast) { T.sx_lo = dxa * ag.iscale_x; T.sx_hi = min((dxb + 1) * ag.iscale_x - 1, ag.sw - 1); }
             else { T.sx_lo = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxa]].si; T.sx_hi = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxb + 1] - 1].si; }
+            if constexpr (PERSP) {
+                T.tabled = (T.sx_hi - T.sx_lo + 1) * sph <= RP_XY_MAX;
+                // The denominator is linear in (x, y): if it keeps its sign at the four corners of the source span it keeps it
+                // inside, the map is then projective on the whole rectangle (lines to lines, convex to convex) and the corner
+                // images bound every tap (+- 1 px for the rounding of each coordinate).
+                const double w00 = M[6] * T.sx_lo + M[7] * sy_lo + M[8], w10 = M[6] * T.sx_hi + M[7] * sy_lo + M[8];
+                const double w01 = M[6] * T.sx_lo + M[7] * sy_hi + M[8], w11 = M[6] * T.sx_hi + M[7] * sy_hi + M[8];
+                const bool same = (w00 > 0 && w10 > 0 && w01 > 0 && w11 > 0) || (w00 < 0 && w10 < 0 && w01 < 0 && w11 < 0);
+                if (T.tabled && same) {
+                    int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
+                    persp_src(M, bw0, T.sx_lo, sy_lo, X00, Y00); persp_src(M, bw0, T.sx_hi, sy_lo, X10, Y10);
+                    persp_src(M, bw0, T.sx_lo, sy_hi, X01, Y01); persp_src(M, bw0, T.sx_hi, sy_hi, X11, Y11);
+                    const int ux0 = min(min(X00, X10), min(X01, X11)) - 1, ux1 = max(max(X00, X10), max(X01, X11)) + 1;
+                    const int uy0 = min(min(Y00, Y10), min(Y01, Y11)) - 1, uy1 = max(max(Y00, Y10), max(Y01, Y11)) + 1;
+                    const int bx0 = max(ux0, 0), bx1 = min(ux1, fw - 1);
+                    const int by0 = max(uy0, 0), by1 = min(uy1, fh - 1);
+                    if (bx1 >= bx0 && by1 >= by0) {
+                        const int px0 = bx0 & ~3, npx4 = (bx1 - px0 + 4) >> 2;
+                        const int wpitch = npx4 * 16, nrows = by1 - by0 + 1;
+                        if ((int64_t)wpitch * nrows <= RP_WIN_BYTES && (((uintptr_t)frames | (uintptr_t)frame_stride | (uintptr_t)stride) & 3) == 0) {
+                            T.windowed = 1; T.wx0 = px0; T.wy0 = by0; T.wpitch = wpitch; T.npx4 = npx4; T.nrows = nrows;
+                        }
+                    }
+                }
+            } else {
             T.tabled = tabled_y && (T.sx_hi - T.sx_lo) < RP_SPAN_X;
             if (T.tabled) {
                 // X, Y are monotone in x and in y, so the corners of the source span bound every tap
@@ -742,6 +793,7 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                         T.windowed = 1; T.wx0 = px0; T.wy0 = by0; T.wpitch = wpitch; T.npx4 = npx4; T.nrows = nrows;
                     }
                 }
+            }
             }
             s_tile[tx] = T;
         }
@@ -782,11 +834,25 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
             const bool windowed = tabled && T.windowed, all_in = T.all_in;
             const int wx0 = T.wx0, wy0 = T.wy0, wpitch = T.wpitch;
             __syncthreads();                                          // previous tile's readers of s_ad / win are done
+            [[maybe_unused]] const int spw = sx_hi - sx_lo + 1;
+            if constexpr (PERSP) {
+                if (tabled) {
+                    const float inv = 1.0f / (float)spw;
+                    for (int i = threadIdx.x; i < spw * sph; i += 256) {
+                        int yy = (int)(((float)i + 0.5f) * inv);          // i / spw (i < 2^13: exact, see load_group)
+                        yy -= (yy * spw > i) ? 1 : 0; yy += ((yy + 1) * spw <= i) ? 1 : 0;
+                        int X, Y;
+                        persp_src(M, bw0, sx_lo + (i - yy * spw), sy_lo + yy, X, Y);
+                        s_xy[i] = ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16);
+                    }
+                }
+            } else {
             if (tabled)
                 for (int i = threadIdx.x; i <= sx_hi - sx_lo; i += 256) {
                     const int x = sx_lo + i;
                     s_ad[i] = sat_int_d(M[0] * x * AB_SCALE); s_bd[i] = sat_int_d(M[3] * x * AB_SCALE);
                 }
+            }
             if (windowed) {
                 const int total = T.npx4 * T.nrows;
 #pragma unroll
@@ -805,6 +871,55 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
             if (dx < ag.dw && dy < ag.dh) {
                 uint8_t o[3];
                 const int xb = ag.fast ? 0 : idx[ag.xidx_ofs + dx], xe = ag.fast ? 0 : idx[ag.xidx_ofs + dx + 1];
+                if constexpr (PERSP) {
+                    if (windowed && !ag.fast && ag.max_xtaps <= 8) {
+                        // LDS coordinate table + LDS window: per tap one table read, the in-frame test and one aligned 4-byte
+                        // window read (out-of-frame taps read the zero pixel; padding taps repeat the last real tap with weight 0)
+                        const int yb = idx[ag.yidx_ofs + dy], ye = idx[ag.yidx_ofs + dy + 1];
+                        auto run = [&](auto xb_tag) {
+                            constexpr int XB = decltype(xb_tag)::value;
+                            float al[XB]; int xo[XB];
+#pragma unroll
+                            for (int k = 0; k < XB; ++k) {
+                                const bool in = xb + k < xe;
+                                const AreaTap t = taps[ag.xtap_ofs + (in ? xb + k : xe - 1)];
+                                al[k] = in ? t.alpha : 0.f;
+                                xo[k] = t.si - sx_lo;
+                            }
+                            float s0 = 0, s1 = 0, s2 = 0;
+                            const int wbase = -wy0 * wpitch - 4 * wx0;
+                            for (int j = yb; j < ye; ++j) {
+                                const AreaTap tyv = taps[ag.ytap_ofs + j];
+                                const int rowb = (tyv.si - sy_lo) * spw;
+                                float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+                                for (int k = 0; k < XB; ++k) {
+                                    const uint32_t e = s_xy[rowb + xo[k]];
+                                    const int X = (int)(short)(e & 0xFFFFu), Y = (int)e >> 16;
+                                    int ofs = (int)__mul24(Y, wpitch) + 4 * X + wbase;
+                                    ofs = ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) ? ofs : RP_WIN_BYTES;
+                                    const uint32_t px = *reinterpret_cast<const uint32_t*>(win + ofs);
+                                    b0 = b0 + (float)(px & 255u) * al[k]; b1 = b1 + (float)((px >> 8) & 255u) * al[k]; b2 = b2 + (float)((px >> 16) & 255u) * al[k];
+                                }
+                                if (j == yb) { s0 = tyv.alpha * b0; s1 = tyv.alpha * b1; s2 = tyv.alpha * b2; }
+                                else { s0 += tyv.alpha * b0; s1 += tyv.alpha * b1; s2 += tyv.alpha * b2; }
+                            }
+                            o[0] = sat_u8_f(s0); o[1] = sat_u8_f(s1); o[2] = sat_u8_f(s2);
+                        };
+                        using T6 = std::integral_constant<int, 6>; using T8 = std::integral_constant<int, 8>;
+                        if (ag.max_xtaps <= 6) run(T6{}); else run(T8{});
+                    } else {
+                        area_pixel_simple(ag, taps, idx, dx, dy, [&](int x, int y, uint8_t* p) {
+                            int X, Y;
+                            if (tabled) { const uint32_t e = s_xy[(y - sy_lo) * spw + (x - sx_lo)]; X = (int)(short)(e & 0xFFFFu); Y = (int)e >> 16; }
+                            else persp_src(M, bw0, x, y, X, Y);
+                            if ((unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh) {
+                                const uint8_t* sp = frame + (int64_t)Y * stride + 3 * X;
+                                p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+                            } else { p[0] = p[1] = p[2] = 0; }
+                        }, o);
+                    }
+                } else {
                 if (windowed && !ag.fast && ag.max_xtaps <= 8) {
                     // common case: LDS tables + LDS window.  Per output pixel: x-tap terms once, then per source row
                     // 2 LDS reads and per tap 2 add/shift pairs, a bounds test and ONE aligned 4-byte LDS read.
@@ -863,6 +978,7 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
                         } else { p[0] = p[1] = p[2] = 0; }
                     }, o);
+                }
                 }
                 const uint8_t* ref = page_small + pd.small_ofs + ((int64_t)dy * ag.dw + dx) * 3;
                 int d0 = (int)o[0] - ref[0], d1 = (int)o[1] - ref[1], d2 = (int)o[2] - ref[2];

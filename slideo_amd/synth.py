@@ -46,3 +46,19 @@ def frames(page_stack, n, w=1920, h=1080, first=0, seed=FRAME_SEED, threads=None
                              out.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p),
                              tm.ctypes.data_as(C.c_void_p), threads)
     return out, tp, tm.reshape(n, 2, 3)
+
+
+def frames_persp(page_stack, n, w=1920, h=1080, persp=0.15, first=0, seed=FRAME_SEED, threads=None):
+    """n frames showing random pages under a HOMOGRAPHY (keystone of about persp / 2 across the slide, then the
+    similarity of frames()).  Returns (frames, truth_page, truth_H [n,3,3] slide->frame)."""
+    page_stack = np.ascontiguousarray(page_stack, np.uint8)
+    P, ph, pw, _ = page_stack.shape
+    out = np.empty((n, h, w, 3), np.uint8)
+    tp = np.empty(n, np.int32)
+    th = np.empty((n, 9), np.float64)
+    threads = threads or min(os.cpu_count() or 1, 64)
+    _L().slideo_synth_frames_persp(C.c_uint64(seed), C.c_int64(first), n,
+                                   page_stack.ctypes.data_as(C.c_void_p), P, pw, ph, w, h, C.c_double(persp),
+                                   out.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p),
+                                   th.ctypes.data_as(C.c_void_p), threads)
+    return out, tp, th.reshape(n, 3, 3)

@@ -21,13 +21,13 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.EXPORTS) == names
-    assert L.slideo_abi_version() == 3
+    assert L.slideo_abi_version() == 4
 
 
 def test_config_struct_matches_oracle_layout(capi, oracle):
     import ctypes as C
     a, b = capi.default_config(), oracle.default_config()
-    assert C.sizeof(a) == C.sizeof(b) == 136
+    assert C.sizeof(a) == C.sizeof(b) == 144        # ABI 4: + verify_model, + ocv.hdlt
     assert bytes(a) == bytes(b)
 
 

@@ -35,7 +35,7 @@ def _compare_trace(gv, gc, ov, oc, tag):
     assert list(gc["survived"]) == list(oc["survived"]), tag
     for a, b in zip(gc, oc):
         if b["inliers"] > 0:
-            scale = np.array([1, 1, 1e3, 1, 1, 1e3])
+            scale = np.array([1, 1, 1e3, 1, 1, 1e3, 1e-3, 1e-3, 1])     # 3x3: translations in px, projective terms ~ 1 / px
             assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale, equal_nan=True), tag
         assert abs(a["similarity"] - b["similarity"]) <= 1e-4, tag
     assert gv["page_idx"] == ov["page_idx"] and gv["inliers"] == ov["inliers"], tag

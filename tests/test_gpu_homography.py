@@ -1,0 +1,105 @@
+"""verify_model 1 (8-DOF homography, BASELINE configs[4] / north_star "RANSAC homography verification"):
+the HIP path (csrc/homography.hip.h ransac_h_kernel, reproject_kernel<PERSP>) against the CPU restatement of
+cv::findHomography + warpPerspective (oracle find_homography / WarpSampler), through the C ABI.
+
+Bar: candidate pages, vote counts and RANSAC inlier counts equal (the per-sample model is computed in the oracle's exact
+operation order), 3x3 transform rel 1e-5 (the refit over the inliers sums in wave order), |d similarity| <= 1e-4, verdicts
+equal.  The default model (0, the reference's estimateAffinePartial2D) is covered by every other test file, unchanged."""
+import numpy as np
+import pytest
+
+from conftest import small_cfg
+from test_gpu_parity import _build_both, _compare_traces
+
+pytestmark = pytest.mark.gpu
+
+
+def _project(H, p):
+    q = np.c_[p, np.ones(len(p))] @ H.T
+    return q[:, :2] / q[:, 2:]
+
+
+def test_homography_traces_cfg0(capi, oracle, cfg0_data):
+    """BASELINE configs[0] with the homography verifier: every candidate of every frame against the oracle."""
+    pages, frames, truth, _ = cfg0_data
+    m, db = _build_both(capi, oracle, small_cfg(capi, verify_model=1), small_cfg(oracle, verify_model=1), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    assert all(g == t or g == -1 for g, t in zip(v["page_idx"], truth))        # (see test_oracle_homography: degenerate strips)
+    assert np.array_equal(m.match_frames(frames), v), "deterministic"
+    m.close()
+
+
+@pytest.mark.parametrize("over", [
+    dict(ransac_threshold=1.5, ransac_max_iters=300, ransac_confidence=0.9, refine_iters=0),
+    dict(knn_k=12, max_candidate_pages=7, max_rated=3, refine_iters=3),
+    dict(min_rating=5.0, min_rating_ratio=0.05, min_similarity=0.3, ransac_max_iters=37),
+], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_homography_other_parameters(capi, oracle, cfg0_data, over):
+    pages, frames, truth, _ = cfg0_data
+    m, db = _build_both(capi, oracle, small_cfg(capi, verify_model=1, **over), small_cfg(oracle, verify_model=1, **over), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    m.close()
+
+
+def test_perspective_frames_1080p(capi, oracle, synth):
+    """Frames generated under a true projective map (csrc/synth.cpp slideo_synth_frames_persp, keystone ~ 10 %), 2001x1125
+    pages, 1080p frames: traces equal the oracle's, the page is found, the generator's homography is recovered, and the
+    reference's similarity model keeps far fewer inliers on the same frames."""
+    pages = synth.pages(4)
+    frames, truth, tH = synth.frames_persp(pages, 6, 1920, 1080, persp=0.2, first=1)
+    kw = dict(nfeatures=1000, verify_model=1)
+    m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    show = truth >= 0
+    # (consecutive synthetic pages may share a template — csrc/synth.cpp, p = 0.3 — and differ by one text row: such a
+    # frame can go to the sibling page, in the oracle as here; the traces above are the parity statement)
+    right = v["page_idx"] == truth
+    assert show.sum() >= 4 and right[show].mean() >= 0.75
+    corners = np.array([[0, 0], [2001, 0], [2001, 1125], [0, 1125], [1000, 560]], np.float64)
+    for i in np.flatnonzero(show & right):
+        c = m.last_candidates(int(i))
+        top = c[np.argmax(c["inliers"])]
+        assert top["page_idx"] == truth[i]
+        assert np.abs(_project(top["transform"].reshape(3, 3), corners) - _project(tH[i], corners)).max() < 8.0
+    m0 = capi.Matcher(capi.default_config(nfeatures=1000))
+    m0.add_pages(list(pages)); m0.finalize()
+    v0 = m0.match_frames(frames)
+    assert (v["inliers"][show] > 1.5 * np.maximum(v0["inliers"][show], 1)).mean() >= 0.75
+    m0.close(); m.close()
+
+
+def test_homography_larger_deck_and_units(capi, oracle, synth):
+    """48 pages / 24 frames (candidates with 5..200 votes: both LDS instances, duplicate-heavy sample schedules of tiny
+    candidates, "no slide" frames) and the same batch cut into pipelined units."""
+    pages = synth.pages(48, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    m, db = _build_both(capi, oracle, small_cfg(capi, verify_model=1), small_cfg(oracle, verify_model=1), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    big = np.concatenate([frames] * 6)                      # 144 frames: two halves in flight
+    vb = m.match_frames(big)
+    assert np.array_equal(vb, np.concatenate([v] * 6))
+    m.close()
+
+
+def test_homography_rng_stream_grows_on_demand(capi, oracle, cfg0_data, monkeypatch):
+    """A stream far too short for the 4-point schedules (rejected subsets consume draws too): grown and re-run."""
+    pages, frames, truth, _ = cfg0_data
+    monkeypatch.setenv("SLIDEO_RNG_STREAM_LEN", "2048")
+    m, db = _build_both(capi, oracle, small_cfg(capi, verify_model=1), small_cfg(oracle, verify_model=1), pages)
+    monkeypatch.delenv("SLIDEO_RNG_STREAM_LEN")
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    m.close()
+
+
+def test_homography_config_validation(capi):
+    with pytest.raises(capi.SlideoError) as e:
+        capi.Matcher(capi.default_config(verify_model=2))
+    assert e.value.code == 5
+    with pytest.raises(capi.SlideoError) as e:
+        capi.Matcher(capi.default_config(verify_model=1, ocv_hdlt=1))       # oracle-only cross-check form
+    assert e.value.code == 5

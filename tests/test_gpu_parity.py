@@ -243,7 +243,10 @@ def _build_both(capi, oracle, gcfg, ocfg, pages):
     return m, db
 
 
-def _compare_traces(m, db, frames, verdicts):
+def _compare_traces(m, db, frames, verdicts, skip_ill_conditioned=False):
+    """skip_ill_conditioned (verify_model 1): a homography refitted over a nearly degenerate inlier set (h33 of the
+    smallest eigenvector ~ 0, entries of 1e6 and more after the division) is noise in both implementations — its
+    entries are only compared when the candidate SURVIVED the rating, i.e. when the matrix is used."""
     for i, fr in enumerate(frames):
         ov, oc = db.match_frame_trace(fr)
         gv = verdicts[i]
@@ -255,8 +258,8 @@ def _compare_traces(m, db, frames, verdicts):
         assert list(gc["inliers"]) == list(oc["inliers"]), "inlier counts differ in frame %d" % i
         assert list(gc["survived"]) == list(oc["survived"])
         for a, b in zip(gc, oc):
-            if b["inliers"] > 0:
-                scale = np.array([1, 1, 1e3, 1, 1, 1e3])
+            if b["inliers"] > 0 and not (skip_ill_conditioned and not b["survived"] and np.abs(b["transform"]).max() > 1e5):
+                scale = np.array([1, 1, 1e3, 1, 1, 1e3, 1e-3, 1e-3, 1])     # 3x3: translations in px, projective terms ~ 1 / px
                 # (equal_nan: two votes on coincident points make the 2-point model degenerate — NaN in both, as in the reference's
                 # arithmetic; such a candidate has 2 inliers and never survives the rating)
                 assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-6 * scale, equal_nan=True)
