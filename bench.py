@@ -38,8 +38,10 @@ WORKLOADS = {
     "cfg1": dict(frame=(1920, 1080), page=(2001, 1125), pages=100, nfeatures=1000, batch=256,
                  name="configs[1]: 1080p batch=256 vs 100 pages, ORB-1000"),
     # BASELINE.json configs[4] shape on one GPU: 4K frames, ORB-2000, 1000-page deck (2 M train descriptors)
-    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64,
-                 name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000"),
+    # ("RANSAC homography verify": verify_model 1 = the 8-DOF model of include/slideo_amd.h on frames generated under a true
+    # projective map; --verify-model 0 --persp 0 gives the reference's similarity model on similarity frames)
+    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64, verify_model=1, persp=0.1,
+                 name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000, homography verification"),
     # BASELINE.json configs[2]: SIFT-128 descriptors, L2 BFMatcher as an N x M x 128 MFMA contraction, 1080p vs 500 pages.
     # The k-NN stage only (bench_cfg2): there is no SIFT extractor on the device, so the descriptor
     # sets are synthetic SIFT-shaped u8 vectors of the sizes the ORB path produces (1000 per frame, ~1850 per page).
@@ -166,6 +168,13 @@ def main():
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: the job is this many frames in all (BASELINE configs[3] is a fixed 216 000-frame job); each of the "
                          "K timed steps then processes total/(K*N) frames per GPU instead of the workload's fixed per-GPU batch")
+    ap.add_argument("--verify-model", type=int, default=-1, choices=[-1, 0, 1],
+                    help="geometric model of the verification: 0 = the reference's 4-DOF similarity (estimateAffinePartial2D), 1 = 8-DOF homography "
+                         "(findHomography + warpPerspective; default: the workload's, 1 for cfg4, else 0)")
+    ap.add_argument("--hdlt", type=int, default=0, choices=[0, 1],
+                    help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors, "
+                         "1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample)")
+    ap.add_argument("--persp", type=float, default=-1.0, help="projective component of the synthetic frames (0 = similarity frames; default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
@@ -223,10 +232,15 @@ def main():
     # ---- synthetic inputs (seeded; same pages on every rank, disjoint frame ranges per rank)
     t0 = time.time()
     pages = synth.pages(P, pw, ph, threads=gen_threads)
-    frames, truth, _ = synth.frames(pages, B, fw, fh, first=rank * B, threads=gen_threads)
+    verify_model = wl.get("verify_model", 0) if args.verify_model < 0 else args.verify_model
+    persp = wl.get("persp", 0.0) if args.persp < 0 else args.persp
+    if persp > 0:
+        frames, truth, _ = synth.frames_persp(pages, B, fw, fh, persp=persp, first=rank * B, threads=gen_threads)
+    else:
+        frames, truth, _ = synth.frames(pages, B, fw, fh, first=rank * B, threads=gen_threads)
     t_gen = time.time() - t0
 
-    cfg = _capi.default_config(nfeatures=wl["nfeatures"])
+    cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt)
     m = _capi.Matcher(cfg, device=local_rank)
     m.set_knn_engine(args.knn)
     args.inflight = min(args.inflight or m.max_in_flight(), m.max_in_flight())
@@ -316,6 +330,8 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
                    "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
+                   "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
+                   "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
                    "inputs": "the same %d synthetic frames per GPU are re-submitted every step, resident in HBM before the timed region (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % B,
                    "collective": ({"backend": backend, "all_gather_of_verdicts_checked": gathered_ok} if use_dist else None),
@@ -388,7 +404,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"])
+        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt)
         budget = host_cpu_budget()
         cores = max(1, min(ncpu, budget["usable"]))
         db = pyoracle.PageDB(ocfg)

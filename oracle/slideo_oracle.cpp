@@ -1258,7 +1258,7 @@ static bool find_homography(const P2f* from, const P2f* to, int count, const sli
     if (count < model_points) return false;
     bool result = false;
     if (count == model_points) {                                        // `method == 0 || npoints == 4`: the kernel alone
-        result = homography_dlt(from, to, count, H) > 0;
+        result = (c.ocv.hdlt == 1 ? homography_4pt_direct(from, to, H) : homography_dlt(from, to, count, H)) > 0;
         if (result) std::fill(mask, mask + count, (uint8_t)1);
         else std::fill(H, H + 9, 0.0);
         return result;

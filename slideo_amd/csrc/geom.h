@@ -204,7 +204,7 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (o.area < 0 || o.area > 1) { *why = "ocv.area must be 0 or 1"; return false; }
     if (o.warp != 0) { *why = "ocv.warp: only 0 (10-bit fixed point) is implemented on the GPU; the CPU restatement has 1"; return false; }
     if (o.lm != 0) { *why = "ocv.lm: only 0 (Gaussian elimination) is implemented on the GPU; the CPU restatement has 1"; return false; }
-    if (o.hdlt != 0) { *why = "ocv.hdlt: only 0 (L^T L + Jacobi eigenvectors) is implemented on the GPU; the CPU restatement has 1"; return false; }
+    if (o.hdlt < 0 || o.hdlt > 1) { *why = "ocv.hdlt must be 0 or 1"; return false; }
     if (c.verify_model < 0 || c.verify_model > 1) { *why = "verify_model must be 0 (similarity) or 1 (homography)"; return false; }
     return true;
 }

@@ -26,16 +26,15 @@
 
 namespace slideo {
 
-constexpr int HJ = 64;                      // lanes = Jacobi slices per block
+// Jacobi slices per block (ocv.hdlt 0).  A wave issues one instruction per 4 cycles whatever its number of active lanes and the
+// sweep is issue bound (~1000 instructions per rotation, ~140 rotations per sample), while the LDS bounds the SLICES per CU
+// (1008 B each): 32 slices per wave = four waves per CU, one on every SIMD (64 slices: two waves, half the SIMDs idle — 2x slower).
+constexpr int HJ = 32;
 constexpr int HJ_TRI = 36, HJ_V = 81, HJ_W = 9;
 constexpr int HJ_SLICE = HJ_TRI + HJ_V + HJ_W;       // doubles per lane
-constexpr int H_WIN = 1024;                 // RNG stream entries staged in LDS per sampling round
+constexpr int H_WIN = 512;                  // RNG stream entries staged in LDS per sampling round
 constexpr int H_QUEUE = 128;                // valid subsets waiting for a Jacobi phase
 constexpr int H_MAX_ATTEMPTS = 10000;       // getSubset(..., maxAttempts) as RANSACPointSetRegistrator::run passes it
-
-__host__ __device__ constexpr size_t ransac_h_lds_bytes(int lds_pts) {
-    return (size_t)HJ_SLICE * HJ * 8 + (size_t)lds_pts * 16 + (size_t)lds_pts + (size_t)H_WIN * 4 + (size_t)H_QUEUE * 8 + 64;
-}
 
 __device__ __forceinline__ int tri9(int i, int j) { return ((i * (17 - i)) >> 1) + (j - i - 1); }   // i < j, upper triangle of 9x9
 __device__ __forceinline__ int tri9u(int a, int b) { return a < b ? tri9(a, b) : tri9(b, a); }
@@ -64,7 +63,8 @@ __device__ __forceinline__ void ltl_add(double (&LtL)[45], double X, double Y, d
 
 // JacobiImpl_<double> (core/src/lapack.cpp) on the lane's LDS slice, then the eigenvector of the smallest eigenvalue.
 // LtL: upper triangle incl. diagonal, row-major (45).  `active` lanes without a problem idle; the loop is wave-uniform.
-__device__ __noinline__ void jacobi9_smallest(double* __restrict__ A, double* __restrict__ V, double* __restrict__ W,
+template <int HJ>       // stride between consecutive elements of a slice (= slices interleaved in the buffer)
+__device__ __forceinline__ void jacobi9_smallest(double* __restrict__ A, double* __restrict__ V, double* __restrict__ W,
                                               const double (&LtL)[45], bool active, double (&h)[9]) {
     // initial state: V = I, W = diagonal, A = strict upper triangle; indR / indC as packed nibbles
     uint64_t indR = 0, indC = 0;
@@ -98,25 +98,58 @@ __device__ __noinline__ void jacobi9_smallest(double* __restrict__ A, double* __
             }
         }
     }
+    // The pivot candidates — the value at each row's / column's tracked maximum — live in registers: rv[i] = A[i][indR[i]]
+    // (i = 0..7), cv[i - 1] = A[indC[i]][i] (i = 1..8).  OpenCV re-reads them from the matrix on every sweep; here they are
+    // kept current instead: a rotation changes rows / columns k and l only, every changed element passes through registers
+    // (na / nb below), so the caches are patched by compare-selects and the LDS is read once per rotation, for the elements
+    // the rotation needs.  Same values, same comparisons, same order.
+    double rv[8], cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rv[i] = 0; cv[i] = 0; }
+    if (active) {
+        auto at = [&](int j, int k) -> double { return LtL[j * 9 - (j * (j - 1)) / 2 + (k - j)]; };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = (int)((indR >> (4 * i)) & 15);
+            double v = 0;
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) v = c == j ? at(i, j) : v;
+            rv[i] = v;
+        }
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int r = (int)((indC >> (4 * i)) & 15);
+            double v = 0;
+#pragma unroll
+            for (int j = 0; j < i; ++j) v = r == j ? at(j, i) : v;
+            cv[i - 1] = v;
+        }
+    }
     bool run = active;
     int iters = 0;
     while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
         if (run) {
             // pivot: the largest of the row maxima, then of the column maxima (strict >, first wins)
-            double rv[8]; int rc[8];
+            int k = 0, l = (int)(indR & 15); double p = rv[0], mv = fabs(rv[0]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { rc[i] = (int)((indR >> (4 * i)) & 15); rv[i] = A[tri9(i, rc[i]) * HJ]; }
-            double cv[8]; int cr[8];
+            for (int i = 1; i < 8; ++i) { const double v = fabs(rv[i]); if (mv < v) { mv = v; k = i; l = (int)((indR >> (4 * i)) & 15); p = rv[i]; } }
 #pragma unroll
-            for (int i = 1; i < 9; ++i) { cr[i - 1] = (int)((indC >> (4 * i)) & 15); cv[i - 1] = A[tri9(cr[i - 1], i) * HJ]; }
-            int k = 0, l = rc[0]; double p = rv[0], mv = fabs(rv[0]);
-#pragma unroll
-            for (int i = 1; i < 8; ++i) { const double v = fabs(rv[i]); if (mv < v) { mv = v; k = i; l = rc[i]; p = rv[i]; } }
-#pragma unroll
-            for (int i = 1; i < 9; ++i) { const double v = fabs(cv[i - 1]); if (mv < v) { mv = v; k = cr[i - 1]; l = i; p = cv[i - 1]; } }
+            for (int i = 1; i < 9; ++i) { const double v = fabs(cv[i - 1]); if (mv < v) { mv = v; k = (int)((indC >> (4 * i)) & 15); l = i; p = cv[i - 1]; } }
             if (fabs(p) <= DBL_EPSILON) run = false;
             else {
+                // everything the rotation reads, requested together
                 const double wk = W[k * HJ], wl = W[l * HJ];
+                double a0[9], b0[9], vk[9], vl[9];
+                int ik[9], il[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const bool on = i != k && i != l;
+                    ik[i] = tri9u(on ? i : (k == 0 ? 1 : 0), on ? k : (k == 0 ? 0 : k)) * HJ;      // (a valid address for the two skipped slots)
+                    il[i] = tri9u(on ? i : (l == 0 ? 1 : 0), on ? l : (l == 0 ? 0 : l)) * HJ;
+                    a0[i] = A[ik[i]]; b0[i] = A[il[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { vk[i] = V[(k * 9 + i) * HJ]; vl[i] = V[(l * 9 + i) * HJ]; }
                 const double y = (wl - wk) * 0.5;
                 double t = fabs(y) + hypot_cv(p, y);
                 double s = hypot_cv(p, t);
@@ -125,35 +158,56 @@ __device__ __noinline__ void jacobi9_smallest(double* __restrict__ A, double* __
                 if (y < 0) { s = -s; t = -t; }
                 A[tri9(k, l) * HJ] = 0;
                 W[k * HJ] = wk - t; W[l * HJ] = wl + t;
-                // rows and columns k and l
+                // rows and columns k and l; na[i] / nb[i] = the new (i,k) / (i,l) elements, 0 in the slots of k and l themselves
+                // (A[k][l] has just become 0: what the refresh below must see there)
+                double na[9], nb[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i)
-                    if (i != k && i != l) {
-                        const int ik = tri9u(i, k) * HJ, il = tri9u(i, l) * HJ;
-                        const double a0 = A[ik], b0 = A[il];
-                        A[ik] = a0 * c - b0 * s; A[il] = a0 * s + b0 * c;
-                    }
+                for (int i = 0; i < 9; ++i) {
+                    const bool on = i != k && i != l;
+                    na[i] = on ? a0[i] * c - b0[i] * s : 0.0;
+                    nb[i] = on ? a0[i] * s + b0[i] * c : 0.0;
+                    if (on) { A[ik[i]] = na[i]; A[il[i]] = nb[i]; }
+                }
                 // eigenvectors
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
-                    const int vk = (k * 9 + i) * HJ, vl = (l * 9 + i) * HJ;
-                    const double a0 = V[vk], b0 = V[vl];
-                    V[vk] = a0 * c - b0 * s; V[vl] = a0 * s + b0 * c;
+                    V[(k * 9 + i) * HJ] = vk[i] * c - vl[i] * s;
+                    V[(l * 9 + i) * HJ] = vk[i] * s + vl[i] * c;
                 }
-                // refresh the tracked maxima of rows / columns k and l only (as OpenCV does)
+                // tracked elements of the OTHER rows / columns that the rotation changed: value only (OpenCV does not re-search them)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c_i = (int)((indR >> (4 * i)) & 15);
+                    if (i != k && i != l) rv[i] = c_i == k ? na[i] : (c_i == l ? nb[i] : rv[i]);
+                }
+#pragma unroll
+                for (int i = 1; i < 9; ++i) {
+                    const int r_i = (int)((indC >> (4 * i)) & 15);
+                    if (i != k && i != l) cv[i - 1] = r_i == k ? na[i] : (r_i == l ? nb[i] : cv[i - 1]);
+                }
+                // rows / columns k and l: searched again (as OpenCV does), over the values just computed
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int idx = j == 0 ? k : l;
-                    int mr = idx + 1, mc = 0; double mvr = -1.0, mvc = -1.0;
+                    int mr = idx + 1, mc = 0; double mvr = -1.0, mvc = -1.0, pr = 0, pc = 0;
 #pragma unroll
                     for (int i = 0; i < 9; ++i)
                         if (i != idx) {
-                            const double v = fabs(A[tri9u(i, idx) * HJ]);
-                            if (i > idx) { if (mvr < v) { mvr = v; mr = i; } }
-                            else { if (mvc < v) { mvc = v; mc = i; } }
+                            const double e = j == 0 ? na[i] : nb[i];
+                            const double v = fabs(e);
+                            if (i > idx) { if (mvr < v) { mvr = v; mr = i; pr = e; } }
+                            else { if (mvc < v) { mvc = v; mc = i; pc = e; } }
                         }
-                    if (idx < 8) indR = (indR & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mr << (4 * idx));
-                    if (idx > 0) indC = (indC & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mc << (4 * idx));
+                    if (idx < 8) {
+                        indR = (indR & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mr << (4 * idx));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) rv[i] = i == idx ? pr : rv[i];
+                    }
+                    if (idx > 0) {
+                        indC = (indC & ~((uint64_t)15 << (4 * idx))) | ((uint64_t)mc << (4 * idx));
+#pragma unroll
+                        for (int i = 1; i < 9; ++i) cv[i - 1] = i == idx ? pc : cv[i - 1];
+                    }
                 }
                 if (++iters >= 9 * 9 * 30) run = false;
             }
@@ -196,9 +250,8 @@ __device__ __forceinline__ void h_denormalise(const double (&h)[9], const HNorm&
     for (int j = 0; j < 9; ++j) H[j] = R[j] * sc;
 }
 
-// HomographyEstimatorCallback::runKernel on 4 pairs p[i] = (from.x, from.y, to.x, to.y); returns 1 model or 0
-__device__ __forceinline__ int dlt4(const float4 (&p)[4], double* A, double* V, double* W, bool active, double (&H)[9]) {
-    HNorm n{};
+// normalisation of HomographyEstimatorCallback::runKernel for 4 pairs p[i] = (from.x, from.y, to.x, to.y); false: no spread
+__device__ __forceinline__ bool norm4(const float4 (&p)[4], HNorm& n) {
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { cmx += p[i].z; cmy += p[i].w; cMx += p[i].x; cMy += p[i].y; }
@@ -208,17 +261,74 @@ __device__ __forceinline__ int dlt4(const float4 (&p)[4], double* A, double* V, 
         smx += fabs(p[i].z - cmx); smy += fabs(p[i].w - cmy);
         sMx += fabs(p[i].x - cMx); sMy += fabs(p[i].y - cMy);
     }
-    const bool ok = active && !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON);
-    smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
-    n.cmx = cmx; n.cmy = cmy; n.cMx = cMx; n.cMy = cMy; n.smx = smx; n.smy = smy; n.sMx = sMx; n.sMy = sMy;
+    const bool ok = !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON);
+    n.cmx = cmx; n.cmy = cmy; n.cMx = cMx; n.cMy = cMy; n.smx = 4 / smx; n.smy = 4 / smy; n.sMx = 4 / sMx; n.sMy = 4 / sMy;
+    return ok;
+}
+
+// ocv.hdlt 0 — HomographyEstimatorCallback::runKernel on 4 pairs: L^T L + Jacobi.  Returns 1 model or 0.
+template <int ST>
+__device__ __forceinline__ int dlt4(const float4 (&p)[4], double* A, double* V, double* W, bool active, double (&H)[9]) {
+    HNorm n{};
+    const bool ok = norm4(p, n) && active;
     double LtL[45];
 #pragma unroll
     for (int e = 0; e < 45; ++e) LtL[e] = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        ltl_add(LtL, (p[i].x - cMx) * sMx, (p[i].y - cMy) * sMy, (p[i].z - cmx) * smx, (p[i].w - cmy) * smy);
+        ltl_add(LtL, (p[i].x - n.cMx) * n.sMx, (p[i].y - n.cMy) * n.sMy, (p[i].z - n.cmx) * n.smx, (p[i].w - n.cmy) * n.smy);
     double h[9];
-    jacobi9_smallest(A, V, W, LtL, ok, h);
+    jacobi9_smallest<ST>(A, V, W, LtL, ok, h);
+    if (ok) h_denormalise(h, n, H);
+    return ok ? 1 : 0;
+}
+
+// ocv.hdlt 1 — the same normalisation, then the 8 equations of the 4 pairs with h33 = 1 by Gaussian elimination with partial
+// pivoting (the oracle's homography_4pt_direct / solve_gauss_n<8>, operation for operation).  The 8 x 9 augmented matrix
+// lives in registers; a pivot row is brought up by compare-selects (rows below the diagonal only, columns >= c only: the
+// entries left of the diagonal are never read again).  ~2.4 k instructions per sample against ~140 k for the Jacobi sweep.
+__device__ __forceinline__ int dlt4_direct(const float4 (&p)[4], bool active, double (&H)[9]) {
+    HNorm n{};
+    bool ok = norm4(p, n) && active;
+    double M[8][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double x = (p[i].z - n.cmx) * n.smx, y = (p[i].w - n.cmy) * n.smy;
+        const double X = (p[i].x - n.cMx) * n.sMx, Y = (p[i].y - n.cMy) * n.sMy;
+        const double r0[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, x}, r1[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, y};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { M[2 * i][j] = r0[j]; M[2 * i + 1][j] = r1[j]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int pr = c; double best = M[c][c];
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) if (fabs(M[r][c]) > fabs(best)) { pr = r; best = M[r][c]; }
+        if (best == 0.0) ok = false;
+#pragma unroll
+        for (int j = c; j < 9; ++j) {
+            const double top = M[c][j];
+            double up = top;
+#pragma unroll
+            for (int r = c + 1; r < 8; ++r) { up = pr == r ? M[r][j] : up; M[r][j] = pr == r ? top : M[r][j]; }
+            M[c][j] = up;
+        }
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = M[r][c] / M[c][c];
+#pragma unroll
+            for (int j = c; j < 9; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    double h[9];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double sm = M[i][8];
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) sm -= M[i][j] * h[j];
+        h[i] = sm / M[i][i];
+    }
+    h[8] = 1;
     if (ok) h_denormalise(h, n, H);
     return ok ? 1 : 0;
 }
@@ -332,6 +442,7 @@ __device__ __noinline__ double lm8_eval(const float4* pts, const uint8_t* mask, 
 // 8x8 Gaussian elimination with partial pivoting (ocv.lm 0) on the lane's LDS slice (every lane solves the same system:
 // no broadcast, no divergence); sc: >= 72 doubles at stride HJ.  AU: upper triangle of the symmetric matrix, dl: added to
 // the diagonal (lambda * D).
+template <int HJ>
 __device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], const double (&dl)[8], const double (&b)[8], double (&x)[8]) {
     {
         int e = 0;
@@ -375,9 +486,51 @@ __device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], cons
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The sample schedule.  getSubset consumes the cv::RNG stream sequentially — an attempt takes 4 draws plus one per duplicate —
+// so where attempt j starts depends on every attempt before it.  (ransac_kernel's prefix-sum fixed point needs about one
+// round per attempt WITH a duplicate: fine for 2-point samples over hundreds of votes, hopeless for 4-point samples over the
+// 5..30 votes of a wrong candidate page, where most attempts have one.)  Here: the stream window is staged in LDS already
+// reduced modulo `count`; nxt[p] = where an attempt starting at window position p ends (a pure function of the window, all
+// positions in parallel); the tables J[d] = nxt^(2^d) by pointer doubling; lane j reads off start_j = nxt^j(0) from the bits
+// of j.  Six table rounds and six look-ups whatever the duplicate rate.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HS_END = H_WIN;                      // absorbing "beyond the window" position
+constexpr int HS_TAB = H_WIN + 8;                  // entries per table
+__host__ __device__ constexpr size_t ransac_h_samp_bytes() { return (size_t)H_WIN * 4 + 6 * (size_t)HS_TAB * 2; }
+
+// An attempt read from window position p: 4 distinct indices, `end` = the position after its last draw (HS_END if it would
+// run past the window).  win[] holds rng % count.
+__device__ __forceinline__ void read_attempt(const uint32_t* win, int p, uint32_t (&idx)[4], int& end) {
+    int q = p;
+    bool fit = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+        for (;;) {
+            if (q >= H_WIN) { fit = false; break; }
+            v = win[q]; ++q;
+            bool dup = false;
+#pragma unroll
+            for (int j = 0; j < i; ++j) dup = dup || v == idx[j];
+            if (!dup) break;
+        }
+        idx[i] = v;
+    }
+    end = fit ? q : HS_END;
+}
+
+// Scratch layout helper of ransac_h_kernel: jbuf (Jacobi slices; hdlt 0 only) | points | sampler tables | queue.
+// With hdlt 0 the sampler tables alias the Jacobi slices (sampling and scoring alternate, never overlap).
+__host__ __device__ constexpr size_t ransac_h_jbuf_bytes(int hdlt) { return hdlt ? 0 : (size_t)HJ_SLICE * HJ * 8; }
+__host__ __device__ constexpr size_t ransac_h_lds_bytes(int lds_pts, int hdlt) {
+    return (hdlt ? ransac_h_samp_bytes() + 64 : ransac_h_jbuf_bytes(0)) + (size_t)lds_pts * 16 + (size_t)H_QUEUE * 8 + 64;
+}
+
 // Two instances share the grid, as ransac_kernel's: <RANSAC_SMALL_PTS, 0> and <RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1>.
-// Dynamic LDS: ransac_h_lds_bytes(LDS_PTS).
-template <int LDS_PTS, int MIN_COUNT>
+// HDLT = slideo_ocv_variants.hdlt: how a minimal sample becomes a model.  Dynamic LDS: ransac_h_lds_bytes(LDS_PTS, HDLT).
+// Leaves per candidate: found, inliers, the RANSAC model in fc.M, the inlier mask in gmask (refine_h_kernel reads them).
+template <int LDS_PTS, int MIN_COUNT, int HDLT>
 __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                       const slideo_keypoint* __restrict__ frame_kp,
                                                       const float2* __restrict__ page_xy,
@@ -385,11 +538,15 @@ __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uin
                                                       FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
                                                       uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
+    constexpr int ST = HJ;                          // slices interleaved in jbuf (hdlt 0)
+    constexpr int CH = HDLT ? 64 : HJ;              // RANSAC iterations scored per phase
+    constexpr size_t REGION0 = HDLT ? ransac_h_samp_bytes() + 64 : ransac_h_jbuf_bytes(0);
     double* jbuf = reinterpret_cast<double*>(hsm);
-    float4* lpts = reinterpret_cast<float4*>(hsm + (size_t)HJ_SLICE * HJ * 8);
-    uint8_t* lmask = reinterpret_cast<uint8_t*>(lpts + LDS_PTS);
-    uint32_t* win = reinterpret_cast<uint32_t*>(hsm + (size_t)HJ_SLICE * HJ * 8 + (size_t)LDS_PTS * 16 + (((size_t)LDS_PTS + 15) & ~(size_t)15));
-    uint2* queue = reinterpret_cast<uint2*>(win + H_WIN);
+    uint32_t* win = reinterpret_cast<uint32_t*>(hsm);                           // (aliases jbuf when HDLT == 0)
+    uint16_t* jt = reinterpret_cast<uint16_t*>(hsm + (size_t)H_WIN * 4);       // 6 tables of HS_TAB
+    float4* lpts = reinterpret_cast<float4*>(hsm + REGION0);
+    uint2* queue = reinterpret_cast<uint2*>(hsm + REGION0 + (size_t)LDS_PTS * 16);
+    static_assert(ransac_h_samp_bytes() + 64 <= ransac_h_jbuf_bytes(0), "sampler tables fit in the Jacobi slices");
 
     const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     FrameCands& fc = fcs[f];
@@ -399,8 +556,10 @@ __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uin
     const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
     const uint2* vt = votes + vbase;
     float4* pts = count <= LDS_PTS ? lpts : gpts + vbase;
-    uint8_t* mask = count <= LDS_PTS ? lmask : gmask + vbase;
-    double* A = jbuf + lane; double* V = A + HJ_TRI * HJ; double* W = V + HJ_V * HJ;
+    uint8_t* mask = gmask + vbase;
+    [[maybe_unused]] double* A = jbuf + (lane & (ST - 1));
+    [[maybe_unused]] double* V = A + HJ_TRI * ST;
+    [[maybe_unused]] double* W = V + HJ_V * ST;
     const uint32_t qbase_f = qofs[f];
     for (int i0 = lane; i0 < count; i0 += 256) {
         uint2 v[4]; float2 s[4]; float2 kq[4];
@@ -420,68 +579,68 @@ __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uin
     double bestH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int found = 0, inl = 0;
     const float thr2 = (float)(vp.thr * vp.thr);
-    if (count == 4) {
-        // `npoints == 4`: the kernel alone, every pair an inlier, no refinement
-        const float4 p4[4] = {pts[0], pts[1], pts[2], pts[3]};
-        found = dlt4(p4, A, V, W, true, bestH);
-        inl = found ? 4 : 0;
-        if (!found) { for (int j = 0; j < 9; ++j) bestH[j] = 0; }
-    } else if (count > 4) {
-        int niters = max(vp.max_iters, 1), max_good = 0, base = 0;
+    if (count >= 4) {
+        // count == 4 (`npoints == 4` in findHomography): the kernel alone on the four pairs as they are — one "iteration" with
+        // the subset (0, 1, 2, 3), no subset check, every pair an inlier whatever its error
+        const bool exact4 = count == 4;
+        int niters = exact4 ? 1 : max(vp.max_iters, 1), max_good = 0, base = 0;
         uint32_t pos = 0;                  // stream position of the next attempt
         int nq = 0;                        // queued valid subsets
         int fail_run = 0;                  // consecutive rejected attempts since the last valid subset
         bool sched_end = false;            // getSubset gave up (10000 attempts): no further iteration exists
         bool overflow = false;
+        if (exact4) { if (lane == 0) queue[0] = make_uint2(0u | (1u << 16), 2u | (3u << 16)); nq = 1; sched_end = true; }
         while (base < niters) {
-            // ---- sampling rounds until a full wave of subsets is queued (or as many as the loop can still use) ----
-            const int need = min(64, niters - base);
+            // ---- sampling rounds until a full phase of subsets is queued (or as many as the loop can still use) ----
+            const int need = min(CH, niters - base);
             while (nq < need && !sched_end) {
                 if (pos + H_WIN + 64 > vp.rng_len) { overflow = true; break; }
                 __syncthreads();
                 for (int i = lane; i < H_WIN; i += 64) win[i] = rng_tab[pos + i] % (uint32_t)count;
                 __syncthreads();
-                auto draw = [&](uint32_t p) -> uint32_t {
-                    return p - pos < (uint32_t)H_WIN ? win[p - pos] : rng_tab[min(p, vp.rng_len - 1)] % (uint32_t)count;
-                };
-                uint32_t shift = 0, total = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-                for (;;) {
-                    uint32_t p = pos + 4 * lane + shift;
-                    const uint32_t p0 = p;
-                    const uint32_t lim = vp.rng_len - 1;
-                    i0 = draw(p); ++p;
-                    for (;;) { i1 = draw(p); ++p; if (i1 != i0 || p >= lim) break; }
-                    for (;;) { i2 = draw(p); ++p; if ((i2 != i0 && i2 != i1) || p >= lim) break; }
-                    for (;;) { i3 = draw(p); ++p; if ((i3 != i0 && i3 != i1 && i3 != i2) || p >= lim) break; }
-                    const uint32_t e = p - p0 - 4;
-                    uint32_t inc = e;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-                    const uint32_t nshift = inc - e;
-                    const bool changed = nshift != shift;
-                    shift = nshift;
-                    if (__builtin_amdgcn_ballot_w64(changed) == 0ull) { total = __shfl(inc, 63); break; }
+                uint16_t* J0 = jt;
+                for (int p = lane; p < HS_TAB; p += 64) {
+                    int end = HS_END;
+                    if (p < H_WIN) { uint32_t idx[4]; read_attempt(win, p, idx, end); }
+                    J0[p] = (uint16_t)end;
                 }
-                pos += 256 + total;
-                if (pos >= vp.rng_len) { overflow = true; break; }
-                const float4 p4[4] = {pts[i0], pts[i1], pts[i2], pts[i3]};
-                const bool valid = check_subset4(p4);
+                __syncthreads();
+#pragma unroll
+                for (int d = 1; d < 6; ++d) {
+                    const uint16_t* Jp = jt + (d - 1) * HS_TAB;
+                    uint16_t* Jn = jt + d * HS_TAB;
+                    for (int p = lane; p < HS_TAB; p += 64) Jn[p] = Jp[Jp[p]];
+                    __syncthreads();
+                }
+                int st = 0;                                             // start of attempt `lane`
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if ((lane >> d) & 1) st = jt[d * HS_TAB + st];
+                uint32_t idx[4] = {0, 1, 2, 3};
+                int end = HS_END;
+                if (st < H_WIN) read_attempt(win, st, idx, end);
+                const bool have = end != HS_END;                        // the attempt lies inside the window
+                const unsigned long long hb = __builtin_amdgcn_ballot_w64(have);
+                const int na = hb == ~0ull ? 64 : __builtin_ctzll(~hb); // attempts of this round (a prefix of the lanes)
+                if (na == 0) { overflow = true; break; }                // (> 500 duplicates in a row: not with count >= 5)
+                pos += (uint32_t)__shfl(end, na - 1);
+                const float4 p4[4] = {pts[idx[0]], pts[idx[1]], pts[idx[2]], pts[idx[3]]};
+                const bool valid = lane < na && check_subset4(p4);
                 const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
                 if (vb == 0ull) {
-                    fail_run += 64;
+                    fail_run += na;
                     if (fail_run >= H_MAX_ATTEMPTS) sched_end = true;
                     continue;
                 }
                 const int first = __builtin_ctzll(vb);
                 if (fail_run + first >= H_MAX_ATTEMPTS) { sched_end = true; continue; }
                 const int rank = __builtin_popcountll(vb & ((1ull << lane) - 1ull));
-                if (valid && nq + rank < H_QUEUE) queue[nq + rank] = make_uint2(i0 | (i1 << 16), i2 | (i3 << 16));
-                nq = min(nq + __builtin_popcountll(vb), H_QUEUE);     // (nq < 64 on entry and <= 64 arrive: never clipped)
-                fail_run = __builtin_clzll(vb);                       // rejected attempts after the round's last valid one
+                if (valid && nq + rank < H_QUEUE) queue[nq + rank] = make_uint2(idx[0] | (idx[1] << 16), idx[2] | (idx[3] << 16));
+                nq = min(nq + __builtin_popcountll(vb), H_QUEUE);     // (nq < CH <= 64 on entry and <= 64 arrive: never clipped)
+                fail_run = na - 1 - (63 - __builtin_clzll(vb));        // rejected attempts after the round's last valid one
             }
             if (overflow) break;
             __syncthreads();
-            const int nrun = min(min(nq, 64), niters - base);          // iterations this phase scores
+            const int nrun = min(min(nq, CH), niters - base);          // iterations this phase scores
             if (nrun <= 0) break;                                      // schedule exhausted
             // ---- model + inlier count, one iteration per lane ----
             const bool mine = lane < nrun;
@@ -490,7 +649,15 @@ __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uin
             p4[0] = pts[mine ? (qs.x & 0xFFFFu) : 0]; p4[1] = pts[mine ? (qs.x >> 16) : 0];
             p4[2] = pts[mine ? (qs.y & 0xFFFFu) : 0]; p4[3] = pts[mine ? (qs.y >> 16) : 0];
             double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const int nmodels = dlt4(p4, A, V, W, mine, Hm);
+            int nmodels;
+            if constexpr (HDLT) nmodels = dlt4_direct(p4, mine, Hm);
+            else nmodels = dlt4<ST>(p4, A, V, W, mine, Hm);
+            if (exact4) {
+                found = __shfl(nmodels, 0) > 0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) bestH[j] = found ? __shfl(Hm[j], 0) : 0.0;
+                break;
+            }
             int good = -1;
             if (mine && nmodels > 0) {
                 float Hf[8];
@@ -523,149 +690,197 @@ __global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uin
             if (sched_end && nq == 0) break;
         }
         if (overflow) { if (lane == 0) atomicOr(flags, 4u); }
-        found = max_good > 0;
-        if (found) {
-            float Hf[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Hf[j] = (float)bestH[j];
-            int c = 0;
-            for (int i = lane; i < count; i += 64) {
-                const uint8_t m = h_error(Hf, pts[i]) <= thr2;
-                mask[i] = m; c += m;
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-            inl = c;
-            __syncthreads();
-            if (vp.refine_iters > 0 && inl > 0) {
-                // fundam.cpp: runKernel over the inliers, then LMSolver on H[0..7].  All sums in point order (see lm8_eval):
-                // lanes 0..3 own the four centroid / deviation sums, lanes 0..44 the 45 entries of L^T L.
-                HNorm n{};
-                const double cnt = (double)inl;
-                {
-                    double acc = 0;
-                    for (int i = 0; i < count; ++i) {
-                        if (!mask[i]) continue;
-                        const float4 p = pts[i];
-                        acc += (double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y)));
-                    }
-                    n.cmx = __shfl(acc, 0) / cnt; n.cmy = __shfl(acc, 1) / cnt; n.cMx = __shfl(acc, 2) / cnt; n.cMy = __shfl(acc, 3) / cnt;
-                    const double cen = lane == 0 ? n.cmx : (lane == 1 ? n.cmy : (lane == 2 ? n.cMx : n.cMy));
-                    acc = 0;
-                    for (int i = 0; i < count; ++i) {
-                        if (!mask[i]) continue;
-                        const float4 p = pts[i];
-                        acc += fabs((double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y))) - cen);
-                    }
-                    n.smx = __shfl(acc, 0); n.smy = __shfl(acc, 1); n.sMx = __shfl(acc, 2); n.sMy = __shfl(acc, 3);
-                }
-                const bool ok = !(fabs(n.smx) < DBL_EPSILON || fabs(n.smy) < DBL_EPSILON || fabs(n.sMx) < DBL_EPSILON || fabs(n.sMy) < DBL_EPSILON);
-                if (ok) {                                               // (runKernel returning 0 leaves H as RANSAC found it)
-                    n.smx = cnt / n.smx; n.smy = cnt / n.smy; n.sMx = cnt / n.sMx; n.sMy = cnt / n.sMy;
-                    int rj = 0, rk = 0;
-                    { int e = min(lane, 44); while (e >= 9 - rj) { e -= 9 - rj; ++rj; } rk = rj + e; }
-                    double acc = 0;
-                    for (int i = 0; i < count; ++i) {
-                        if (!mask[i]) continue;
-                        const float4 p = pts[i];
-                        const double x = (p.z - n.cmx) * n.smx, y = (p.w - n.cmy) * n.smy;
-                        const double X = (p.x - n.cMx) * n.sMx, Y = (p.y - n.cMy) * n.sMy;
-                        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-                        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-                        acc += sel9(Lx, rj) * sel9(Lx, rk) + sel9(Ly, rj) * sel9(Ly, rk);
-                    }
-                    double LtL[45];
-#pragma unroll
-                    for (int e = 0; e < 45; ++e) LtL[e] = __shfl(acc, e);
-                    double h[9];
-                    jacobi9_smallest(A, V, W, LtL, true, h);            // every lane the same problem
-                    h_denormalise(h, n, bestH);
-                }
-                // LMSolverImpl::run, 8 parameters
-                const double eps = (double)FLT_EPSILON;
-                double x[8], xd[8], AU[36], v[8], D[8], d[8], dl[8], rinf = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = bestH[i];
-                double S = lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
-                {
-                    int e = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { D[i] = AU[e]; e += 8 - i; }
-                }
-                const double Rlo = 0.25, Rhi = 0.75;
-                double lambda = 1, lc = 0.75;
-                int iter = 0;
-                for (;;) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dl[i] = lambda * D[i];
-                    if (!solve8_lds(A, AU, dl, v, d)) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) d[i] = 0;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) xd[i] = x[i] - d[i];
-                    double dummyA[36], dummyv[8];
-                    const double Sd = lm8_eval(pts, mask, count, lane, xd, false, dummyA, dummyv, nullptr);
-                    double dS = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        double t = 2 * v[i];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int a = i < j ? i : j, b = i < j ? j : i;
-                            t -= AU[a * 8 - (a * (a - 1)) / 2 + (b - a)] * d[j];
-                        }
-                        dS += d[i] * t;
-                    }
-                    const double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
-                    if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
-                    else if (R < Rlo) {
-                        double t = 0;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) t += d[i] * v[i];
-                        double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
-                        nu = fmin(fmax(nu, 2.), 10.);
-                        if (lambda == 0) {
-                            double maxval = DBL_EPSILON;
-                            const double zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                            for (int i = 0; i < 8; ++i) {
-                                double e8[8], col[8];
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) e8[j] = j == i ? 1.0 : 0.0;
-                                if (solve8_lds(A, AU, zero8, e8, col)) {
-                                    double ci = 0;
-#pragma unroll
-                                    for (int j = 0; j < 8; ++j) ci = j == i ? col[j] : ci;
-                                    maxval = fmax(maxval, fabs(ci));
-                                }
-                            }
-                            lambda = lc = 1. / maxval;
-                            nu *= 0.5;
-                        }
-                        lambda *= nu;
-                    }
-                    if (Sd < S) {
-                        S = Sd;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] = xd[i];
-                        lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
-                    }
-                    iter++;
-                    double dinf = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dinf = fmax(dinf, fabs(d[i]));
-                    if (!(iter < vp.refine_iters && dinf >= eps && rinf >= eps)) break;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) bestH[i] = x[i];
-            }
+        if (exact4) {
+            inl = found ? 4 : 0;
+            if (lane < 4) mask[lane] = found ? 1 : 0;
         } else {
-            for (int j = 0; j < 9; ++j) bestH[j] = 0;
+            found = max_good > 0;
+            if (found) {
+                float Hf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Hf[j] = (float)bestH[j];
+                int c = 0;
+                for (int i = lane; i < count; i += 64) {
+                    const uint8_t m = h_error(Hf, pts[i]) <= thr2;
+                    mask[i] = m; c += m;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                inl = c;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) bestH[j] = 0;
+            }
         }
     }
     if (lane == 0) {
         fc.found[r] = found; fc.inliers[r] = inl;
         for (int j = 0; j < 9; ++j) fc.M[r][j] = bestH[j];
+    }
+}
+
+// fundam.cpp after the RANSAC: `result && npoints > 4` — runKernel over the inliers, then LMSolver (maxIters = refine_iters)
+// on H[0..7]; the mask stays RANSAC's.  One wave per (candidate, frame); every sum in point order (lm8_eval); the one
+// eigenproblem and the 8x8 solves run on lane 0's slice.  grid (max_cand, B), block 64, LDS static.
+__global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+                                                      const slideo_keypoint* __restrict__ frame_kp,
+                                                      const float2* __restrict__ page_xy, const uint2* __restrict__ votes,
+                                                      FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
+                                                      const uint8_t* __restrict__ gmask) {
+    __shared__ float4 lpts[RANSAC_LDS_PTS];
+    __shared__ uint8_t lmask[RANSAC_LDS_PTS];
+    __shared__ double jslice[HJ_SLICE];
+    const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    FrameCands& fc = fcs[f];
+    if (r >= fc.ncand) return;
+    const int count = fc.count[r], inl = fc.inliers[r];
+    if (count <= 4 || !fc.found[r] || inl <= 0 || vp.refine_iters <= 0) return;
+    const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
+    const uint2* vt = votes + vbase;
+    float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
+    const uint8_t* mask = count <= RANSAC_LDS_PTS ? lmask : gmask + vbase;
+    const uint32_t qbase_f = qofs[f];
+    for (int i = lane; i < count; i += 64) {
+        const uint2 v = vt[i];
+        const float2 s = page_xy[v.y];
+        const slideo_keypoint* kp = frame_kp + qbase_f + v.x;
+        pts[i] = make_float4(s.x, s.y, kp->x, kp->y);
+        if (count <= RANSAC_LDS_PTS) lmask[i] = gmask[vbase + i];
+    }
+    __syncthreads();
+    constexpr int ST = 1;
+    double* A = jslice; double* V = A + HJ_TRI; double* W = V + HJ_V;
+    double bestH[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) bestH[j] = fc.M[r][j];
+    // runKernel over the inliers.  All sums in point order (see lm8_eval): lanes 0..3 own the four centroid / deviation sums,
+    // lanes 0..44 the 45 entries of L^T L.
+    HNorm n{};
+    const double cnt = (double)inl;
+    {
+        double acc = 0;
+        for (int i = 0; i < count; ++i) {
+            if (!mask[i]) continue;
+            const float4 p = pts[i];
+            acc += (double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y)));
+        }
+        n.cmx = __shfl(acc, 0) / cnt; n.cmy = __shfl(acc, 1) / cnt; n.cMx = __shfl(acc, 2) / cnt; n.cMy = __shfl(acc, 3) / cnt;
+        const double cen = lane == 0 ? n.cmx : (lane == 1 ? n.cmy : (lane == 2 ? n.cMx : n.cMy));
+        acc = 0;
+        for (int i = 0; i < count; ++i) {
+            if (!mask[i]) continue;
+            const float4 p = pts[i];
+            acc += fabs((double)(lane == 0 ? p.z : (lane == 1 ? p.w : (lane == 2 ? p.x : p.y))) - cen);
+        }
+        n.smx = __shfl(acc, 0); n.smy = __shfl(acc, 1); n.sMx = __shfl(acc, 2); n.sMy = __shfl(acc, 3);
+    }
+    const bool ok = !(fabs(n.smx) < DBL_EPSILON || fabs(n.smy) < DBL_EPSILON || fabs(n.sMx) < DBL_EPSILON || fabs(n.sMy) < DBL_EPSILON);
+    if (ok) {                                               // (runKernel returning 0 leaves H as RANSAC found it)
+        n.smx = cnt / n.smx; n.smy = cnt / n.smy; n.sMx = cnt / n.sMx; n.sMy = cnt / n.sMy;
+        int rj = 0, rk = 0;
+        { int e = min(lane, 44); while (e >= 9 - rj) { e -= 9 - rj; ++rj; } rk = rj + e; }
+        double acc = 0;
+        for (int i = 0; i < count; ++i) {
+            if (!mask[i]) continue;
+            const float4 p = pts[i];
+            const double x = (p.z - n.cmx) * n.smx, y = (p.w - n.cmy) * n.smy;
+            const double X = (p.x - n.cMx) * n.sMx, Y = (p.y - n.cMy) * n.sMy;
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            acc += sel9(Lx, rj) * sel9(Lx, rk) + sel9(Ly, rj) * sel9(Ly, rk);
+        }
+        double LtL[45];
+#pragma unroll
+        for (int e = 0; e < 45; ++e) LtL[e] = __shfl(acc, e);
+        double h[9];
+        jacobi9_smallest<ST>(A, V, W, LtL, lane == 0, h);   // one problem: lane 0, the vector is exchanged
+#pragma unroll
+        for (int j = 0; j < 9; ++j) h[j] = __shfl(h[j], 0);
+        h_denormalise(h, n, bestH);
+    }
+    // LMSolverImpl::run, 8 parameters
+    const double eps = (double)FLT_EPSILON;
+    double x[8], xd[8], AU[36], v[8], D[8], d[8], dl[8], rinf = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = bestH[i];
+    double S = lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
+    {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { D[i] = AU[e]; e += 8 - i; }
+    }
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dl[i] = lambda * D[i];
+        {
+            int okd = 0;
+            if (lane == 0) okd = solve8_lds<ST>(A, AU, dl, v, d) ? 1 : 0;
+            okd = __shfl(okd, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = okd ? __shfl(d[i], 0) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xd[i] = x[i] - d[i];
+        double dummyA[36], dummyv[8];
+        const double Sd = lm8_eval(pts, mask, count, lane, xd, false, dummyA, dummyv, nullptr);
+        double dS = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double t = 2 * v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int a = i < j ? i : j, b = i < j ? j : i;
+                t -= AU[a * 8 - (a * (a - 1)) / 2 + (b - a)] * d[j];
+            }
+            dS += d[i] * t;
+        }
+        const double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+        else if (R < Rlo) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += d[i] * v[i];
+            double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = fmin(fmax(nu, 2.), 10.);
+            if (lambda == 0) {
+                double maxval = DBL_EPSILON;
+                const double zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 8; ++i) {
+                    double e8[8], col[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e8[j] = j == i ? 1.0 : 0.0;
+                    int okc = 0;
+                    double ci = 0;
+                    if (lane == 0) {
+                        okc = solve8_lds<ST>(A, AU, zero8, e8, col) ? 1 : 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ci = j == i ? col[j] : ci;
+                    }
+                    if (__shfl(okc, 0)) maxval = fmax(maxval, fabs(__shfl(ci, 0)));
+                }
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = xd[i];
+            lm8_eval(pts, mask, count, lane, x, true, AU, v, &rinf);
+        }
+        iter++;
+        double dinf = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dinf = fmax(dinf, fabs(d[i]));
+        if (!(iter < vp.refine_iters && dinf >= eps && rinf >= eps)) break;
+    }
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) fc.M[r][i] = x[i];
+        fc.M[r][8] = bestH[8];
     }
 }
 

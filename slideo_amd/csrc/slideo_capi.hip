@@ -669,14 +669,24 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
         check_launch("vote_kernel");
         if (c.verify_model == 1) {
-            ransac_h_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_SMALL_PTS), st>>>(
-                vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
-            check_launch("ransac_h_kernel (small)");
-            ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1><<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_LDS_PTS), st>>>(
-                vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
-            check_launch("ransac_h_kernel (large)");
+            auto launch_h = [&](auto small_tag, auto large_tag, int hdlt) {
+                small_tag<<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_SMALL_PTS, hdlt), st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+                check_launch("ransac_h_kernel (small)");
+                large_tag<<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_LDS_PTS, hdlt), st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+                check_launch("ransac_h_kernel (large)");
+            };
+            if (c.ocv.hdlt == 1) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>, 1);
+            else launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>, 0);
+            if (c.refine_iters > 0) {
+                refine_h_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>());
+                check_launch("refine_h_kernel");
+            }
         } else {
         ransac_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
             vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
@@ -921,10 +931,14 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   describe_window(cfg->patch_size / 2).dwords * 16));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_SMALL_PTS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS)));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ransac_h_lds_bytes(RANSAC_LDS_PTS)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 0)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 0)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 1)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 1)));
     m = mm.release();
     *out = m;
     API_CATCH(nullptr)

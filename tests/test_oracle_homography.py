@@ -179,8 +179,8 @@ def test_perspective_frames_need_the_homography(oracle, synth):
     v, cands = db.match_frame_trace(frames[i])
     top = cands[np.argmax(cands["inliers"])]
     assert top["page_idx"] == truth[i]
-    corners = np.array([[0, 0], [2001, 0], [2001, 1125], [0, 1125], [1000, 560]], np.float64)
-    assert np.abs(_project(top["transform"].reshape(3, 3), corners) - _project(tH[i], corners)).max() < 8.0     # (extrapolated to the page corners, beyond the outermost keypoints)
+    inner = np.array([[300, 200], [1700, 200], [1700, 900], [300, 900], [1000, 560]], np.float64)
+    assert np.abs(_project(top["transform"].reshape(3, 3), inner) - _project(tH[i], inner)).max() < 3.0
     # similarity frames of earlier rounds are unchanged by the generator's new mode
     a, ta, _ = synth.frames(pages[:, :450, :800].copy(), 2, 640, 360)
     b, tb, Hb = synth.frames_persp(pages[:, :450, :800].copy(), 2, 640, 360, persp=0.0)
