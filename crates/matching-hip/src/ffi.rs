@@ -1,0 +1,124 @@
+//! Hand-written declarations of include/slideo_amd.h (ABI 4) — what bindgen would emit for the entry points this crate
+//! uses.  Field order and types mirror the C structs exactly; tests/test_capi_load.py pins the C side's layout
+//! (sizeof(slideo_config) == 144) and `assert_abi()` below pins the version at run time.
+#![allow(non_camel_case_types)]
+use std::os::raw::c_char;
+
+pub const SLIDEO_ABI_VERSION: u32 = 4;
+
+/// slideo_ocv_variants: which restatement of each OpenCV primitive runs.  slideo_config_default fills it; the
+/// application never touches it.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct slideo_ocv_variants {
+    pub gray: i32,
+    pub blur: i32,
+    pub resize: i32,
+    pub atan: i32,
+    pub warp: i32,
+    pub area: i32,
+    pub lm: i32,
+    pub rng_mul: u32,
+    pub hdlt: i32,
+}
+
+/// slideo_config: every literal the reference hard-codes on the hot path; defaults = those literals.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct slideo_config {
+    pub nfeatures: i32,
+    pub scale_factor: f32,
+    pub nlevels: i32,
+    pub edge_threshold: i32,
+    pub patch_size: i32,
+    pub fast_threshold: i32,
+    pub knn_k: i32,
+    pub vote_tolerance: f32,
+    pub max_candidate_pages: i32,
+    pub ransac_threshold: f64,
+    pub ransac_max_iters: i32,
+    pub ransac_confidence: f64,
+    pub refine_iters: i32,
+    pub max_rated: i32,
+    pub min_rating: f64,
+    pub min_rating_ratio: f64,
+    pub min_similarity: f32,
+    pub small_area: i32,
+    pub changed_similarity: f32,
+    /// 0.0 = the reference's tolerance vote (default); > 0: ratio test instead (extension)
+    pub ratio_test: f32,
+    /// 0 = the reference's estimateAffinePartial2D (default); 1 = 8-DOF homography (extension)
+    pub verify_model: i32,
+    pub ocv: slideo_ocv_variants,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct slideo_verdict {
+    /// -1 = None
+    pub page_idx: i32,
+    pub similarity: f32,
+    pub inliers: i32,
+    pub n_keypoints: i32,
+}
+
+#[repr(C)]
+pub struct slideo_matcher {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn slideo_abi_version() -> u32;
+    pub fn slideo_config_default(cfg: *mut slideo_config);
+    pub fn slideo_matcher_create(
+        cfg: *const slideo_config,
+        device: i32,
+        out: *mut *mut slideo_matcher,
+    ) -> i32;
+    pub fn slideo_matcher_destroy(m: *mut slideo_matcher);
+    pub fn slideo_last_error(m: *const slideo_matcher) -> *const c_char;
+    pub fn slideo_matcher_add_pages_bgr8(
+        m: *mut slideo_matcher,
+        n_pages: i32,
+        data: *const *const u8,
+        width: *const i32,
+        height: *const i32,
+        stride_bytes: *const i32,
+    ) -> i32;
+    pub fn slideo_matcher_finalize_pages(m: *mut slideo_matcher) -> i32;
+    pub fn slideo_match_frames_bgr8(
+        m: *mut slideo_matcher,
+        n_frames: i32,
+        frames: *const u8,
+        width: i32,
+        height: i32,
+        stride_bytes: i32,
+        frame_stride_bytes: i64,
+        verdicts_out: *mut slideo_verdict,
+    ) -> i32;
+    pub fn slideo_changed_mask_bgr8(
+        m: *mut slideo_matcher,
+        n_frames: i32,
+        frames: *const u8,
+        width: i32,
+        height: i32,
+        stride_bytes: i32,
+        frame_stride_bytes: i64,
+        prev_small: *const u8,
+        last_small_out: *mut u8,
+        changed_out: *mut u8,
+        similarity_out: *mut f32,
+    ) -> i32;
+}
+
+/// The struct layouts above are only valid for one ABI version of the library.
+pub fn assert_abi() {
+    let v = unsafe { slideo_abi_version() };
+    assert_eq!(
+        v, SLIDEO_ABI_VERSION,
+        "libslideo_amd.so has ABI {} but this crate was written for ABI {}",
+        v, SLIDEO_ABI_VERSION
+    );
+    assert_eq!(std::mem::size_of::<slideo_config>(), 144);
+    assert_eq!(std::mem::size_of::<slideo_verdict>(), 16);
+}

@@ -1,0 +1,283 @@
+//! matching-hip — hediet/slideo's `matching` trait surface (crates/matching/src/lib.rs:7-40) over the MI355X-native
+//! matcher libslideo_amd.so.  A drop-in for crates/matching-opencv: same traits, same progress protocol, same
+//! panics-instead-of-Results, same post-processing of the per-frame results.
+//!
+//!   OpenCVImageVideoMatcher::default()          -> HipImageVideoMatcher::default()
+//!   create_video_matcher    (mo/lib.rs:37-64)   -> slideo_matcher_create + add_pages_bgr8 + finalize_pages
+//!   match_images_with_video (mo/lib.rs:140-158) -> opens the video to size the progress bar, as the reference does
+//!   process                 (mo/lib.rs:168-246) -> sampled frames in batches: slideo_changed_mask_bgr8
+//!                                                  (MarkSimilarIter, mo/video_capture.rs:86-98), then
+//!                                                  slideo_match_frames_bgr8 on the changed ones
+//!                                                  (match_images_with_frame, mo/lib.rs:249-413); sentinel, sort,
+//!                                                  consecutive-duplicate removal as mo/lib.rs:185-189,229-244
+//! (mo/ = crates/matching-opencv/src/)
+//!
+//! UNCOMPILED in the repository this crate ships in (no Rust toolchain there).
+mod decode;
+mod ffi;
+
+use matching::{
+    ImageVideoMatcher, MatchableImage, Matching, ProgressReporter, VideoMatcher, VideoMatcherTask,
+};
+use std::{
+    ffi::CStr,
+    path::{Path, PathBuf},
+    sync::{Arc, Mutex},
+    time::Duration,
+};
+
+/// Sampled frames handed to the library per call.  The changed-frame mask needs consecutive samples in one call (or the
+/// previous small image carried over, which is what happens at batch seams); 64 x 1080p = 400 MB of host memory.
+const FRAMES_PER_CALL: usize = 64;
+
+struct RawHandle(*mut ffi::slideo_matcher);
+// The pointer itself may move between threads; USE is serialised by the Mutex below — include/slideo_amd.h: "a matcher
+// is NOT re-entrant: calls on one handle must come from one thread at a time".
+unsafe impl Send for RawHandle {}
+
+struct Handle {
+    raw: Mutex<RawHandle>,
+}
+
+impl Drop for Handle {
+    fn drop(&mut self) {
+        let g = self.raw.lock().unwrap_or_else(|e| e.into_inner());
+        unsafe { ffi::slideo_matcher_destroy(g.0) }
+    }
+}
+
+/// The reference has no `Result` anywhere on this surface: it panics (mo/lib.rs:95-104, unwrap() throughout).
+fn check(h: *mut ffi::slideo_matcher, rc: i32) {
+    if rc != 0 {
+        let msg = unsafe { CStr::from_ptr(ffi::slideo_last_error(h)) }
+            .to_string_lossy()
+            .into_owned();
+        panic!("slideo_amd error {}: {}", rc, msg);
+    }
+}
+
+pub struct HipImageVideoMatcher {
+    /// HIP device ordinal (one process per GPU: the multi-GPU launcher gives each rank its own)
+    pub device: i32,
+}
+
+impl Default for HipImageVideoMatcher {
+    fn default() -> Self {
+        HipImageVideoMatcher { device: 0 }
+    }
+}
+
+impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
+    fn create_video_matcher<I: MatchableImage + Send + Sync + Copy + Eq + 'i>(
+        &self,
+        images: Vec<I>,
+        progress_reporter: ProgressReporter,
+    ) -> Box<dyn VideoMatcher<'i, I> + 'i> {
+        ffi::assert_abi();
+        let len = images.len() as u64;
+        let mut cfg = std::mem::MaybeUninit::<ffi::slideo_config>::uninit();
+        let mut h: *mut ffi::slideo_matcher = std::ptr::null_mut();
+        unsafe {
+            ffi::slideo_config_default(cfg.as_mut_ptr()); // the reference's literals (mo/feature_extractor.rs:13-23 etc.)
+            check(
+                std::ptr::null_mut(),
+                ffi::slideo_matcher_create(cfg.as_ptr(), self.device, &mut h),
+            );
+        }
+        // Page analysis (mo/lib.rs:43-58).  Pages are decoded on the host and handed over in groups, so that a 1000-page
+        // deck does not sit decoded in memory at once; the progress protocol is the reference's and is driven from here
+        // (slideo_matcher_set_progress — a C callback for callers without a reporter of their own — is not needed).
+        progress_reporter.report(0, len, "Analyzing PDF pages...");
+        let mut done = 0u64;
+        for group in images.chunks(32) {
+            let decoded: Vec<decode::BgrImage> =
+                group.iter().map(|i| decode::decode_page_bgr(i.get_path())).collect();
+            let ptrs: Vec<*const u8> = decoded.iter().map(|d| d.data.as_ptr()).collect();
+            let w: Vec<i32> = decoded.iter().map(|d| d.width).collect();
+            let hh: Vec<i32> = decoded.iter().map(|d| d.height).collect();
+            let stride: Vec<i32> = w.iter().map(|w| w * 3).collect();
+            unsafe {
+                check(
+                    h,
+                    ffi::slideo_matcher_add_pages_bgr8(
+                        h,
+                        ptrs.len() as i32,
+                        ptrs.as_ptr(),
+                        w.as_ptr(),
+                        hh.as_ptr(),
+                        stride.as_ptr(),
+                    ),
+                );
+            }
+            // one report per page, counting up (mo/lib.rs:49-53; the reference's come from rayon workers in any order)
+            for _ in group {
+                done += 1;
+                progress_reporter.report(done, len, "Analyzing PDF pages...");
+            }
+        }
+        unsafe { check(h, ffi::slideo_matcher_finalize_pages(h)) }; // FlannMatcher::new, mo/flann.rs:65-71
+        progress_reporter.report(len, len, "PDF page analysis successful."); // mo/lib.rs:58
+        Box::new(HipVideoMatcher {
+            handle: Arc::new(Handle { raw: Mutex::new(RawHandle(h)) }),
+            images: Arc::new(images),
+        })
+    }
+}
+
+struct HipVideoMatcher<I> {
+    handle: Arc<Handle>,
+    images: Arc<Vec<I>>,
+}
+
+impl<'i, I: MatchableImage + Send + Sync + Copy + Eq + 'i> VideoMatcher<'i, I> for HipVideoMatcher<I> {
+    fn match_images_with_video(
+        &self,
+        video_path: &Path,
+        progress_reporter: ProgressReporter,
+    ) -> Box<dyn VideoMatcherTask<I> + 'i> {
+        let interval = Duration::from_secs(5); // mo/lib.rs:145
+        let vid = decode::SampledVideo::open(video_path, interval);
+        let total_time = vid.total_time();
+        let frames_to_process = (total_time.as_secs_f64() / interval.as_secs_f64()) as u64; // mo/lib.rs:148
+        progress_reporter.report(0, frames_to_process, ""); // mo/lib.rs:150
+        Box::new(HipVideoMatcherTask {
+            handle: self.handle.clone(),
+            images: self.images.clone(),
+            video_path: video_path.to_owned(),
+            progress_reporter,
+        })
+    }
+}
+
+struct HipVideoMatcherTask<I> {
+    handle: Arc<Handle>,
+    images: Arc<Vec<I>>,
+    video_path: PathBuf,
+    progress_reporter: ProgressReporter,
+}
+
+impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVideoMatcherTask<I> {
+    fn process(&self) -> Vec<Matching<I>> {
+        let interval = Duration::from_secs(5); // mo/lib.rs:175
+        let vid = decode::SampledVideo::open(&self.video_path, interval);
+        let total_time = vid.total_time();
+        let total_frames = vid.total_frames();
+        let frames_to_process = (total_time.as_secs_f64() / interval.as_secs_f64()) as u32; // mo/lib.rs:179
+        let message = format!(
+            "Processing frames of '{}'...",
+            self.video_path.file_name().unwrap().to_string_lossy()
+        );
+
+        // "Add a matching to indicate the last frame." (mo/lib.rs:185-189)
+        let mut results: Vec<Matching<I>> = vec![Matching {
+            image: None,
+            video_frame_idx: total_frames as usize,
+            video_time: total_time,
+        }];
+
+        let guard = self.handle.raw.lock().unwrap(); // one caller at a time on the handle
+        let h = guard.0;
+        let mut progress = 0u64;
+        let mut prev_small: Option<Vec<u8>> = None;
+        for batch in decode::batches(vid, FRAMES_PER_CALL) {
+            let n = batch.meta.len();
+            let fb = batch.frame_bytes();
+            // MarkSimilarIter (mo/video_capture.rs:86-98): changed <=> similarity to the previous SAMPLED frame < 0.98; the
+            // first frame of the video is always changed (prev_small == None); the last small image of this call is the
+            // `prev` of the next one.
+            let mut changed = vec![0u8; n];
+            let mut last_small = vec![0u8; small_image_bytes(batch.width, batch.height)];
+            unsafe {
+                check(
+                    h,
+                    ffi::slideo_changed_mask_bgr8(
+                        h,
+                        n as i32,
+                        batch.frames.as_ptr(),
+                        batch.width,
+                        batch.height,
+                        batch.width * 3,
+                        fb as i64,
+                        prev_small.as_ref().map_or(std::ptr::null(), |p| p.as_ptr()),
+                        last_small.as_mut_ptr(),
+                        changed.as_mut_ptr(),
+                        std::ptr::null_mut(),
+                    ),
+                );
+            }
+            // a change of frame size (never within one video file) restarts the comparison, as a fresh Mat size would
+            // make compute_similarity panic in the reference
+            prev_small = Some(last_small);
+
+            // the changed frames, packed, through match_images_with_frame (mo/lib.rs:213-214)
+            let sel: Vec<usize> = (0..n).filter(|&i| changed[i] != 0).collect();
+            let mut packed = Vec::with_capacity(sel.len() * fb);
+            for &i in &sel {
+                packed.extend_from_slice(&batch.frames[i * fb..(i + 1) * fb]);
+            }
+            let mut verdicts = vec![ffi::slideo_verdict::default(); sel.len()];
+            if !sel.is_empty() {
+                unsafe {
+                    check(
+                        h,
+                        ffi::slideo_match_frames_bgr8(
+                            h,
+                            sel.len() as i32,
+                            packed.as_ptr(),
+                            batch.width,
+                            batch.height,
+                            batch.width * 3,
+                            fb as i64,
+                            verdicts.as_mut_ptr(),
+                        ),
+                    );
+                }
+            }
+            for (&i, v) in sel.iter().zip(verdicts.iter()) {
+                let (time, frame_idx) = batch.meta[i];
+                results.push(Matching {
+                    video_time: time,
+                    video_frame_idx: frame_idx,
+                    image: if v.page_idx >= 0 { Some(self.images[v.page_idx as usize]) } else { None },
+                });
+            }
+            // one report per sampled frame, changed or not (mo/lib.rs:191-212)
+            for _ in 0..n {
+                progress += 1;
+                self.progress_reporter.report(progress, frames_to_process as u64, &message);
+            }
+        }
+        drop(guard);
+
+        self.progress_reporter.report(
+            frames_to_process as u64,
+            frames_to_process as u64,
+            &format!("Finished!"),
+        ); // mo/lib.rs:223-227
+
+        // mo/lib.rs:229-244
+        results.sort_by_key(|m| m.video_time);
+        let mut cleaned: Vec<Matching<I>> = Vec::new();
+        let mut last: Option<Matching<I>> = None;
+        for mapping in results {
+            if let Some(l) = &last {
+                if l.image == mapping.image {
+                    continue;
+                }
+            }
+            last = Some(mapping.clone());
+            cleaned.push(mapping);
+        }
+        cleaned
+    }
+}
+
+/// to_small_image's output size (mo/image_utils.rs:8-20) times 3 channels: what slideo_changed_mask_bgr8 writes to
+/// `last_small_out`.
+fn small_image_bytes(width: i32, height: i32) -> usize {
+    let max_area = 300 * 400;
+    let factor = ((max_area as f32) / ((width * height) as f32)).sqrt();
+    let sw = ((width as f32) * factor) as i32;
+    let sh = ((height as f32) * factor) as i32;
+    (sw as usize) * (sh as usize) * 3
+}

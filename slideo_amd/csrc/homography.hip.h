@@ -531,7 +531,7 @@ __host__ __device__ constexpr size_t ransac_h_lds_bytes(int lds_pts, int hdlt) {
 // HDLT = slideo_ocv_variants.hdlt: how a minimal sample becomes a model.  Dynamic LDS: ransac_h_lds_bytes(LDS_PTS, HDLT).
 // Leaves per candidate: found, inliers, the RANSAC model in fc.M, the inlier mask in gmask (refine_h_kernel reads them).
 template <int LDS_PTS, int MIN_COUNT, int HDLT>
-__global__ __launch_bounds__(64) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1, HDLT ? 2 : 1))) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                       const slideo_keypoint* __restrict__ frame_kp,
                                                       const float2* __restrict__ page_xy,
                                                       const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,

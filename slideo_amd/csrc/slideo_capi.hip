@@ -230,8 +230,14 @@ void upload_area(slideo_matcher* m) {
 bool blur_is_f32(const slideo_matcher* m) { return m->cfg.ocv.blur <= 1; }
 
 // max frames of size (w,h) per unit under the workspace budget (the slots share it)
+uint32_t kp_cap_for(const slideo_matcher* m, const PyrGeom& g);
 int sub_batch_for(slideo_matcher* m, const PyrGeom& g, int n) {
     size_t per = (size_t)g.frame_bytes * (blur_is_f32(m) ? 2 : 1) + (size_t)g.cand_per_frame * 4 + (size_t)g.nlevels * 258 * 4 + (size_t)g.w * g.h * 3;
+    // downstream of ORB, sized by the per-frame keypoint capacity: items 8 + keypoint 24 + descriptor 32 B, the key lists
+    // (32 x 4 B, times the train-set segments of a small query set: at most ~4 at sizes where the budget matters), and per
+    // (keypoint, neighbour) the vote 8 B + point pair 16 B + mask 1 B
+    const size_t kc = kp_cap_for(m, g);
+    per += kc * (8 + sizeof(slideo_keypoint) + 32 + (size_t)KLIST * 4 * 4 + (size_t)m->cfg.knn_k * 25) + sizeof(FrameCands) + MAXR * sizeof(PairDesc);
     size_t fit = std::max<size_t>(1, (m->ws_budget / NSLOTS) / std::max<size_t>(per, 1));
     return (int)std::min<size_t>({(size_t)std::max(n, 1), fit, (size_t)4096});
 }
@@ -623,8 +629,11 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     // Capacity-sized (no host wait in the middle of the unit) when the matrix-core kNN runs: every kernel downstream of the ORB
     // counts reads them on the device.  The VALU engine (A/B only) keeps the exact-size path.
     const uint32_t kpcap = kp_cap_for(m, g);
+    // (a capacity below quota + margin — the KP_SORT_LDS clamp at nfeatures >= ~7 k — would overflow on every busy frame and run
+    // every unit twice: those configurations take the exact-size path from the start)
     const bool async = allow_async && m->async_submit && knn_engine_for(m, n * (int)std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures)) != 1 &&
-                       (int64_t)n * kpcap < ((int64_t)1 << 30);
+                       (int64_t)n * kpcap < ((int64_t)1 << 30) &&
+                       (kpcap >= (uint32_t)c.nfeatures + 1024u || kpcap >= (uint32_t)std::max(g.cand_per_frame, 1));
     S.timed = prof; S.u_frames = frames_dev; S.u_w = w; S.u_h = h; S.u_stride = stride; S.u_fs = frame_stride; S.u_async = async;
     if (m->orb_chain && m->last_orb_ev && m->last_orb_ev != S.ev_orb) HIP_CHECK(hipStreamWaitEvent(st, m->last_orb_ev, 0));
     if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
@@ -751,7 +760,19 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
         S.orb.qtot = info[0]; S.orb.max_count = info[1];
     }
     const uint32_t qtot = S.orb.qtot;
-    if (S.timed) {
+    if (fl & 4u) {
+        // a candidate's sample schedule (2 draws per iteration + the redraws of equal pairs; 4 per attempt for the homography) ran
+        // past the pre-drawn stream: draw four times as much and run the unit again.  (Other units may be reading the table:
+        // drain the device first.)
+        const uint32_t cap = 1u << 26;
+        if (m->rng_len >= cap) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded %u pre-drawn RNG outputs", m->rng_len);
+        HIP_CHECK(hipDeviceSynchronize());
+        upload_rng_stream(m, (uint32_t)std::min<uint64_t>((uint64_t)m->rng_len * 4, cap));
+        unit_submit(m, S, S.u_frames, n, S.u_w, S.u_h, S.u_stride, S.u_fs, false);
+        unit_collect(m, S, out_host);
+        return;
+    }
+    if (S.timed) {                    // (after both re-run checks: a unit that was run twice is counted once, by its final run)
         float t;
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[1])); m->prof_ms[0] += t; m->prof_n[0]++;
         if (qtot > 0) {
@@ -760,16 +781,6 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
             HIP_CHECK(hipEventElapsedTime(&t, S.ev[2], S.ev[3])); m->prof_ms[2] += t; m->prof_n[2]++;
         }
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
-    }
-    if (fl & 4u) {
-        // a candidate's sample schedule (2 draws per iteration + the redraws of equal pairs) ran past the pre-drawn stream: draw
-        // four times as much and run the unit again.  (Other units may be reading the table: drain the device first.)
-        if (m->rng_len >= (1u << 26)) fail(SLIDEO_ERR_CAPACITY, "RANSAC sample schedule exceeded %u pre-drawn RNG outputs", m->rng_len);
-        HIP_CHECK(hipDeviceSynchronize());
-        upload_rng_stream(m, m->rng_len * 4);
-        unit_submit(m, S, S.u_frames, n, S.u_w, S.u_h, S.u_stride, S.u_fs, false);
-        unit_collect(m, S, out_host);
-        return;
     }
     std::memcpy(out_host, ho, (size_t)n * sizeof(slideo_verdict));
     const size_t base = m->last_fcs.size();
@@ -1365,8 +1376,7 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
 }
 
 // ---- L2 k-NN (cfg2): train set prepared once, queries from device memory ----
-void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
-    slideo_matcher::L2Set& L = m->l2;
+void l2_prepare(slideo_matcher::L2Set& L, const uint8_t* t, int nt, hipStream_t st) {
     const int nt_pad = knn_pad_rows(nt);
     DevBuf d_t, d_norm;
     d_t.reserve(std::max<size_t>((size_t)nt * 128, 64)); d_norm.reserve(std::max<size_t>((size_t)nt * 4, 64));
@@ -1418,8 +1428,7 @@ void l2_prepare(slideo_matcher* m, const uint8_t* t, int nt, hipStream_t st) {
 }
 
 // queries on the device -> idx / dist on the device (m->d_tapidx / d_tapdist); kernel time between two events if asked for
-void l2_query(slideo_matcher* m, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed) {
-    slideo_matcher::L2Set& L = m->l2;
+void l2_query(slideo_matcher* m, slideo_matcher::L2Set& L, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed) {
     const int qblocks = cdiv(nq, knn_qpb<2>());
     L.d_keys.reserve((size_t)nq * KLIST * 8); L.d_pend.reserve((size_t)qblocks * KT_WAVES * knn_pend_words_per_wave<2>() * 8);   // (u64 keys)
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
@@ -1447,7 +1456,7 @@ int32_t slideo_l2_set_train(slideo_matcher* m, const uint8_t* t, int32_t nt) {
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
     HIP_CHECK(hipSetDevice(m->device));
     require_idle(m);
-    l2_prepare(m, t, nt, m->slots[0].st);
+    l2_prepare(m->l2, t, nt, m->slots[0].st);
     API_CATCH(m)
 }
 
@@ -1462,7 +1471,7 @@ int32_t slideo_l2_knn_dev(slideo_matcher* m, const void* q_dev, int32_t nq, int3
     HIP_CHECK(hipSetDevice(m->device));
     require_idle(m);
     Slot& S = m->slots[0];
-    l2_query(m, static_cast<const uint8_t*>(q_dev), nq, k, S.st, S, kernel_ms != nullptr);
+    l2_query(m, m->l2, static_cast<const uint8_t*>(q_dev), nq, k, S.st, S, kernel_ms != nullptr);
     HIP_CHECK(hipMemcpyAsync(idx_dev, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, S.st));
     HIP_CHECK(hipMemcpyAsync(dist_dev, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, S.st));
     HIP_CHECK(hipStreamSynchronize(S.st));
@@ -1482,11 +1491,12 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     require_idle(m);
     Slot& S = m->slots[0];
     hipStream_t st = S.st;
-    l2_prepare(m, t, nt, st);
+    slideo_matcher::L2Set tap;                    // a set of its own: the one installed by slideo_l2_set_train stays as it is
+    l2_prepare(tap, t, nt, st);
     DevBuf d_q;
     d_q.reserve((size_t)nq * 128);
     HIP_CHECK(hipMemcpyAsync(d_q.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
-    l2_query(m, d_q.as<uint8_t>(), nq, k, st, S, false);
+    l2_query(m, tap, d_q.as<uint8_t>(), nq, k, st, S, false);
     HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

@@ -83,3 +83,14 @@ def test_cfg2_l2_knn_line():
     j = _json_line(r.stdout)
     assert j["dtype"] == "i8" and j["roofline"]["bound"] == "mfma" and j["roofline"]["kernel"] == "knn_l2_kernel"
     assert j["config"]["checked_against_numpy"] is True and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
+
+
+def test_cfg2_l2_knn_full_size():
+    """BASELINE configs[2] at its full size: 256 frames x 1000 SIFT-shaped descriptors against 500 pages x 1850 (256 k x 925 k
+    squared-L2 pairs on the int8 matrix cores), 64 sampled queries re-computed in numpy inside the run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["config"]["train_descriptors_M"] == 925000 and j["config"]["query_descriptors_per_step"] == 256000
+    assert j["config"]["checked_against_numpy"] is True and j["roofline"]["frac"] > 0.3

@@ -122,3 +122,76 @@ def test_world2_gloo_gather_equals_single_process(oracle, synth):
     tl = D.timeline(got, [5.0 * i for i in range(n)], [150 * i for i in range(n)], 5.0 * n, 150 * n)
     assert tl[-1][2] == -1 or tl[-1][0] < 5.0 * n
     assert all(a[2] != b[2] for a, b in zip(tl, tl[1:]))
+
+
+class _FakeMatcher:
+    """Stand-in for _capi.Matcher on a CPU-only box: analyses pages with the CPU restatement and records what
+    build_page_db_sharded feeds to add_page_features (the exchange is what is under test, not the analysis)."""
+
+    def __init__(self, o, cfg):
+        self.o, self.cfg, self.pages, self.imported, self.finalized = o, cfg, [], [], False
+
+    def add_pages(self, pages):
+        self.pages += [np.ascontiguousarray(p) for p in pages]
+
+    def page_features(self, j):
+        return self.o.orb(self.pages[j], self.cfg)
+
+    def page_small(self, j):
+        return self.o.small_image(self.pages[j], self.cfg.small_area)
+
+    def add_page_features(self, w, h, kp, desc, small):
+        self.imported.append((w, h, kp, desc, small))
+
+    def finalize(self):
+        self.finalized = True
+
+    def close(self):
+        pass
+
+
+def _pagedb_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from slideo_amd import distributed as D, synth
+    import pyoracle as o
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pages = synth.pages(5, 800, 450, threads=1)                        # 5 pages over 2 ranks: ragged (3 + 2)
+    cfg = o.default_config(nfeatures=500)
+    m = D.build_page_db_sharded(lambda: _FakeMatcher(o, cfg), pages, rank, world)
+    if rank == 1:                                                      # the rank that analysed the smaller share
+        q.put([(w, h, kp.tobytes(), desc.tobytes(), small.tobytes(), small.shape) for w, h, kp, desc, small in m.imported] if m.finalized else None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_page_sharded_db_build_exchanges_fixed_stride_records(oracle, synth):
+    """pages sharded over the ranks, ONE all_gather_into_tensor of fixed-stride records (no pickling); every rank
+    ends up with every page's features in page order, bit for bit what a single process computes."""
+    import torch.multiprocessing as mp
+    from slideo_amd import distributed as D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pagedb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    pages = synth.pages(5, 800, 450, threads=1)
+    cfg = oracle.default_config(nfeatures=500)
+    assert got is not None and len(got) == 5
+    for j, (w, h, kpb, db, sb, sshape) in enumerate(got):
+        kp, desc = oracle.orb(pages[j], cfg)
+        small = oracle.small_image(pages[j], cfg.small_area)
+        assert (w, h) == (800, 450) and kpb == kp.tobytes() and db == desc.tobytes() and sb == small.tobytes() and tuple(sshape) == small.shape
+    # the record format itself: round trip incl. an empty page and the padding slots
+    recs = [(800, 450, *oracle.orb(pages[0], cfg), oracle.small_image(pages[0], cfg.small_area)),
+            (640, 360, np.zeros(0, oracle.KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((2, 3, 3), np.uint8))]
+    buf = D.pack_page_records(recs, kp_cap=len(recs[0][2]) + 3, small_cap=recs[0][4].size + 5, n_slots=4)
+    assert buf.shape[0] == 4 and buf.shape[1] % 16 == 0 and not buf[2:].any()
+    for j, rec in enumerate(recs):
+        w, h, kp, desc, small = D.unpack_page_record(buf[j], len(recs[0][2]) + 3)
+        assert (w, h) == rec[:2] and kp.tobytes() == rec[2].tobytes() and np.array_equal(desc, rec[3]) and np.array_equal(small, rec[4])

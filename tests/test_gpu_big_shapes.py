@@ -80,16 +80,19 @@ def test_headline_shape_traces_vs_oracle(capi, oracle, synth, deck500):
         gk, gd = m.page_features(p)
         ok, od = db.page_features(p)
         assert np.array_equal(gd, od) and np.array_equal(gk["x"], ok["x"]) and np.array_equal(gk["angle"], ok["angle"])
-    idx = _sample(truth, 10)
-    otr = _oracle_traces(db, frames, idx)
+    # the decision trace of EVERY one of the 256 frames against the oracle for the default engine / list mode (the AVX-512 CPU
+    # leg does ~4 frames/s per core), a spread sample of 10 for the other three combinations — which must also return identical
+    # decisions on all 256 frames
+    idx_all, idx_some = list(range(B)), _sample(truth, 10)
+    otr = _oracle_traces(db, frames, idx_all)
     d_frames = torch.from_numpy(frames).cuda()
     ref_v = ref_c = None
-    for engine in ("mfma4", "mfma2"):
+    for engine in ("mfma2", "mfma4"):
         for exact in (False, True):
             m.set_knn_engine(engine)
             m.set_knn_exact_lists(exact)
             v, cands = _one_unit(m, d_frames, B, fw, fh)
-            for i in idx:
+            for i in (idx_all if ref_v is None else idx_some):
                 _compare_trace(v[i], cands[i], otr[i][0], otr[i][1], "engine %s exact_lists %s frame %d" % (engine, exact, i))
             if ref_v is None:
                 ref_v, ref_c = v, cands
@@ -130,25 +133,68 @@ def test_configs1_exact_shape(capi, oracle, synth):
 
 
 def test_configs4_shape_4k_orb2000_end_to_end(capi, oracle, synth):
-    """BASELINE configs[4] shape: 3840x2160 frames, ORB-2000 = the reference's literals throughout, multi-scale pyramid,
-    RANSAC verification, verdicts; 100 pages.  Every frame's decision trace against the oracle."""
-    P, B, fw, fh = 100, 6, 3840, 2160
+    """BASELINE configs[4] shape at its deck size: 3840x2160 frames, ORB-2000 = the reference's literals throughout, multi-scale
+    pyramid, RANSAC verification, verdicts; 1000 pages (1.8 M train descriptors), 16 frames.  Every frame's decision trace
+    against the oracle, and every miss against the synthetic truth explained: the accuracy at this shape (0.875 in bench.py)
+    is the reference's absolute acceptance rule `rating > 50` (mo/lib.rs:333) — the true page IS the best-rated candidate, with
+    at most 50 inliers — which the oracle applies identically."""
+    P, B, fw, fh = 1000, 16, 3840, 2160
     pages = synth.pages(P, threads=min(64, NCPU))
     frames, truth, _ = synth.frames(pages, B, fw, fh, first=40, threads=min(64, NCPU))
     db = oracle.PageDB(oracle.default_config())
     db.add_pages(pages, threads=NCPU)
     assert db.finalize() == 0
     m = capi.Matcher(capi.default_config())
-    m.add_pages(list(pages[:50])); m.add_pages(list(pages[50:]))
+    for i in range(0, P, 50):
+        m.add_pages(list(pages[i:i + 50]))
     m.finalize()
-    assert m.descriptor_count == db.descriptor_count > 150000
+    assert m.descriptor_count == db.descriptor_count > 1500000
     otr = _oracle_traces(db, frames, list(range(B)))
     v = m.match_frames(frames)
+    misses = 0
     for i in range(B):
-        _compare_trace(v[i], m.last_candidates(i), otr[i][0], otr[i][1], "frame %d" % i)
-    assert (v["page_idx"] == truth).sum() >= B - 2
+        c = m.last_candidates(i)
+        _compare_trace(v[i], c, otr[i][0], otr[i][1], "frame %d" % i)
+        if v["page_idx"][i] != truth[i]:
+            misses += 1
+            assert otr[i][0]["page_idx"] == v["page_idx"][i]                      # the oracle misses the same frame the same way
+            if truth[i] >= 0 and v["page_idx"][i] == -1:
+                best = c[np.argmax(c["inliers"])]
+                # (consecutive synthetic pages may share a template, SURVEY 8d: the best-rated page is the true one or its sibling)
+                assert abs(int(best["page_idx"]) - int(truth[i])) <= 2 and best["inliers"] <= 50, "a miss that is not the rating > 50 rule"
+    assert misses <= B // 4
     assert v["n_keypoints"].min() > 1500
     m.close()
+
+
+def test_configs4_shape_homography_verification(capi, oracle, synth):
+    """configs[4] as BASELINE words it ("RANSAC homography verify"): 4K frames generated under a projective map, ORB-2000,
+    verify_model 1 in both sample-solver forms; every frame's trace against the oracle (csrc/homography.hip.h)."""
+    from test_gpu_parity import _compare_traces
+    P, B, fw, fh = 60, 4, 3840, 2160
+    pages = synth.pages(P, threads=min(64, NCPU))
+    frames, truth, _ = synth.frames_persp(pages, B, fw, fh, persp=0.1, first=7, threads=min(64, NCPU))
+    for hdlt in (1, 0):
+        kw = dict(verify_model=1, ocv_hdlt=hdlt)
+        db = oracle.PageDB(oracle.default_config(**kw))
+        db.add_pages(pages, threads=NCPU)
+        assert db.finalize() == 0
+        m = capi.Matcher(capi.default_config(**kw))
+        m.add_pages(list(pages)); m.finalize()
+        v = m.match_frames(frames)
+        otr = _oracle_traces(db, frames, list(range(B)))
+        for i in range(B):
+            gc, (ov, oc) = m.last_candidates(i), otr[i]
+            assert v[i]["n_keypoints"] == ov["n_keypoints"] and list(gc["page_idx"]) == list(oc["page_idx"])
+            assert list(gc["n_votes"]) == list(oc["n_votes"]) and list(gc["inliers"]) == list(oc["inliers"]), (hdlt, i)
+            assert list(gc["survived"]) == list(oc["survived"])
+            for a, b in zip(gc, oc):
+                if b["survived"]:
+                    assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-9), (hdlt, i)
+                assert abs(a["similarity"] - b["similarity"]) <= 1e-4
+            assert v[i]["page_idx"] == ov["page_idx"] and v[i]["inliers"] == ov["inliers"]
+        assert (v["page_idx"] == truth).mean() >= 0.5
+        m.close()
 
 
 # ---- configs[3] shape: the lecture flow, two ranks on one GPU --------------------------------------------------------------
@@ -213,6 +259,20 @@ def test_configs3_shape_lecture_two_ranks_one_gpu(capi, synth):
     want, have = set(map(k, tt)), set(map(k, tl2))
     assert len(want - have) <= max(1, len(want) // 20) and len(have - want) <= max(1, len(want) // 20), (sorted(want - have), sorted(have - want))
     assert 0.02 < changed1.mean() < 0.5                                   # the mask removes most sampled frames
+    # the oracle's column: changed flags of all 96 samples (video_capture.rs:86-98 restated on the CPU) and the verdict of every
+    # changed sample against the CPU restatement over the same 1000-page deck
+    import pyoracle
+    ocfg = pyoracle.default_config(nfeatures=1000)
+    samples = LT.sample_frames(pages, visits, 0, LECT_SAMPLES)
+    och = pyoracle.changed_mask(samples, ocfg)[0].astype(bool)
+    assert np.array_equal(och, changed1), "changed flags: HIP path vs oracle"
+    db = pyoracle.PageDB(ocfg)
+    db.add_pages(pages, threads=NCPU)
+    assert db.finalize() == 0
+    sel = np.flatnonzero(och)
+    ov = db.match_frames(samples[sel], threads=min(NCPU, len(sel)))
+    assert np.array_equal(ov["page_idx"], page1[sel]), "verdicts of the changed samples: HIP path vs oracle"
+    assert (page1[~och] == -2).all()
 
 
 def test_page_db_from_imported_features_equals_direct_build(capi, synth):
