@@ -252,6 +252,7 @@ def main():
     torch.cuda.synchronize()
     t_db = time.time() - t0
     M = m.descriptor_count
+    Mu = m.unique_descriptor_count             # what the k-NN stage searches (equal rows collapsed, results unchanged)
 
     d_frames = torch.from_numpy(frames).cuda()          # inputs resident in HBM before timing
     stream = torch.cuda.current_stream().cuda_stream
@@ -329,7 +330,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
-                   "train_descriptors_M": int(M), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
+                   "train_descriptors_M": int(M), "train_descriptors_unique": int(Mu), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
                    "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
@@ -344,9 +345,12 @@ def main():
         if knn_n > 0:
             avg_s = knn_ms / knn_n * 1e-3
             pairs_per_launch = knn_pairs / knn_n
-            q_per_launch = pairs_per_launch / max(M, 1)
+            # (pairs = query descriptors x train rows EVALUATED: the matrix-core engine searches the Mu distinct rows of the M train
+            # descriptors and restores the full-set result exactly — knn_expand_dups_kernel, inside the timed interval)
+            Mk = Mu if args.knn != "valu" else M
+            q_per_launch = pairs_per_launch / max(Mk, 1)
             # minimal operand traffic: packed queries + packed train once, 32 keys per query out
-            alg_bytes = 32.0 * (q_per_launch + M) + q_per_launch * 32 * 4
+            alg_bytes = 32.0 * (q_per_launch + Mk) + q_per_launch * 32 * 4
             hbm_view = {"bound": "hbm", "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(alg_bytes)}
             # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/knn_traffic.json; FETCH_SIZE doubled
@@ -354,10 +358,18 @@ def main():
             traffic = None
             if args.workload == "headline" and args.knn == "mfma" and not args.batch and not args.pages:
                 try:
-                    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "knn_traffic.json")))
-                    fx2, wr, nd = 2 * tj["fetch_size_kib"], tj["write_size_kib"], tj["dispatches"]
-                    traffic = {"bytes_per_launch": int((fx2 + wr) / nd * 1024), "fetch_kib_x2": int(fx2 / nd), "write_kib": int(wr / nd),
-                               "source": tj["source"], "note": tj["note"]}
+                    here = os.path.dirname(os.path.abspath(__file__))
+                    tj = json.load(open(os.path.join(here, "profiles", "knn_traffic.json")))
+                    # the figure was measured offline on ONE build of the kernel over ONE train matrix: it is only reported while the
+                    # kernel source and the matrix size are the ones it was measured on (otherwise null — never a stale number)
+                    import hashlib
+                    sha = hashlib.sha1(open(os.path.join(here, "slideo_amd", "csrc", "knn_tile.hip.h"), "rb").read()).hexdigest()
+                    if tj.get("kernel_source_sha1") == sha and int(tj.get("train_rows_searched", -1)) == int(Mk):
+                        fx2, wr, nd = 2 * tj["fetch_size_kib"], tj["write_size_kib"], tj["dispatches"]
+                        traffic = {"bytes_per_launch": int((fx2 + wr) / nd * 1024), "fetch_kib_x2": int(fx2 / nd), "write_kib": int(wr / nd),
+                                   "source": tj["source"], "note": tj["note"]}
+                    else:
+                        traffic = None
                 except (OSError, KeyError, ValueError):
                     traffic = None
             # `traffic` = HBM bytes per launch (a number, or null where it was not measured); the passes behind it in traffic_detail
@@ -368,9 +380,15 @@ def main():
                 # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
                 flops = 2.0 * 256 * pairs_per_launch
                 achieved = flops / avg_s / 1e12
+                # `achieved` counts the pairs the kernel EVALUATES (query descriptors x distinct train rows).  The job's algorithmic
+                # size by SURVEY 8(d) is K x M over ALL train rows — the same result, which the de-duplicated search delivers with
+                # M / Mu times fewer evaluations: that figure is `algorithmic` (flops of the brute-force definition per second).
+                alg = 2.0 * 256 * (q_per_launch * M) / avg_s / 1e12
                 out["roofline"] = dict({"kernel": "knn_tile2_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4; --knn mfma4 selects knn_tile4_kernel)", "bound": "mfma",
                                         "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512}, **common)
+                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512,
+                                        "algorithmic": {"pairs_per_launch": int(q_per_launch * M), "achieved": round(alg, 2), "frac": round(alg / MFMA_FP4_PEAK_TFLOPS, 4),
+                                                        "note": "K x M pairs of the brute-force definition (SURVEY 8d) per second of kernel time; the kernel evaluates K x Mu (equal train rows collapsed, results identical)"}}, **common)
             else:
                 laneops = LANEOPS_PER_PAIR * pairs_per_launch
                 achieved = laneops / avg_s / 1e12

@@ -248,6 +248,11 @@ int32_t     slideo_matcher_finalize_pages(slideo_matcher* m);
 int32_t     slideo_matcher_page_count(const slideo_matcher* m);
 /* Total descriptors over all pages (M).  -1 before finalize. */
 int64_t     slideo_matcher_descriptor_count(const slideo_matcher* m);
+/* Distinct descriptors among them (<= M).  The matcher's k-NN stage searches these and then restores, exactly, what a search
+ * over all M rows returns (csrc/knn.hip.h knn_expand_dups_kernel): FlannMatcher::knn_match returns every matching row
+ * (mo/flann.rs:73-89) and the vote counts per row (mo/lib.rs:268-282), so equal rows of different pages all vote.  Decks
+ * repeat templates: 21 % of the rows of the 500-page benchmark deck are duplicates.  -1 before finalize. */
+int64_t     slideo_matcher_unique_descriptor_count(const slideo_matcher* m);
 /* Copies page `page_idx`'s keypoints/descriptors (canonical order) to host. */
 int32_t     slideo_matcher_get_page_features(const slideo_matcher* m, int32_t page_idx,
                                              slideo_keypoint* kp, uint8_t* desc32,

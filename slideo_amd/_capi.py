@@ -57,6 +57,7 @@ EXPORTS = [
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
+    "slideo_matcher_unique_descriptor_count",
 ]
 
 _lib = None
@@ -83,6 +84,7 @@ def lib():
         L.slideo_last_error.restype = C.c_char_p
         L.slideo_last_error.argtypes = [C.c_void_p]
         L.slideo_matcher_descriptor_count.restype = C.c_int64
+        L.slideo_matcher_unique_descriptor_count.restype = C.c_int64
         L.slideo_matcher_descriptor_count.argtypes = [C.c_void_p]
         L.slideo_matcher_page_count.argtypes = [C.c_void_p]
         L.slideo_matcher_max_in_flight.argtypes = [C.c_void_p]
@@ -187,6 +189,11 @@ class Matcher:
     @property
     def descriptor_count(self):
         return int(lib().slideo_matcher_descriptor_count(self._h))
+
+    @property
+    def unique_descriptor_count(self):
+        """Distinct rows among the train descriptors: what the k-NN stage actually searches (results are those of all rows)."""
+        return int(lib().slideo_matcher_unique_descriptor_count(self._h))
 
     def page_features(self, page):
         n = C.c_int32()

@@ -130,6 +130,50 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_merge_kernel(uint32_t* __restri
     for (int i = 0; i < KLIST; ++i) o[i] = lst[i];
 }
 
+// Train-set de-duplication (exactness preserving).  Slide decks repeat templates, so many of the pages' 256-bit descriptors
+// are IDENTICAL rows of the train matrix (21 % of the headline set).  The matcher searches the unique rows only — a key then
+// carries the LOWEST original row of the group of equal rows — and this kernel restores what a search over all rows returns:
+// every further member of a key's group is inserted with the same distance (grp_next[row] = the next higher row with the same
+// descriptor, -1 at the end of a group).  Why the k best unique rows suffice: the members of a group share one distance, so the
+// rows of the true top k at the k-th distance are the lowest rows at that distance, their groups are exactly the groups whose
+// lowest row is at most the k-th row, and those come first among the groups of that distance — at most k groups in all.
+// Lists are [nq][KLIST] ascending keys, in place.  nq_dev != null: the query count lives on the device.
+template <int KLIST>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_expand_dups_kernel(uint32_t* __restrict__ lists, int nq, const int32_t* __restrict__ grp_next,
+                                                                    const uint32_t* __restrict__ nq_dev = nullptr) {
+    if (nq_dev) nq = (int)*nq_dev;
+    const int qi = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t* o = lists + (size_t)qi * KLIST;
+    uint32_t lst[KLIST];
+    int32_t nx[KLIST];
+    {
+        const uint4* o4 = reinterpret_cast<const uint4*>(o);
+#pragma unroll
+        for (int i = 0; i < KLIST / 4; ++i) { const uint4 v = o4[i]; lst[4 * i] = v.x; lst[4 * i + 1] = v.y; lst[4 * i + 2] = v.z; lst[4 * i + 3] = v.w; }
+    }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < KLIST; ++i) { nx[i] = lst[i] != KNN_EMPTY ? grp_next[lst[i] & KNN_IDX_MASK] : -1; any = any || nx[i] >= 0; }
+    if (!any) return;
+    uint32_t dkey[KLIST];
+#pragma unroll
+    for (int i = 0; i < KLIST; ++i) dkey[i] = lst[i] & ~KNN_IDX_MASK;               // the heads' distances (the list changes below)
+#pragma unroll
+    for (int i = 0; i < KLIST; ++i) {
+        int32_t row = nx[i];
+        while (row >= 0) {
+            const uint32_t key = dkey[i] | (uint32_t)row;
+            if (key >= lst[KLIST - 1]) break;                                       // members ascend: nothing later can enter
+            knn_insert<KLIST>(lst, key);
+            row = grp_next[row];
+        }
+    }
+    uint4* o4 = reinterpret_cast<uint4*>(o);
+#pragma unroll
+    for (int i = 0; i < KLIST / 4; ++i) o4[i] = make_uint4(lst[4 * i], lst[4 * i + 1], lst[4 * i + 2], lst[4 * i + 3]);
+}
+
 // Debug-tap unpack: keys [nq][KLIST] -> idx [nq][k] (i32, -1 pad), dist [nq][k] (u16, 65535 pad)
 __global__ void knn_unpack_kernel(const uint32_t* __restrict__ keys, int nq, int klist, int k,
                                   int32_t* __restrict__ idx, uint16_t* __restrict__ dist) {

@@ -65,7 +65,7 @@ struct Slot {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_orb = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
-    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false;
+    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask;
     PinBuf h_info, h_out;
@@ -121,6 +121,11 @@ struct slideo_matcher {
     int64_t M = -1;
     DevBuf d_train, d_train_page, d_page_xy, d_pageinfo, d_page_small;
     DevBuf d_trainb, d_train_side, d_train_nminh, d_train_perm;   // {0,1} FP4 operand in norm order + its side arrays (knn_tile.hip.h)
+    // train-set de-duplication (knn.hip.h knn_expand_dups_kernel): the matrix-core engine searches the Mu unique rows, keys carry
+    // the lowest original row of a group, d_grp_next chains the equal rows.  SLIDEO_KNN_DEDUP=0 searches all M rows.
+    DevBuf d_utrain, d_grp_next;
+    int64_t Mu = -1;
+    int knn_dedup = 1;
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
@@ -416,7 +421,8 @@ int knn_pad_rows(int nt) { return cdiv(std::max(nt, 1), KT_ST_ROWS) * KT_ST_ROWS
 // nt x 32 bytes of popcounts), expanded to tile-major FP4 on the device, plus per super-tile the rows' norms and original
 // indices and per tile half its smallest norm.  `t_host`: the packed rows in host memory.
 struct TrainBits { DevBuf *tx, *side, *nminh, *perm; };
-void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, TrainBits o, hipStream_t st) {
+// rowid (may be null): the row number a key carries for row i of t_host / t_dev (de-duplicated sets: the lowest original row)
+void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, TrainBits o, hipStream_t st, const int32_t* rowid = nullptr) {
     const int nt_pad = knn_pad_rows(nt), n_st = nt_pad / KT_ST_ROWS;
     std::vector<uint16_t> norm((size_t)std::max(nt, 1));
     uint32_t hist[258] = {0};
@@ -453,7 +459,7 @@ void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, Tr
         const float nf = perm[r] >= 0 ? (float)norm[perm[r]] : KT_PAD_NORM;     // (pad rows may now sit inside the stream: the partial last tile)
         uint32_t bits; std::memcpy(&bits, &nf, 4);
         side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + (r % KT_ST_ROWS)] = bits;
-        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + KT_ST_ROWS + (r % KT_ST_ROWS)] = (uint32_t)perm[r];
+        side[(size_t)(r / KT_ST_ROWS) * KT_SIDE_U32 + KT_ST_ROWS + (r % KT_ST_ROWS)] = (uint32_t)(perm[r] >= 0 && rowid ? rowid[perm[r]] : perm[r]);
         if (r % 32 == 0) nminh[r / 32] = 0.5f * nf;                      // ascending order: a tile's first row has its smallest norm
     }
     o.tx->reserve((size_t)nt_pad * 128); o.side->reserve(side.size() * 4 + 16); o.nminh->reserve(nminh.size() * 4 + 16);
@@ -648,7 +654,11 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         qtot = qplan = S.orb.qtot;
     }
     // all workspace before the timed kNN interval
-    knn_reserve(m, S, (int)qplan, (int)m->M, (int)qtot);
+    // (the matrix-core engine searches the unique rows of the train set, the VALU engine — A/B only — all of them)
+    const bool dedup = m->Mu < m->M && knn_engine_for(m, (int)qplan) != 1;
+    const int nt_knn = (int)(dedup ? m->Mu : m->M);
+    S.u_nt = nt_knn;
+    knn_reserve(m, S, (int)qplan, nt_knn, (int)qtot);
     S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
     S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
     S.d_gmask.reserve(std::max<size_t>((size_t)qtot * c.knn_k, 16));
@@ -671,8 +681,13 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         // (the ratio test needs the exact two nearest rows: exact lists)
         const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
         const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, (int)m->M, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
-        if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
+        if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
+        if (dedup) {
+            knn_expand_dups_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(
+                S.d_keys.as<uint32_t>(), (int)qtot, m->d_grp_next.as<int32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
+            check_launch("knn_expand_dups_kernel");
+        }
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
@@ -777,7 +792,7 @@ void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[1])); m->prof_ms[0] += t; m->prof_n[0]++;
         if (qtot > 0) {
             HIP_CHECK(hipEventElapsedTime(&t, S.ev[1], S.ev[2])); m->prof_ms[1] += t; m->prof_n[1]++;
-            m->prof_pairs += (int64_t)qtot * m->M;
+            m->prof_pairs += (int64_t)qtot * S.u_nt;       // pairs EVALUATED: unique train rows when the set is de-duplicated
             HIP_CHECK(hipEventElapsedTime(&t, S.ev[2], S.ev[3])); m->prof_ms[2] += t; m->prof_n[2]++;
         }
         HIP_CHECK(hipEventElapsedTime(&t, S.ev[0], S.ev[4])); m->prof_ms[3] += t; m->prof_n[3]++;
@@ -909,6 +924,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     mm->cfg = *cfg; mm->device = device;
     if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_ASYNC_SUBMIT")) mm->async_submit = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_KNN_DEDUP")) mm->knn_dedup = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_PYR_CHAIN")) mm->pyr_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
@@ -1130,7 +1146,36 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         HIP_CHECK(hipMemcpy(m->d_train.p, train.data(), train.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
-        prepare_train_bits(train.data(), m->d_train.as<uint32_t>(), (int)M, TrainBits{&m->d_trainb, &m->d_train_side, &m->d_train_nminh, &m->d_train_perm}, m->stream);
+        // equal rows: sort the row numbers by descriptor (ties by row), chain each group, keep the lowest row of each
+        std::vector<int32_t> order((size_t)M), grp_next((size_t)M, -1), urow;
+        for (int64_t i = 0; i < M; ++i) order[i] = (int32_t)i;
+        m->Mu = M;
+        if (m->knn_dedup) {
+            const uint64_t* t64 = reinterpret_cast<const uint64_t*>(train.data());
+            auto less = [&](int32_t a, int32_t b) {
+                const uint64_t* x = t64 + (size_t)a * 4; const uint64_t* y = t64 + (size_t)b * 4;
+                for (int j = 0; j < 4; ++j) if (x[j] != y[j]) return x[j] < y[j];
+                return a < b;
+            };
+            std::sort(order.begin(), order.end(), less);
+            std::vector<uint8_t> head((size_t)M, 1);
+            for (int64_t i = 1; i < M; ++i)
+                if (std::memcmp(t64 + (size_t)order[i - 1] * 4, t64 + (size_t)order[i] * 4, 32) == 0) { grp_next[order[i - 1]] = order[i]; head[order[i]] = 0; }
+            for (int64_t i = 0; i < M; ++i) if (head[i]) urow.push_back((int32_t)i);
+            m->Mu = (int64_t)urow.size();
+        }
+        m->d_grp_next.reserve(grp_next.size() * 4 + 16);
+        HIP_CHECK(hipMemcpy(m->d_grp_next.p, grp_next.data(), grp_next.size() * 4, hipMemcpyHostToDevice));
+        if (m->Mu < M) {
+            std::vector<uint8_t> utrain((size_t)m->Mu * 32);
+            for (int64_t i = 0; i < m->Mu; ++i) std::memcpy(utrain.data() + (size_t)i * 32, train.data() + (size_t)urow[i] * 32, 32);
+            m->d_utrain.reserve(utrain.size() + 64);
+            HIP_CHECK(hipMemcpy(m->d_utrain.p, utrain.data(), utrain.size(), hipMemcpyHostToDevice));
+            prepare_train_bits(utrain.data(), m->d_utrain.as<uint32_t>(), (int)m->Mu, TrainBits{&m->d_trainb, &m->d_train_side, &m->d_train_nminh, &m->d_train_perm},
+                               m->stream, urow.data());
+        } else {
+            prepare_train_bits(train.data(), m->d_train.as<uint32_t>(), (int)M, TrainBits{&m->d_trainb, &m->d_train_side, &m->d_train_nminh, &m->d_train_perm}, m->stream);
+        }
         HIP_CHECK(hipStreamSynchronize(m->stream));
     }
     if (P > 0) {
@@ -1145,6 +1190,7 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
 
 int32_t slideo_matcher_page_count(const slideo_matcher* m) { return m ? (int32_t)m->pages.size() : -1; }
 int64_t slideo_matcher_descriptor_count(const slideo_matcher* m) { return m && m->finalized ? m->M : -1; }
+int64_t slideo_matcher_unique_descriptor_count(const slideo_matcher* m) { return m && m->finalized ? m->Mu : -1; }
 
 int32_t slideo_matcher_get_page_features(const slideo_matcher* cm, int32_t page_idx, slideo_keypoint* kp, uint8_t* desc32,
                                          int32_t capacity, int32_t* n_out) {

@@ -163,7 +163,7 @@ def test_configs4_shape_4k_orb2000_end_to_end(capi, oracle, synth):
                 # (consecutive synthetic pages may share a template, SURVEY 8d: the best-rated page is the true one or its sibling)
                 assert abs(int(best["page_idx"]) - int(truth[i])) <= 2 and best["inliers"] <= 50, "a miss that is not the rating > 50 rule"
     assert misses <= B // 4
-    assert v["n_keypoints"].min() > 1500
+    assert v["n_keypoints"][truth >= 0].min() > 1500
     m.close()
 
 

@@ -725,3 +725,42 @@ def test_fused_pyramid_chain_equals_per_level_kernels(capi, oracle, synth, monke
         assert np.array_equal(da, db) and np.array_equal(ka["x"], kb["x"]) and np.array_equal(ka["angle"], kb["angle"])
     _cmp_orb(capi, oracle, mc, oracle.default_config(nfeatures=700), pages[0])
     mc.close(); mp.close()
+
+
+def test_train_set_dedup_is_exact(capi, oracle, synth, monkeypatch):
+    """Equal descriptors across pages (a deck that repeats pages / templates): the matcher searches the DISTINCT rows and
+    restores the full-set k-NN exactly (knn.hip.h knn_expand_dups_kernel) — every copy of a row votes, in row order, as
+    FlannMatcher::knn_match + the per-row vote of the reference (mo/flann.rs:73-89, mo/lib.rs:268-282) would have it."""
+    base = synth.pages(6, 800, 450)
+    pages = np.concatenate([base, base[[1, 4]], base[1:2]])              # page 1 three times (1, 6, 8), page 4 twice (4, 7)
+    frames, truth, _ = synth.frames(base, 10, 640, 360)
+    m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
+    M, Mu = m.descriptor_count, m.unique_descriptor_count
+    assert M == db.descriptor_count
+    n1, n4 = len(m.page_features(1)[0]), len(m.page_features(4)[0])
+    assert Mu <= M - 2 * n1 - n4 and Mu >= M - 2 * n1 - n4 - 60           # the copies collapse (a few rows repeat inside a page too)
+    for engine in ("mfma2", "mfma4"):
+        m.set_knn_engine(engine)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)                                  # votes per candidate: the copies split them as in the oracle
+    m.set_knn_exact_lists(True)
+    v2 = m.match_frames(frames)
+    assert np.array_equal(v, v2)
+    # a frame of page 1: all three copies are candidates with identical votes and inliers, the first (lowest index) wins
+    i1 = int(np.flatnonzero(truth == 1)[0]) if (truth == 1).any() else None
+    if i1 is not None:
+        c = m.last_candidates(i1)
+        trio = c[np.isin(c["page_idx"], [1, 6, 8])]
+        assert len(trio) == 3 and len(set(trio["n_votes"])) == 1 and len(set(trio["inliers"])) == 1
+        assert v[i1]["page_idx"] == 1
+    m.close()
+    # and the switch: SLIDEO_KNN_DEDUP=0 searches all rows — identical traces
+    monkeypatch.setenv("SLIDEO_KNN_DEDUP", "0")
+    m0 = capi.Matcher(small_cfg(capi))
+    monkeypatch.delenv("SLIDEO_KNN_DEDUP")
+    m0.add_pages(list(pages)); m0.finalize()
+    assert m0.unique_descriptor_count == m0.descriptor_count == M
+    v0 = m0.match_frames(frames)
+    assert np.array_equal(v0, v)
+    _compare_traces(m0, db, frames, v0)
+    m0.close()
