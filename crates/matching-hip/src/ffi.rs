@@ -96,6 +96,12 @@ extern "C" {
         frame_stride_bytes: i64,
         verdicts_out: *mut slideo_verdict,
     ) -> i32;
+    pub fn slideo_match_kept_frames(
+        m: *mut slideo_matcher,
+        n_sel: i32,
+        sel: *const i32,
+        verdicts_out: *mut slideo_verdict,
+    ) -> i32;
     pub fn slideo_changed_mask_bgr8(
         m: *mut slideo_matcher,
         n_frames: i32,

@@ -7,7 +7,7 @@
 //!   match_images_with_video (mo/lib.rs:140-158) -> opens the video to size the progress bar, as the reference does
 //!   process                 (mo/lib.rs:168-246) -> sampled frames in batches: slideo_changed_mask_bgr8
 //!                                                  (MarkSimilarIter, mo/video_capture.rs:86-98), then
-//!                                                  slideo_match_frames_bgr8 on the changed ones
+//!                                                  slideo_match_kept_frames on the changed ones (the mask's upload)
 //!                                                  (match_images_with_frame, mo/lib.rs:249-413); sentinel, sort,
 //!                                                  consecutive-duplicate removal as mo/lib.rs:185-189,229-244
 //! (mo/ = crates/matching-opencv/src/)
@@ -209,32 +209,20 @@ impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVid
             // make compute_similarity panic in the reference
             prev_small = Some(last_small);
 
-            // the changed frames, packed, through match_images_with_frame (mo/lib.rs:213-214)
-            let sel: Vec<usize> = (0..n).filter(|&i| changed[i] != 0).collect();
-            let mut packed = Vec::with_capacity(sel.len() * fb);
-            for &i in &sel {
-                packed.extend_from_slice(&batch.frames[i * fb..(i + 1) * fb]);
-            }
+            // the changed frames through match_images_with_frame (mo/lib.rs:213-214): the mask call left its upload on the
+            // device, slideo_match_kept_frames matches a subset of it by index — no second copy over PCIe
+            let sel: Vec<i32> = (0..n as i32).filter(|&i| changed[i as usize] != 0).collect();
             let mut verdicts = vec![ffi::slideo_verdict::default(); sel.len()];
             if !sel.is_empty() {
                 unsafe {
                     check(
                         h,
-                        ffi::slideo_match_frames_bgr8(
-                            h,
-                            sel.len() as i32,
-                            packed.as_ptr(),
-                            batch.width,
-                            batch.height,
-                            batch.width * 3,
-                            fb as i64,
-                            verdicts.as_mut_ptr(),
-                        ),
+                        ffi::slideo_match_kept_frames(h, sel.len() as i32, sel.as_ptr(), verdicts.as_mut_ptr()),
                     );
                 }
             }
             for (&i, v) in sel.iter().zip(verdicts.iter()) {
-                let (time, frame_idx) = batch.meta[i];
+                let (time, frame_idx) = batch.meta[i as usize];
                 results.push(Matching {
                     video_time: time,
                     video_frame_idx: frame_idx,

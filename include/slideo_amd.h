@@ -301,6 +301,18 @@ int32_t     slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames,
                                      const uint8_t* prev_small, uint8_t* last_small_out,
                                      uint8_t* changed_out, float* similarity_out);
 
+/* The frames of the LAST slideo_changed_mask_bgr8 call are still on the device when it returns.  This matches a subset of
+ * them — sel[i] = index into that call's frames, ascending or not — exactly as slideo_match_frames_bgr8 would match the same
+ * frames, without uploading them a second time: what OpenCVVideoMatcherTask::process does with the frames MarkSimilarIter
+ * flagged as changed (mo/lib.rs:205-214).  Must directly follow the mask call on this handle (any other call that uploads
+ * frames invalidates the kept ones: SLIDEO_ERR_STATE). */
+int32_t     slideo_match_kept_frames(slideo_matcher* m, int32_t n_sel, const int32_t* sel, slideo_verdict* verdicts_out);
+
+/* Optional: page-lock a frame buffer the caller reuses across calls (hipHostRegister / hipHostUnregister), so that the H2D
+ * copies read it by DMA directly.  Not needed for correctness; pageable memory is staged by the runtime. */
+int32_t     slideo_host_register(void* ptr, size_t bytes);
+int32_t     slideo_host_unregister(void* ptr);
+
 /* Optional progress sink for add_pages / match_frames. */
 int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user);
 

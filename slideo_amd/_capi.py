@@ -57,7 +57,7 @@ EXPORTS = [
     "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
-    "slideo_matcher_unique_descriptor_count",
+    "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
 ]
 
 _lib = None
@@ -263,6 +263,13 @@ class Matcher:
         self._check(lib().slideo_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
                                                    _p(prev_small), _p(last), _p(changed), _p(sims)))
         return changed.astype(bool), sims, last
+
+    def match_kept_frames(self, sel):
+        """Verdicts of frames `sel` (indices) of the LAST changed_mask call, from the copy that call left on the device."""
+        sel = np.ascontiguousarray(sel, np.int32)
+        out = np.zeros(len(sel), VERDICT_DTYPE)
+        self._check(lib().slideo_match_kept_frames(self._h, len(sel), _p(sel), _p(out)))
+        return out
 
     def set_knn_engine(self, engine):
         """'mfma' (default: FP4 matrix cores, wave shape chosen per launch), 'mfma4' / 'mfma2' (the two shapes forced:

@@ -63,7 +63,7 @@ struct OrbOut {            // where the last ORB run of a slot left its results 
 struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_in = nullptr, ev_orb = nullptr;
+    hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_up = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
@@ -126,6 +126,14 @@ struct slideo_matcher {
     DevBuf d_utrain, d_grp_next;
     int64_t Mu = -1;
     int knn_dedup = 1;
+    int host_unit = 32;              // frames per unit of a HOST-memory batch (SLIDEO_HOST_UNIT; 0 = the device-path rule)
+    // every H2D copy of frame units goes through ONE stream, in submission order: copies issued on the units' own streams run
+    // concurrently and share the link, so the first unit's frames arrive when all of them have (measured: 39 - 45 ms per 256
+    // frames from pinned memory against 31 in order)
+    hipStream_t copy_st = nullptr;
+    // the frames slideo_changed_mask_bgr8 uploaded last (slot 0's staging buffer), for slideo_match_kept_frames
+    struct Kept { bool valid = false; int n = 0, w = 0, h = 0, stride = 0; } kept;
+    DevBuf d_kept;
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)
@@ -589,16 +597,29 @@ void run_small(slideo_matcher* m, const uint8_t* imgs_dev, int n, int w, int h, 
     check_launch("small_image_kernel");
 }
 
-// copies n host frames into S.d_stage with frame stride h*stride
-void upload_frames(Slot& S, const uint8_t* host, int n, int h, int stride, int64_t frame_stride) {
+// copies n host frames into S.d_stage with frame stride h*stride; `cs` != null: on that (copy) stream, and S.st waits for it
+void upload_frames(Slot& S, const uint8_t* host, int n, int h, int stride, int64_t frame_stride, hipStream_t cs = nullptr) {
     const size_t fb = (size_t)h * stride;
     S.d_stage.reserve(fb * n + 16);
+    hipStream_t st = cs ? cs : S.st;
     if ((size_t)frame_stride == fb) {
-        HIP_CHECK(hipMemcpyAsync(S.d_stage.p, host, fb * n, hipMemcpyHostToDevice, S.st));
+        HIP_CHECK(hipMemcpyAsync(S.d_stage.p, host, fb * n, hipMemcpyHostToDevice, st));
     } else {
         for (int i = 0; i < n; ++i)
-            HIP_CHECK(hipMemcpyAsync(S.d_stage.as<uint8_t>() + fb * i, host + (size_t)frame_stride * i, fb, hipMemcpyHostToDevice, S.st));
+            HIP_CHECK(hipMemcpyAsync(S.d_stage.as<uint8_t>() + fb * i, host + (size_t)frame_stride * i, fb, hipMemcpyHostToDevice, st));
     }
+    if (cs) {
+        HIP_CHECK(hipEventRecord(S.ev_up, cs));
+        HIP_CHECK(hipStreamWaitEvent(S.st, S.ev_up, 0));
+    }
+}
+
+// page-locked (hipHostMalloc / hipHostRegister) host memory?  Copies from it are truly asynchronous DMA; copies from pageable
+// memory are staged by the runtime inside the call.
+bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 
 void validate_image(int w, int h, int stride) {
@@ -824,6 +845,10 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
     upload_area(m);
     int unit = sub_batch_for(m, ge.g, n);
     if (n >= 128 && unit >= (n + 1) / 2) unit = (n + 1) / 2;      // two halves overlap ORB with kNN / verify
+    // Host frames: the call is bound by the H2D copies (6.2 MB per 1080p frame: 256 frames = 29 ms at 55 GB/s against 14 ms of
+    // kernels), so what matters is that the copy engines never wait: short units, each copied on its slot's stream while the
+    // units before it compute — with two halves the second half's kernels start only when all of it has arrived.
+    if (!on_device && m->host_unit > 0 && n >= 2 * m->host_unit) unit = std::min(unit, m->host_unit);
     struct Pending { Slot* S; int ofs; };
     std::vector<Pending> pend;
     if (on_device && user_stream)
@@ -832,6 +857,7 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
             HIP_CHECK(hipStreamWaitEvent(S.st, S.ev_in, 0));
         }
     int done = 0;
+    const bool src_pinned = !on_device && host_is_pinned(frames);
     try {
         for (int i = 0; i < n; i += unit) {
             const int cnt = std::min(unit, n - i);
@@ -847,8 +873,12 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
             int64_t fs = frame_stride;
             if (on_device) dev = frames + (int64_t)i * frame_stride;
             else {
-                upload_frames(S, frames + (int64_t)i * frame_stride, cnt, h, stride, frame_stride);
+                // pinned source: asynchronous copies, kept in submission order on the one copy stream (see copy_st); pageable
+                // source: the runtime stages the copy inside the call, on the unit's own stream (measured: 32.7 ms per 256 frames
+                // that way against 54.8 through the copy stream)
+                upload_frames(S, frames + (int64_t)i * frame_stride, cnt, h, stride, frame_stride, src_pinned ? m->copy_st : nullptr);
                 dev = S.d_stage.as<uint8_t>(); fs = (int64_t)h * stride;
+                m->kept.valid = false;                       // (slot 0's staging buffer may be overwritten)
             }
             unit_submit(m, S, dev, cnt, w, h, stride, fs);
             pend.push_back({&S, i});
@@ -925,6 +955,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_ASYNC_SUBMIT")) mm->async_submit = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_KNN_DEDUP")) mm->knn_dedup = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_HOST_UNIT")) mm->host_unit = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_PYR_CHAIN")) mm->pyr_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
@@ -933,7 +964,9 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         for (auto& e : S.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_orb, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
     }
+    HIP_CHECK(hipStreamCreateWithFlags(&mm->copy_st, hipStreamNonBlocking));
     mm->stream = mm->slots[0].st;
     OrbTables t{};
     umax_table(cfg->patch_size / 2, t.umax);
@@ -979,7 +1012,9 @@ void slideo_matcher_destroy(slideo_matcher* m) {
         for (auto& e : S.ev) if (e) (void)hipEventDestroy(e);
         if (S.ev_in) (void)hipEventDestroy(S.ev_in);
         if (S.ev_orb) (void)hipEventDestroy(S.ev_orb);
+        if (S.ev_up) (void)hipEventDestroy(S.ev_up);
     }
+    if (m->copy_st) (void)hipStreamDestroy(m->copy_st);
     delete m;
 }
 
@@ -1307,7 +1342,9 @@ int32_t slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames, const uint
     hipStream_t st = S.st;
     int sw = 0, sh = 0;
     const size_t fb = (size_t)height * stride_bytes;
+    m->kept.valid = false;
     upload_frames(S, frames, n_frames, height, stride_bytes, frame_stride_bytes);
+    m->kept = slideo_matcher::Kept{true, n_frames, width, height, stride_bytes};   // stays in slot 0's staging buffer: slideo_match_kept_frames
     run_small(m, S.d_stage.as<uint8_t>(), n_frames, width, height, stride_bytes, (int64_t)fb, sw, sh, st);
     const size_t sb = (size_t)sw * sh * 3;
     DevBuf& prev = m->d_prev_small;
@@ -1340,6 +1377,43 @@ int32_t slideo_changed_mask_bgr8(slideo_matcher* m, int32_t n_frames, const uint
         if (similarity_out) similarity_out[i] = sim;
     }
     API_CATCH(m)
+}
+
+int32_t slideo_match_kept_frames(slideo_matcher* m, int32_t n_sel, const int32_t* sel, slideo_verdict* verdicts_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (n_sel < 0 || (n_sel > 0 && (!sel || !verdicts_out))) fail(SLIDEO_ERR_INVALID_ARG, "null selection/verdicts");
+    if (!m->kept.valid) fail(SLIDEO_ERR_STATE, "no frames kept: slideo_changed_mask_bgr8 must be the call before (its upload is what is matched)");
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    const slideo_matcher::Kept k = m->kept;
+    const size_t fb = (size_t)k.h * k.stride;
+    for (int i = 0; i < n_sel; ++i) if (sel[i] < 0 || sel[i] >= k.n) fail(SLIDEO_ERR_INVALID_ARG, "selected frame %d outside the %d kept", sel[i], k.n);
+    if (n_sel == 0) return SLIDEO_OK;
+    // the selected frames packed back to back (device to device: 6 MB per 1080p frame at HBM speed), runs of consecutive
+    // indices in one copy
+    m->d_kept.reserve(fb * (size_t)n_sel + 16);
+    hipStream_t st = m->slots[0].st;
+    for (int i = 0; i < n_sel;) {
+        int j = i + 1;
+        while (j < n_sel && sel[j] == sel[j - 1] + 1) ++j;
+        HIP_CHECK(hipMemcpyAsync(m->d_kept.as<uint8_t>() + fb * i, m->slots[0].d_stage.as<uint8_t>() + fb * sel[i], fb * (size_t)(j - i), hipMemcpyDeviceToDevice, st));
+        i = j;
+    }
+    match_frames_impl(m, n_sel, m->d_kept.as<uint8_t>(), true, k.w, k.h, k.stride, (int64_t)fb, verdicts_out, st);
+    API_CATCH(m)
+}
+
+// Pins a caller's frame buffer (hipHostRegister) so that the H2D copies of slideo_match_frames_bgr8 / slideo_changed_mask_bgr8
+// read it by DMA without the runtime's staging copy.  Worth it for a buffer that is reused across calls (a decoder's frame ring):
+// registering costs about as much as one copy of the buffer.
+int32_t slideo_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return SLIDEO_ERR_INVALID_ARG;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? SLIDEO_OK : SLIDEO_ERR_HIP;
+}
+int32_t slideo_host_unregister(void* ptr) {
+    if (!ptr) return SLIDEO_ERR_INVALID_ARG;
+    return hipHostUnregister(ptr) == hipSuccess ? SLIDEO_OK : SLIDEO_ERR_HIP;
 }
 
 // ---- debug taps ---------------------------------------------------------------------------

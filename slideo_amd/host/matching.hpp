@@ -206,7 +206,7 @@ public:
         const double step = std::floor(video.fps * interval);
         const size_t fb = (size_t)video.width * video.height * 3;
         const int batch = 64;
-        std::vector<uint8_t> frames, sel, prev_small, last_small;
+        std::vector<uint8_t> frames, prev_small, last_small;
         std::vector<std::pair<double, size_t>> meta;
         int sw = 0, sh = 0;
         auto flush = [&]() {
@@ -222,12 +222,12 @@ public:
             h_->check(slideo_changed_mask_bgr8(h_->m, n, frames.data(), video.width, video.height, video.width * 3, (int64_t)fb,
                                                prev_small.empty() ? nullptr : prev_small.data(), last_small.data(), changed.data(), nullptr));   // video_capture.rs:86-98
             prev_small = last_small;
-            sel.clear();
-            std::vector<int> idx;
-            for (int i = 0; i < n; ++i) if (changed[i]) { idx.push_back(i); sel.insert(sel.end(), frames.begin() + (size_t)i * fb, frames.begin() + (size_t)(i + 1) * fb); }
+            std::vector<int32_t> idx;
+            for (int i = 0; i < n; ++i) if (changed[i]) idx.push_back(i);
             if (!idx.empty()) {
                 std::vector<slideo_verdict> v(idx.size());
-                h_->check(slideo_match_frames_bgr8(h_->m, (int32_t)idx.size(), sel.data(), video.width, video.height, video.width * 3, (int64_t)fb, v.data()));   // mo/lib.rs:213-214
+                // mo/lib.rs:213-214 on the copy of the frames the mask call left on the device (no second upload)
+                h_->check(slideo_match_kept_frames(h_->m, (int32_t)idx.size(), idx.data(), v.data()));
                 for (size_t k = 0; k < idx.size(); ++k) {
                     std::optional<I> img;
                     if (v[k].page_idx >= 0) img = (*images_)[(size_t)v[k].page_idx];

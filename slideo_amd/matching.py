@@ -128,7 +128,8 @@ class HipVideoMatcherTask:
             changed, _, prev_small = m.changed_mask(stack, prev_small)               # MarkSimilarIter, video_capture.rs:86-98
             idx = np.nonzero(changed)[0]
             if len(idx):
-                verdicts = m.match_frames(stack[idx])                                # match_images_with_frame, lib.rs:213-214
+                # match_images_with_frame, lib.rs:213-214 — on the copy of the frames the mask call left on the device
+                verdicts = m.match_kept_frames(idx) if hasattr(m, "match_kept_frames") else m.match_frames(stack[idx])
                 for j, v in zip(idx, verdicts):
                     t, fi = pend_meta[j]
                     img = self._images[v["page_idx"]] if v["page_idx"] >= 0 else None

@@ -764,3 +764,29 @@ def test_train_set_dedup_is_exact(capi, oracle, synth, monkeypatch):
     assert np.array_equal(v0, v)
     _compare_traces(m0, db, frames, v0)
     m0.close()
+
+
+def test_match_kept_frames_equals_a_second_upload(capi, cfg0_data):
+    """slideo_match_kept_frames: the frames the changed-mask call uploaded are matched from the device copy — same verdicts
+    and traces as uploading the changed subset again (what process() did before), in any selection order."""
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    with pytest.raises(capi.SlideoError) as e:
+        m.match_kept_frames([0])
+    assert e.value.code == 4                                            # STATE: no mask call before
+    changed, _, _ = m.changed_mask(frames)
+    sel = np.array([5, 0, 1, 2, 7], np.int32)
+    vk = m.match_kept_frames(sel)
+    ck = [m.last_candidates(i) for i in range(len(sel))]
+    vu = m.match_frames(frames[sel])
+    assert np.array_equal(vk, vu)
+    for i in range(len(sel)):
+        assert np.array_equal(ck[i], m.last_candidates(i))
+    with pytest.raises(capi.SlideoError):
+        m.match_kept_frames([0])                                        # the host-frame call above overwrote the staging buffer
+    m.changed_mask(frames[:3])
+    with pytest.raises(capi.SlideoError):
+        m.match_kept_frames([3])                                        # outside the kept frames
+    assert np.array_equal(m.match_kept_frames([]), np.zeros(0, capi.VERDICT_DTYPE))
+    m.close()

@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from slideo_amd import _capi, synth
 pages = synth.pages(500, 2001, 1125, threads=64)
