@@ -385,6 +385,37 @@ int32_t     slideo_l2_set_train(slideo_matcher* m, const uint8_t* t, int32_t nt)
 int32_t     slideo_l2_knn_dev(slideo_matcher* m, const void* q_dev, int32_t nq, int32_t k, void* idx_dev /* i32 [nq*k] */,
                               void* dist_dev /* u32 [nq*k] */, float* kernel_ms);
 
+/* ---- SIFT (north-star extension, BASELINE configs[2]; no counterpart in the reference, whose only extractor is ORB:
+ * mo/feature_extractor.rs:3-4,13).  cv::SIFT::detectAndCompute of OpenCV 4.5.2 as restated in oracle/sift_oracle.h (the
+ * parity target; its header lists the two documented departures): doubled first octave, nOctaveLayers + 3 Gaussian layers per
+ * octave, DoG extrema with sub-pixel refinement, contrast and edge tests, orientation histogram (one keypoint per peak),
+ * retainBest(nfeatures) by response with ties kept, 4 x 4 x 8 descriptors as 128 bytes (OpenCV's are integer-valued 0..255).
+ * Keypoints come back in canonical order (octave, layer, row, column, orientation bin); `octave` holds OpenCV's packed field
+ * (octave & 255 | layer << 8 | sub-layer << 16), x / y / size in input-image pixels.  The descriptors feed slideo_l2_knn_dev.
+ * Limits: n_octave_layers must be 3; image sides <= 4095 (the doubled image's coordinates travel in 13 bits). */
+typedef struct slideo_sift_config {
+    int32_t nfeatures;            /* 0 = keep every keypoint (cv::SIFT::create default)  */
+    int32_t n_octave_layers;      /* 3    */
+    double  contrast_threshold;   /* 0.04 */
+    double  edge_threshold;       /* 10   */
+    double  sigma;                /* 1.6  */
+} slideo_sift_config;
+void        slideo_sift_config_default(slideo_sift_config* cfg);
+/* One host image.  *n_out = keypoints found even when it exceeds `capacity` (then SLIDEO_ERR_CAPACITY). */
+int32_t     slideo_sift_bgr8(slideo_matcher* m, const slideo_sift_config* cfg, const uint8_t* bgr, int32_t width, int32_t height,
+                             int32_t stride_bytes, slideo_keypoint* kp, uint8_t* desc128, int32_t capacity, int32_t* n_out);
+/* A batch of equally sized frames in DEVICE memory -> keypoints and descriptors in DEVICE memory, frame after frame:
+ * frame f owns rows [qofs_out[f], qofs_out[f + 1]) of kp_dev (slideo_keypoint) and desc_dev (128 bytes each).  qofs_out: n + 1
+ * host values.  capacity_total rows must fit (else SLIDEO_ERR_CAPACITY).  kernel_ms (may be null): HIP-event time of the call's
+ * kernels.  bench.py --workload cfg2 times this + slideo_l2_knn_dev. */
+int32_t     slideo_sift_frames_dev(slideo_matcher* m, const slideo_sift_config* cfg, int32_t n_frames, const uint8_t* frames_dev,
+                                   int32_t width, int32_t height, int32_t stride_bytes, int64_t frame_stride_bytes,
+                                   int64_t capacity_total, void* kp_dev, void* desc_dev, uint32_t* qofs_out, float* kernel_ms);
+/* Pyramid tap (parity tests): Gaussian layer (dog == 0, layer 0 .. 5) or difference layer (dog != 0, layer 0 .. 4) of `octave`. */
+int32_t     slideo_sift_layer_bgr8(slideo_matcher* m, const slideo_sift_config* cfg, const uint8_t* bgr, int32_t width, int32_t height,
+                                   int32_t stride_bytes, int32_t octave, int32_t layer, int32_t dog, float* out, int64_t out_capacity,
+                                   int32_t* lw, int32_t* lh);
+
 /* to_small_image (mo/image_utils.rs:8-20) of one host image. */
 int32_t     slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
                                     int32_t height, int32_t stride_bytes, uint8_t* out,

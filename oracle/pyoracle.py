@@ -43,9 +43,15 @@ CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers",
                             ("transform", "<f8", (9,))])
 
 
+class SiftConfig(C.Structure):
+    """slideo_sift_config (include/slideo_amd.h): cv::SIFT::create's arguments."""
+    _fields_ = [("nfeatures", C.c_int32), ("n_octave_layers", C.c_int32), ("contrast_threshold", C.c_double),
+                ("edge_threshold", C.c_double), ("sigma", C.c_double)]
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "slideo_oracle.cpp")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "slideo_oracle.cpp"), os.path.join(_HERE, "sift_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
 
@@ -181,6 +187,43 @@ def orb(bgr, cfg, cap=None):
     if n > cap:
         return orb(bgr, cfg, cap=n)
     return kp[:n].copy(), desc[:n].copy()
+
+
+def sift_config(**over):
+    c = SiftConfig()
+    lib().so_sift_config_default(C.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def sift(bgr, scfg=None, cfg=None, cap=None):
+    """cv::SIFT::detectAndCompute restated (oracle/sift_oracle.h): (keypoints, descriptors u8 [n,128], stats)."""
+    bgr = _img3(bgr)
+    h, w, _ = bgr.shape
+    scfg = scfg or sift_config()
+    cfg = cfg or default_config()
+    cap = cap or 20000
+    kp = np.zeros(cap, KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 128), np.uint8)
+    st = np.zeros(3, np.int32)
+    n = lib().so_sift_bgr8(_p(bgr), w, h, w * 3, C.byref(scfg), C.byref(cfg.ocv), _p(kp), _p(desc), cap, _p(st))
+    if n > cap:
+        return sift(bgr, scfg, cfg, cap=n)
+    return kp[:n].copy(), desc[:n].copy(), dict(octaves=int(st[0]), extrema=int(st[1]), refined=int(st[2]))
+
+
+def sift_layer(bgr, octave, layer, dog=False, scfg=None, cfg=None):
+    bgr = _img3(bgr)
+    h, w, _ = bgr.shape
+    scfg = scfg or sift_config()
+    cfg = cfg or default_config()
+    out = np.empty(4 * h * w, np.float32)
+    lw = C.c_int32(); lh = C.c_int32()
+    rc = lib().so_sift_layer(_p(bgr), w, h, w * 3, C.byref(scfg), C.byref(cfg.ocv), octave, layer, int(dog), _p(out), C.c_int64(out.size),
+                             C.byref(lw), C.byref(lh))
+    assert rc == 0, rc
+    return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
 
 
 def knn_hamming(q, t, k):

@@ -1676,6 +1676,8 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
 
 }  // namespace
 
+#include "sift_oracle.h"
+
 // ===========================================================================
 // C interface (ctypes)
 // ===========================================================================

@@ -37,6 +37,20 @@ class Config(C.Structure):
     ]
 
 
+class SiftConfig(C.Structure):
+    """slideo_sift_config (include/slideo_amd.h): cv::SIFT::create's arguments."""
+    _fields_ = [("nfeatures", C.c_int32), ("n_octave_layers", C.c_int32), ("contrast_threshold", C.c_double),
+                ("edge_threshold", C.c_double), ("sigma", C.c_double)]
+
+
+def sift_config(**over):
+    c = SiftConfig()
+    lib().slideo_sift_config_default(C.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                            ("response", "<f4"), ("octave", "<i4")])
 VERDICT_DTYPE = np.dtype([("page_idx", "<i4"), ("similarity", "<f4"), ("inliers", "<i4"),
@@ -58,6 +72,7 @@ EXPORTS = [
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
     "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
+    "slideo_sift_config_default", "slideo_sift_bgr8", "slideo_sift_frames_dev", "slideo_sift_layer_bgr8",
 ]
 
 _lib = None
@@ -263,6 +278,39 @@ class Matcher:
         self._check(lib().slideo_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
                                                    _p(prev_small), _p(last), _p(changed), _p(sims)))
         return changed.astype(bool), sims, last
+
+    # ---- SIFT (north-star extension, csrc/sift.hip.h) ---------------------------------------
+    def sift(self, bgr, scfg=None, cap=20000):
+        """cv::SIFT::detectAndCompute on one host image: (keypoints, descriptors u8 [n, 128])."""
+        bgr = _img3(bgr)
+        h, w, _ = bgr.shape
+        scfg = scfg or sift_config()
+        kp = np.zeros(cap, KEYPOINT_DTYPE); desc = np.zeros((cap, 128), np.uint8)
+        n = C.c_int32()
+        rc = lib().slideo_sift_bgr8(self._h, C.byref(scfg), _p(bgr), w, h, w * 3, _p(kp), _p(desc), cap, C.byref(n))
+        if rc == 7 and n.value > cap:
+            return self.sift(bgr, scfg, cap=n.value)
+        self._check(rc)
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def sift_layer(self, bgr, octave, layer, dog=False, scfg=None):
+        bgr = _img3(bgr)
+        h, w, _ = bgr.shape
+        scfg = scfg or sift_config()
+        out = np.empty(4 * h * w, np.float32)
+        lw = C.c_int32(); lh = C.c_int32()
+        self._check(lib().slideo_sift_layer_bgr8(self._h, C.byref(scfg), _p(bgr), w, h, w * 3, octave, layer, int(dog), _p(out),
+                                                 C.c_int64(out.size), C.byref(lw), C.byref(lh)))
+        return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+    def sift_frames_dev(self, frames_ptr, n, w, h, kp_ptr, desc_ptr, capacity_total, scfg=None):
+        """SIFT of n device frames into device arrays; returns (qofs [n + 1] host, kernel ms)."""
+        scfg = scfg or sift_config()
+        qofs = np.zeros(n + 1, np.uint32)
+        ms = C.c_float()
+        self._check(lib().slideo_sift_frames_dev(self._h, C.byref(scfg), n, C.c_void_p(frames_ptr), w, h, w * 3, C.c_int64(w * h * 3),
+                                                 C.c_int64(capacity_total), C.c_void_p(kp_ptr), C.c_void_p(desc_ptr), _p(qofs), C.byref(ms)))
+        return qofs, float(ms.value)
 
     def match_kept_frames(self, sel):
         """Verdicts of frames `sel` (indices) of the LAST changed_mask call, from the copy that call left on the device."""

@@ -1,0 +1,494 @@
+// sift.hip.h — SIFT keypoint detect + describe on gfx950 (BASELINE configs[2] / north_star "SIFT keypoint detect+describe";
+// SURVEY 8(f) N4).  The reference has no SIFT (its only extractor is ORB, crates/matching-opencv/src/feature_extractor.rs:3-4,13):
+// the parity target is the CPU restatement of cv::SIFT::detectAndCompute (OpenCV 4.5.2, recalled) in oracle/sift_oracle.h, whose
+// header lists what is restated and the two documented departures (fixed-point histogram sums, canonical keypoint order).
+// Every float operation below is written in the oracle's order, so the whole extractor is bit-exact against it: pyramid layers,
+// keypoints and the 128 descriptor bytes.
+//
+//   sift_base_kernel      BGR -> gray (u8, the ORB path's coefficients) -> f32, 2x bilinear upsample (firstOctave = -1)
+//   sift_blur_kernel      GaussianBlur on f32 = sepFilter2D: row pass (taps in order) and column pass (centre, then symmetric
+//                         pairs) through LDS in ONE launch per layer, BORDER_REFLECT_101; optionally writes the DoG layer
+//                         (this layer minus its input) in the same pass — the difference pyramid costs no read of its own
+//   sift_half_kernel      next octave's first layer: every second pixel of layer nOctaveLayers
+//   sift_extrema_kernel   |v| > threshold and >= / <= all 26 neighbours -> candidate list (atomic append; order is restored later)
+//   sift_refine_kernel    one wave per candidate: adjustLocalExtrema (every lane the same few dozen flops), then the
+//                         orientation histogram — samples across the lanes, 36 bins of 64-bit fixed point in LDS (integer
+//                         atomics: order independent) — smoothing, peaks -> raw keypoints
+//   sift_select_kernel    one block per frame: canonical order (bitonic sort of keys in global memory), duplicates out,
+//                         retainBest(nfeatures) by a 4-pass radix select on the response bits (ties kept)
+//   sift_describe_kernel  one wave per kept keypoint: 4 x 4 x 8 histogram (360 fixed-point bins in LDS), trilinear votes across
+//                         the lanes, normalisation and the 0.2 clamp in the oracle's (serial) summation order, 128 bytes out
+//
+// Bounds: HBM.  Per 1080p frame the doubled base image is 3840 x 2160 f32 = 33 MB and the pyramid writes (6 Gaussian + 5 DoG
+// layers) x 4/3 octaves x 33 MB = 486 MB and reads about as much again: ~1 GB per frame, 120 us at 8 TB/s — SIFT with the
+// doubled first octave is two orders of magnitude more traffic than ORB's byte pyramid (42 MB).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb.hip.h"
+
+namespace slideo {
+
+constexpr int SIFT_MAX_OCT = 12;
+constexpr int SIFT_NL = 3;                      // nOctaveLayers (the only value the kernels implement)
+constexpr int SIFT_BORDER = 5, SIFT_STEPS = 5, SIFT_BINS = 36;
+constexpr int SIFT_MAX_TAPS = 32;               // cvRound(8 sigma + 1) | 1 <= 27 for sigma <= 3.1
+constexpr int SIFT_BT_W = 64, SIFT_BT_H = 32;   // blur tile (outputs) per 256-thread block
+constexpr double SIFT_FIXD = 1048576.0;         // 2^20
+
+struct SiftGeom {
+    int32_t w, h;                               // input image
+    int32_t n_oct;
+    int32_t ow[SIFT_MAX_OCT], oh[SIFT_MAX_OCT];
+    int64_t g_ofs[SIFT_MAX_OCT], d_ofs[SIFT_MAX_OCT];      // float offsets of an octave's first Gaussian / DoG layer inside one frame
+    int64_t g_frame, d_frame;                   // floats per frame
+};
+
+struct SiftTaps { int32_t n; float k[SIFT_MAX_TAPS]; };
+
+struct SiftParams {
+    int32_t nfeatures, cand_cap, raw_cap;
+    float contrast_threshold, edge_threshold, sigma;
+    int32_t threshold;                          // floor(0.5 * contrastThreshold / nOctaveLayers * 255)
+    int32_t atan_fma, blur_fma;
+};
+
+struct SiftRaw { slideo_keypoint kp; uint64_t key; };      // raw keypoint + canonical key (octave, layer, r, c, bin)
+
+__device__ __forceinline__ int sift_reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// grid (ceil(2w / 256), 2h, n)
+__global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride, int stride, int w, int h,
+                                                        GrayCoef gc, float* __restrict__ out, int64_t out_frame) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int W = 2 * w;
+    if (x >= W) return;
+    const uint8_t* img = frames + (int64_t)blockIdx.z * frame_stride;
+    auto gray = [&](int yy, int xx) -> float {
+        const uint8_t* p = img + (int64_t)yy * stride + 3 * xx;
+        return (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1u << (gc.shift - 1))) >> gc.shift);
+    };
+    auto coef = [](int d, int n, int& i0, int& i1, float& a0, float& a1) {
+        float f = (float)(((double)d + 0.5) * 0.5 - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { s = 0; f = 0; }
+        if (s >= n - 1) { s = n - 1; f = 0; }
+        i0 = s; i1 = min(s + 1, n - 1); a0 = 1.f - f; a1 = f;
+    };
+    int x0, x1, y0, y1; float a0, a1, b0, b1;
+    coef(x, w, x0, x1, a0, a1);
+    coef(y, h, y0, y1, b0, b1);
+    const float t0 = gray(y0, x0) * a0 + gray(y0, x1) * a1;
+    const float t1 = gray(y1, x0) * a0 + gray(y1, x1) * a1;
+    out[(int64_t)blockIdx.z * out_frame + (int64_t)y * W + x] = t0 * b0 + t1 * b1;
+}
+
+// grid (tiles_x * tiles_y, n), block 256.  src / dst: layer pointers of frame 0, per-frame strides in floats.
+// dog != null: dog = dst - src (the difference layer between the input and the output layer).
+template <bool FMA>
+__global__ __launch_bounds__(256) void sift_blur_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
+                                                        float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp) {
+    constexpr int TW = SIFT_BT_W, TH = SIFT_BT_H, MAXR = SIFT_MAX_TAPS / 2;
+    __shared__ float s_in[(TH + 2 * MAXR) * (TW + 2 * MAXR)];
+    __shared__ float s_row[(TH + 2 * MAXR) * TW];
+    const int r = tp.n / 2;
+    const int tiles_x = (w + TW - 1) / TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* S = src + (int64_t)blockIdx.y * src_frame;
+    const int iw = TW + 2 * r, ih = TH + 2 * r;
+    for (int i = threadIdx.x; i < iw * ih; i += 256) {
+        const int yy = i / iw, xx = i - yy * iw;
+        s_in[i] = S[(int64_t)sift_reflect101(y0 - r + yy, h) * w + sift_reflect101(x0 - r + xx, w)];
+    }
+    __syncthreads();
+    auto mad = [](float a, float b, float c) -> float { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
+    // row pass: s = k[0] S[0], then += k[j] S[j] in tap order
+    for (int i = threadIdx.x; i < ih * TW; i += 256) {
+        const int yy = i / TW, xx = i - yy * TW;
+        const float* p = s_in + yy * iw + xx;
+        float s = tp.k[0] * p[0];
+        for (int j = 1; j < tp.n; ++j) s = mad(tp.k[j], p[j], s);
+        s_row[i] = s;
+    }
+    __syncthreads();
+    // column pass: s = k[r] T[c], then += k[r + j] (T[c + j] + T[c - j])
+    float* D = dst + (int64_t)blockIdx.y * dst_frame;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int yy = i / TW, xx = i - yy * TW;
+        const int gx = x0 + xx, gy = y0 + yy;
+        if (gx >= w || gy >= h) continue;
+        const float* p = s_row + (yy + r) * TW + xx;
+        float s = tp.k[r] * p[0];
+        for (int j = 1; j <= r; ++j) s = mad(tp.k[r + j], p[j * TW] + p[-j * TW], s);
+        D[(int64_t)gy * w + gx] = s;
+        if (dog) dog[(int64_t)blockIdx.y * dog_frame + (int64_t)gy * w + gx] = s - s_in[(yy + r) * iw + xx + r];
+    }
+}
+
+// dst(x, y) = src(2x, 2y).  grid (ceil(dw / 256), dh, n)
+__global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict__ src, int64_t src_frame, int sw, float* __restrict__ dst,
+                                                        int64_t dst_frame, int dw, int dh) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    dst[(int64_t)blockIdx.z * dst_frame + (int64_t)y * dw + x] = src[(int64_t)blockIdx.z * src_frame + (int64_t)(2 * y) * sw + 2 * x];
+}
+
+// candidate = o << 28 | layer << 26 | r << 13 | c.  grid (ceil(ow / 64), ceil(oh / 4), n * 3 layers), block 256 (64 x 4)
+__global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParams sp, int o, const float* __restrict__ dogp,
+                                                           uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t* __restrict__ flags) {
+    const int f = blockIdx.z / SIFT_NL, layer = 1 + blockIdx.z % SIFT_NL;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int w = g.ow[o], h = g.oh[o];
+    if (c < SIFT_BORDER || c >= w - SIFT_BORDER || r < SIFT_BORDER || r >= h - SIFT_BORDER) return;
+    const int64_t lsz = (int64_t)w * h;
+    const float* img = dogp + (int64_t)f * g.d_frame + g.d_ofs[o] + lsz * layer;
+    const float* prev = img - lsz;
+    const float* next = img + lsz;
+    const int64_t p = (int64_t)r * w + c;
+    const float val = img[p];
+    if (!(fabsf(val) > (float)sp.threshold)) return;
+    bool ext = true;
+    if (val > 0) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int64_t q = p + dy * w + dx;
+                if (dy || dx) ext = ext && (val >= img[q]);
+                ext = ext && (val >= prev[q]) && (val >= next[q]);
+            }
+    } else {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int64_t q = p + dy * w + dx;
+                if (dy || dx) ext = ext && (val <= img[q]);
+                ext = ext && (val <= prev[q]) && (val <= next[q]);
+            }
+    }
+    if (!ext) return;
+    const uint32_t slot = atomicAdd(&cand_count[f], 1u);
+    if (slot >= (uint32_t)sp.cand_cap) { atomicOr(flags, 16u); return; }
+    cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)layer << 26) | ((uint32_t)r << 13) | (uint32_t)c;
+}
+
+// Matx33f::solve(b, DECOMP_LU) (matx.hpp Matx_FastSolveOp<float, 3, 3, 1>): Cramer's rule in f32; singular -> 0
+__device__ __forceinline__ void sift_solve3(const float (&a)[3][3], const float (&b)[3], float (&x)[3]) {
+    float d = a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) - a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2]) +
+              a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    x[0] = x[1] = x[2] = 0;
+    if (d == 0) return;
+    d = 1 / d;
+    x[0] = d * (b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2]) + a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * (a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) - b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) + a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * (a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) - a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0]) + b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
+}
+
+__device__ __forceinline__ float sift_expf(float x) { return (float)exp((double)x); }
+
+// grid (cand_cap / 4, n), block 256 = 4 waves, one candidate per wave
+__global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams sp, const float* __restrict__ gauss, const float* __restrict__ dogp,
+                                                          const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_count,
+                                                          SiftRaw* __restrict__ raw, uint32_t* __restrict__ raw_count, uint32_t* __restrict__ flags) {
+    __shared__ unsigned long long s_hist[4][SIFT_BINS];
+    __shared__ float s_sm[4][SIFT_BINS];
+    const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ci = blockIdx.x * 4 + wave;
+    const uint32_t ncand = min(cand_count[f], (uint32_t)sp.cand_cap);
+    if (ci >= ncand) return;                                            // (wave-uniform; no block barrier below)
+    const uint32_t cw = cand[(size_t)f * sp.cand_cap + ci];
+    const int octv = (int)(cw >> 28);
+    int layer = (int)((cw >> 26) & 3), r = (int)((cw >> 13) & 8191), c = (int)(cw & 8191);
+    const int w = g.ow[octv], h = g.oh[octv];
+    const int64_t lsz = (int64_t)w * h;
+    const float* dbase = dogp + (int64_t)f * g.d_frame + g.d_ofs[octv];
+    const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int it = 0;
+    bool ok = true;
+    for (; it < SIFT_STEPS; ++it) {
+        const float* img = dbase + lsz * layer;
+        const float* prev = img - lsz;
+        const float* next = img + lsz;
+        const int64_t p = (int64_t)r * w + c;
+        const float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + w] - img[p - w]) * deriv_scale, (next[p] - prev[p]) * deriv_scale};
+        const float v2 = img[p] * 2;
+        const float dxx = (img[p + 1] + img[p - 1] - v2) * second_deriv_scale;
+        const float dyy = (img[p + w] + img[p - w] - v2) * second_deriv_scale;
+        const float dss = (next[p] + prev[p] - v2) * second_deriv_scale;
+        const float dxy = (img[p + w + 1] - img[p + w - 1] - img[p - w + 1] + img[p - w - 1]) * cross_deriv_scale;
+        const float dxs = (next[p + 1] - next[p - 1] - prev[p + 1] + prev[p - 1]) * cross_deriv_scale;
+        const float dys = (next[p + w] - next[p - w] - prev[p + w] + prev[p - w]) * cross_deriv_scale;
+        const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float X[3];
+        sift_solve3(H, dD, X);
+        xi = -X[2]; xr = -X[1]; xc = -X[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        const float big = (float)(INT_MAX / 3);
+        if (fabsf(xi) > big || fabsf(xr) > big || fabsf(xc) > big) { ok = false; break; }
+        c += (int)rintf(xc); r += (int)rintf(xr); layer += (int)rintf(xi);
+        if (layer < 1 || layer > SIFT_NL || c < SIFT_BORDER || c >= w - SIFT_BORDER || r < SIFT_BORDER || r >= h - SIFT_BORDER) { ok = false; break; }
+    }
+    if (!ok || it >= SIFT_STEPS) return;
+    slideo_keypoint kpt;
+    {
+        const float* img = dbase + lsz * layer;
+        const float* prev = img - lsz;
+        const float* next = img + lsz;
+        const int64_t p = (int64_t)r * w + c;
+        const float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + w] - img[p - w]) * deriv_scale, (next[p] - prev[p]) * deriv_scale};
+        const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
+        const float contr = img[p] * img_scale + t * 0.5f;
+        if (fabsf(contr) * SIFT_NL < sp.contrast_threshold) return;
+        const float v2 = img[p] * 2.f;
+        const float dxx = (img[p + 1] + img[p - 1] - v2) * second_deriv_scale;
+        const float dyy = (img[p + w] + img[p - w] - v2) * second_deriv_scale;
+        const float dxy = (img[p + w + 1] - img[p + w - 1] - img[p - w + 1] + img[p - w - 1]) * cross_deriv_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        const float et = sp.edge_threshold;
+        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) return;
+        kpt.x = ((float)c + xc) * (float)(1 << octv);
+        kpt.y = ((float)r + xr) * (float)(1 << octv);
+        kpt.octave = octv + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
+        kpt.size = sp.sigma * (float)pow(2.0, (double)(((float)layer + xi) / SIFT_NL)) * (float)(1 << octv) * 2;      // (f64 pow rounded to f32, as the oracle)
+        kpt.response = fabsf(contr);
+        kpt.angle = 0;
+    }
+    // orientation histogram on the Gaussian layer the extremum ended in
+    const float scl_octv = kpt.size * 0.5f / (float)(1 << octv);
+    const int radius = (int)rintf(4.5f * scl_octv);
+    const float sigma = 1.5f * scl_octv;
+    const float expf_scale = -1.f / (2.f * sigma * sigma);
+    const float* gimg = gauss + (int64_t)f * g.g_frame + g.g_ofs[octv] + lsz * layer;
+    if (lane < SIFT_BINS) s_hist[wave][lane] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    const int side = 2 * radius + 1;
+    for (int s = lane; s < side * side; s += 64) {
+        const int i = s / side - radius, j = s - (s / side) * side - radius;
+        const int y = r + i, x = c + j;
+        if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
+        const int64_t p = (int64_t)y * w + x;
+        const float dx = gimg[p + 1] - gimg[p - 1], dy = gimg[p - w] - gimg[p + w];
+        const float wgt = sift_expf((float)(i * i + j * j) * expf_scale);
+        const float ori = fast_atan2f_cv(dy, dx, sp.atan_fma != 0), mag = sqrtf(dx * dx + dy * dy);
+        int bin = (int)rintf((SIFT_BINS / 360.f) * ori);
+        if (bin >= SIFT_BINS) bin -= SIFT_BINS;
+        if (bin < 0) bin += SIFT_BINS;
+        atomicAdd(&s_hist[wave][bin], (unsigned long long)(long long)llrint((double)(wgt * mag) * SIFT_FIXD));
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float hv = 0;
+    if (lane < SIFT_BINS) {
+        auto th = [&](int i) -> float { return (float)((double)(long long)s_hist[wave][(i + SIFT_BINS) % SIFT_BINS] / SIFT_FIXD); };
+        hv = (th(lane - 2) + th(lane + 2)) * (1.f / 16.f) + (th(lane - 1) + th(lane + 1)) * (4.f / 16.f) + th(lane) * (6.f / 16.f);
+        s_sm[wave][lane] = hv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float omax = lane < SIFT_BINS ? hv : 0.f;               // (hist >= 0: the maximum over the 36 bins)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d));
+    const float mag_thr = omax * 0.8f;
+    if (lane < SIFT_BINS) {
+        const int n = SIFT_BINS, j = lane;
+        const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+        const float hl = s_sm[wave][l], hr = s_sm[wave][r2], hj = hv;
+        if (hj > hl && hj > hr && hj >= mag_thr) {
+            float bin = (float)j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+            bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+            slideo_keypoint k2 = kpt;
+            k2.angle = 360.f - (float)((360.f / n) * bin);
+            if (fabsf(k2.angle - 360.f) < FLT_EPSILON) k2.angle = 0.f;
+            const uint32_t slot = atomicAdd(&raw_count[f], 1u);
+            if (slot < (uint32_t)sp.raw_cap) {
+                SiftRaw o;
+                o.kp = k2;
+                o.key = ((uint64_t)octv << 34) | ((uint64_t)layer << 32) | ((uint64_t)r << 19) | ((uint64_t)c << 6) | (uint64_t)j;
+                raw[(size_t)f * sp.raw_cap + slot] = o;
+            } else atomicOr(flags, 32u);
+        }
+    }
+}
+
+// One block of 1024 per frame.  items: [n][raw_cap] u64 workspace; kept: [n][raw_cap] u32 (slots of the kept keypoints in
+// canonical order); kept_count[n].
+__global__ __launch_bounds__(1024) void sift_select_kernel(SiftParams sp, const SiftRaw* __restrict__ raw, const uint32_t* __restrict__ raw_count,
+                                                           uint64_t* __restrict__ items, uint32_t* __restrict__ kept, uint32_t* __restrict__ kept_count) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_prefix, s_need, s_n;
+    __shared__ uint32_t s_scan[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = min(raw_count[f], (uint32_t)sp.raw_cap);
+    const SiftRaw* R = raw + (size_t)f * sp.raw_cap;
+    uint64_t* a = items + (size_t)f * sp.raw_cap;
+    for (uint32_t i = tid; i < n; i += 1024) a[i] = (R[i].key << 16) | (uint64_t)i;          // (raw_cap <= 65536)
+    __syncthreads();
+    // canonical order: the bitonic network of sort_global_kernel on the frame's items (virtual +infinity tail)
+    uint32_t np = 2;
+    while (np < n) np <<= 1;
+    auto cmpx = [&](uint32_t lo, uint32_t hi) {
+        if (hi < n) {
+            const uint64_t x = a[lo], y = a[hi];
+            if (x > y) { a[lo] = y; a[hi] = x; }
+        }
+    };
+    if (n > 1)
+        for (uint32_t k = 2; k <= np; k <<= 1) {
+            const uint32_t hk = k >> 1;
+            for (uint32_t i = tid; i < np / 2; i += 1024) { const uint32_t base = (i / hk) * k, t = i % hk; cmpx(base + t, base + k - 1 - t); }
+            __syncthreads();
+            for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < np / 2; i += 1024) { const uint32_t lo = (i / j) * 2 * j + (i % j); cmpx(lo, lo + j); }
+                __syncthreads();
+            }
+        }
+    // unique keys (equal keys = two extrema refined to the same keypoint: exact duplicates); uniq(i) = first of its run
+    auto uniq = [&](uint32_t i) -> bool { return i == 0 || (a[i] >> 16) != (a[i - 1] >> 16); };
+    auto resp_bits = [&](uint32_t i) -> uint32_t { return __float_as_uint(R[(uint32_t)(a[i] & 0xFFFFu)].kp.response); };   // response >= 0: bit order = value order
+    // number of unique keypoints
+    uint32_t cnt = 0;
+    for (uint32_t i = tid; i < n; i += 1024) cnt += uniq(i) ? 1u : 0u;
+    s_scan[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (int i = 0; i < 1024; ++i) t += s_scan[i]; s_n = t; s_prefix = 0; s_need = (uint32_t)max(sp.nfeatures, 0); }
+    __syncthreads();
+    uint32_t thr_bits = 0;                                 // keep response >= thr
+    if (sp.nfeatures > 0 && s_n > (uint32_t)sp.nfeatures) {
+        // radix select of the nfeatures-th largest response: 4 passes of 8 bits from the top
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            for (uint32_t i = tid; i < n; i += 1024)
+                if (uniq(i)) {
+                    const uint32_t b = resp_bits(i);
+                    if (pass == 0 || (b >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(b >> shift) & 255u], 1u);
+                }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t need = s_need, d = 255;
+                for (;; --d) { if (s_hist[d] >= need) break; need -= s_hist[d]; if (d == 0) break; }
+                s_need = need; s_prefix = prefix | (d << shift);
+            }
+            __syncthreads();
+        }
+        thr_bits = s_prefix;
+    }
+    // compaction in canonical order
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t b0 = min(n, tid * per), b1 = min(n, b0 + per);
+    cnt = 0;
+    for (uint32_t i = b0; i < b1; ++i) cnt += (uniq(i) && resp_bits(i) >= thr_bits) ? 1u : 0u;
+    s_scan[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; ++i) { const uint32_t v = s_scan[i]; s_scan[i] = run; run += v; } kept_count[f] = run; }
+    __syncthreads();
+    uint32_t o = s_scan[tid];
+    uint32_t* K = kept + (size_t)f * sp.raw_cap;
+    for (uint32_t i = b0; i < b1; ++i)
+        if (uniq(i) && resp_bits(i) >= thr_bits) K[o++] = (uint32_t)(a[i] & 0xFFFFu);
+}
+
+// grid (ceil(total_cap / 4)), block 256 = 4 waves, one kept keypoint per wave; qofs from scan_kernel over kept_count.
+// Writes the keypoint (scaled back to the input image) and its 128 descriptor bytes.
+__global__ __launch_bounds__(256) void sift_describe_kernel(SiftGeom g, SiftParams sp, int nframes, const float* __restrict__ gauss,
+                                                            const SiftRaw* __restrict__ raw, const uint32_t* __restrict__ kept,
+                                                            const uint32_t* __restrict__ qofs, slideo_keypoint* __restrict__ kp_out,
+                                                            uint8_t* __restrict__ desc_out) {
+    __shared__ unsigned long long s_h[4][360];
+    __shared__ float s_v[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t gi = blockIdx.x * 4 + wave;
+    const uint32_t total = qofs[nframes];
+    if (gi >= total) return;
+    int f = 0;
+    { int lo = 0, hi = nframes; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qofs[mid] <= gi) lo = mid; else hi = mid; } f = lo; }
+    const uint32_t slot = kept[(size_t)f * sp.raw_cap + (gi - qofs[f])];
+    slideo_keypoint k = raw[(size_t)f * sp.raw_cap + slot].kp;
+    const int octave = k.octave & 255, layer = (k.octave >> 8) & 255;
+    const float scale = 1.f / (float)(1 << octave);
+    const float size = k.size * scale;
+    float ori = 360.f - k.angle;
+    if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
+    const float ptx = k.x * scale, pty = k.y * scale, scl = size * 0.5f;
+    const int w = g.ow[octave], h = g.oh[octave];
+    const float* img = gauss + (int64_t)f * g.g_frame + g.g_ofs[octave] + (int64_t)w * h * layer;
+    constexpr int d = 4, n = 8;
+    const int px = (int)rintf(ptx), py = (int)rintf(pty);
+    float cos_t = (float)cos((double)(ori * (float)(3.14159265358979323846 / 180)));
+    float sin_t = (float)sin((double)(ori * (float)(3.14159265358979323846 / 180)));
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = 3.f * scl;
+    int radius = (int)rintf(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
+    cos_t /= hist_width; sin_t /= hist_width;
+    for (int i = lane; i < 360; i += 64) s_h[wave][i] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int side = 2 * radius + 1;
+    for (int s = lane; s < side * side; s += 64) {
+        const int i = s / side - radius, j = s - (s / side) * side - radius;
+        const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
+        float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+        const int r = py + i, c = px + j;
+        if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
+        const int64_t p = (int64_t)r * w + c;
+        const float dx = img[p + 1] - img[p - 1], dy = img[p - w] - img[p + w];
+        const float wg = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+        const float o = fast_atan2f_cv(dy, dx, sp.atan_fma != 0);
+        float obin = (o - ori) * bins_per_rad;
+        const float mag = sqrtf(dx * dx + dy * dy) * wg;
+        const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+        int o0 = (int)floorf(obin);
+        rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
+        if (o0 < 0) o0 += n;
+        if (o0 >= n) o0 -= n;
+        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+        const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+        const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+        const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+        auto add = [&](int kx, float v) { atomicAdd(&s_h[wave][kx], (unsigned long long)(long long)llrint((double)v * SIFT_FIXD)); };
+        add(idx, v_rco000); add(idx + 1, v_rco001); add(idx + (n + 2), v_rco010); add(idx + (n + 3), v_rco011);
+        add(idx + (d + 2) * (n + 2), v_rco100); add(idx + (d + 2) * (n + 2) + 1, v_rco101);
+        add(idx + (d + 3) * (n + 2), v_rco110); add(idx + (d + 3) * (n + 2) + 1, v_rco111);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int e = lane; e < 128; e += 64) {
+        const int cell = e >> 3, kk = e & 7, i = cell >> 2, j = cell & 3;
+        const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+        long long hq = (long long)s_h[wave][idx + kk];
+        if (kk < 2) hq += (long long)s_h[wave][idx + n + kk];           // circular orientation bins
+        s_v[wave][e] = (float)((double)hq / SIFT_FIXD);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the two norms in the oracle's serial order (every lane the same 256 adds)
+    float nrm2 = 0;
+    for (int e = 0; e < 128; ++e) { const float v = s_v[wave][e]; nrm2 += v * v; }
+    const float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0;
+    for (int e = 0; e < 128; ++e) { const float v = fminf(s_v[wave][e], thr); nrm2 += v * v; }
+    nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+    for (int e = lane; e < 128; e += 64) {
+        const int q = (int)rintf(fminf(s_v[wave][e], thr) * nrm2);
+        desc_out[(size_t)gi * 128 + e] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+    if (lane == 0) {
+        k.octave = (k.octave & ~255) | ((k.octave - 1) & 255);
+        k.x *= 0.5f; k.y *= 0.5f; k.size *= 0.5f;
+        kp_out[gi] = k;
+    }
+}
+
+}  // namespace slideo

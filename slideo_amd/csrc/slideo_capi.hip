@@ -22,6 +22,7 @@
 #include "slideo_amd.h"
 #include "verify.hip.h"
 #include "homography.hip.h"
+#include "sift.hip.h"
 
 using namespace slideo;
 
@@ -152,6 +153,7 @@ struct slideo_matcher {
     int next_slot = 0;
     int64_t next_ticket = 1;
     DevBuf d_small, d_ssd, d_prev_small, d_tapq, d_tapt, d_tapidx, d_tapdist;
+    struct SiftWs { DevBuf base, gauss, dog, cand, counts, raw, items, kept, qofs, info, kp, desc; } sift;     // csrc/sift.hip.h
 
     // stage profiling (HIP events on the launch streams)
     bool profiling = false;
@@ -1620,6 +1622,244 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
     HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    API_CATCH(m)
+}
+
+// ---- SIFT (csrc/sift.hip.h) --------------------------------------------------------------------------------------------
+namespace {
+
+SiftGeom sift_geom(int w, int h) {
+    SiftGeom g{};
+    g.w = w; g.h = h;
+    int bw = 2 * w, bh = 2 * h;
+    g.n_oct = std::max(0, (int)std::lrint(std::log((double)std::min(bw, bh)) / std::log(2.) - 2) + 1);
+    if (g.n_oct > SIFT_MAX_OCT) g.n_oct = SIFT_MAX_OCT;
+    int64_t go = 0, dofs = 0;
+    for (int o = 0; o < g.n_oct; ++o) {
+        g.ow[o] = bw; g.oh[o] = bh; g.g_ofs[o] = go; g.d_ofs[o] = dofs;
+        go += (int64_t)bw * bh * (SIFT_NL + 3); dofs += (int64_t)bw * bh * (SIFT_NL + 2);
+        bw /= 2; bh /= 2;
+        if (bw < 1 || bh < 1) { g.n_oct = o + 1; break; }
+    }
+    g.g_frame = go; g.d_frame = dofs;
+    return g;
+}
+
+SiftTaps sift_taps(double sigma) {          // getGaussianKernel(cvRound(8 sigma + 1) | 1, sigma) in f32 (oracle sift_gauss_kernel)
+    SiftTaps t{};
+    const int n = (int)std::lrint(sigma * 4 * 2 + 1) | 1;
+    if (n > SIFT_MAX_TAPS - 1) fail(SLIDEO_ERR_UNSUPPORTED, "SIFT blur of sigma %.3f needs %d taps (> %d)", sigma, n, SIFT_MAX_TAPS - 1);
+    t.n = n;
+    double kd[SIFT_MAX_TAPS], sum = 0;
+    const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; kd[i] = std::exp(s2 * x * x); sum += kd[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) t.k[i] = (float)(kd[i] * sum);
+    return t;
+}
+
+void sift_check_cfg(const slideo_sift_config* sc, int w, int h) {
+    if (!sc) fail(SLIDEO_ERR_INVALID_ARG, "null SIFT config");
+    if (sc->n_octave_layers != SIFT_NL) fail(SLIDEO_ERR_UNSUPPORTED, "SIFT n_octave_layers must be %d", SIFT_NL);
+    if (!(sc->sigma > 0.5) || !(sc->contrast_threshold >= 0) || !(sc->edge_threshold > 0) || sc->nfeatures < 0) fail(SLIDEO_ERR_INVALID_ARG, "bad SIFT config");
+    if (w > 4095 || h > 4095) fail(SLIDEO_ERR_UNSUPPORTED, "SIFT image %dx%d: sides must be <= 4095", w, h);
+}
+
+void sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n,
+                      const SiftTaps& tp, hipStream_t st) {
+    const dim3 grid(cdiv(w, SIFT_BT_W) * cdiv(h, SIFT_BT_H), n);
+    if (m->cfg.ocv.blur != 1) sift_blur_kernel<true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    else sift_blur_kernel<false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    check_launch("sift_blur_kernel");
+}
+
+// Gaussian + DoG pyramids of nb frames (device) into m->sift.gauss / dog
+void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, int h, int stride, int64_t fs, const slideo_sift_config& sc,
+                   const SiftGeom& g, hipStream_t st) {
+    auto& W = m->sift;
+    const int64_t base_frame = (int64_t)g.ow[0] * g.oh[0];
+    W.base.reserve((size_t)base_frame * nb * 4);
+    W.gauss.reserve((size_t)g.g_frame * nb * 4 + 64);
+    W.dog.reserve((size_t)g.d_frame * nb * 4 + 64);
+    const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
+    sift_base_kernel<<<dim3(cdiv(2 * w, 256), 2 * h, nb), 256, 0, st>>>(frames_dev, fs, stride, w, h, gc, W.base.as<float>(), base_frame);
+    check_launch("sift_base_kernel");
+    const float sigma = (float)sc.sigma;
+    const float sig_diff = std::sqrt(std::max(sigma * sigma - 0.5f * 0.5f * 4, 0.01f));
+    float* G = W.gauss.as<float>();
+    float* D = W.dog.as<float>();
+    sift_blur_launch(m, W.base.as<float>(), base_frame, G + g.g_ofs[0], g.g_frame, nullptr, 0, g.ow[0], g.oh[0], nb, sift_taps(sig_diff), st);
+    double sig[SIFT_NL + 3];
+    sig[0] = sc.sigma;
+    const double k = std::pow(2., 1. / SIFT_NL);
+    for (int i = 1; i < SIFT_NL + 3; ++i) { const double sp = std::pow(k, (double)(i - 1)) * sc.sigma, stt = sp * k; sig[i] = std::sqrt(stt * stt - sp * sp); }
+    for (int o = 0; o < g.n_oct; ++o) {
+        const int ow = g.ow[o], oh = g.oh[o];
+        const int64_t lsz = (int64_t)ow * oh;
+        if (o > 0) {
+            sift_half_kernel<<<dim3(cdiv(ow, 256), oh, nb), 256, 0, st>>>(G + g.g_ofs[o - 1] + (int64_t)g.ow[o - 1] * g.oh[o - 1] * SIFT_NL, g.g_frame, g.ow[o - 1],
+                                                                          G + g.g_ofs[o], g.g_frame, ow, oh);
+            check_launch("sift_half_kernel");
+        }
+        for (int i = 1; i < SIFT_NL + 3; ++i)
+            sift_blur_launch(m, G + g.g_ofs[o] + lsz * (i - 1), g.g_frame, G + g.g_ofs[o] + lsz * i, g.g_frame, D + g.d_ofs[o] + lsz * (i - 1), g.d_frame,
+                             ow, oh, nb, sift_taps(sig[i]), st);
+    }
+}
+
+// SIFT of n device frames: results appended at kp_dev / desc_dev from row `row0`; per-frame counts into counts_host[0..n).
+// Returns the rows written.
+int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t fs, const slideo_sift_config& sc,
+                   int64_t row0, int64_t capacity_total, slideo_keypoint* kp_dev, uint8_t* desc_dev, uint32_t* counts_host, hipStream_t st) {
+    auto& W = m->sift;
+    const SiftGeom g = sift_geom(w, h);
+    SiftParams sp{};
+    sp.nfeatures = sc.nfeatures; sp.cand_cap = 1 << 16; sp.raw_cap = 1 << 15;
+    sp.contrast_threshold = (float)sc.contrast_threshold; sp.edge_threshold = (float)sc.edge_threshold; sp.sigma = (float)sc.sigma;
+    sp.threshold = (int)std::floor(0.5 * sc.contrast_threshold / SIFT_NL * 255);
+    sp.atan_fma = m->cfg.ocv.atan; sp.blur_fma = m->cfg.ocv.blur != 1;
+    // frames per pass under a 24 GB budget for the pyramids (486 MB per 1080p frame)
+    const size_t per = ((size_t)g.g_frame + (size_t)g.d_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
+    const int nb_max = (int)std::max<size_t>(1, ((size_t)24 << 30) / std::max<size_t>(per, 1));
+    int64_t rows = 0;
+    for (int f0 = 0; f0 < n; f0 += nb_max) {
+        const int nb = std::min(nb_max, n - f0);
+        sift_pyramids(m, frames_dev + (int64_t)f0 * fs, nb, w, h, stride, fs, sc, g, st);
+        W.cand.reserve((size_t)nb * sp.cand_cap * 4);
+        W.counts.reserve((size_t)nb * 3 * 4 + 16);                 // cand_count | raw_count | kept_count
+        W.raw.reserve((size_t)nb * sp.raw_cap * sizeof(SiftRaw));
+        W.items.reserve((size_t)nb * sp.raw_cap * 8);
+        W.kept.reserve((size_t)nb * sp.raw_cap * 4);
+        W.qofs.reserve((size_t)(nb + 1) * 4); W.info.reserve(64);
+        uint32_t* cand_count = W.counts.as<uint32_t>();
+        uint32_t* raw_count = cand_count + nb;
+        uint32_t* kept_count = raw_count + nb;
+        uint32_t* flags = W.info.as<uint32_t>() + 4;
+        HIP_CHECK(hipMemsetAsync(W.counts.p, 0, (size_t)nb * 3 * 4, st));
+        HIP_CHECK(hipMemsetAsync(W.info.p, 0, 32, st));
+        for (int o = 0; o < g.n_oct; ++o) {
+            if (g.ow[o] <= 2 * SIFT_BORDER || g.oh[o] <= 2 * SIFT_BORDER) continue;
+            sift_extrema_kernel<<<dim3(cdiv(g.ow[o], 64), cdiv(g.oh[o], 4), nb * SIFT_NL), 256, 0, st>>>(g, sp, o, W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
+            check_launch("sift_extrema_kernel");
+        }
+        // (the candidate count is on the device: the grid covers the capacity, surplus waves leave at once)
+        std::vector<uint32_t> hc((size_t)nb * 3);
+        HIP_CHECK(hipMemcpyAsync(hc.data(), W.counts.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        uint32_t maxc = 0;
+        for (int i = 0; i < nb; ++i) maxc = std::max(maxc, std::min(hc[i], (uint32_t)sp.cand_cap));
+        if (maxc > 0) {
+            sift_refine_kernel<<<dim3(cdiv((int)maxc, 4), nb), 256, 0, st>>>(g, sp, W.gauss.as<float>(), W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count,
+                                                                            W.raw.as<SiftRaw>(), raw_count, flags);
+            check_launch("sift_refine_kernel");
+        }
+        sift_select_kernel<<<nb, 1024, 0, st>>>(sp, W.raw.as<SiftRaw>(), raw_count, W.items.as<uint64_t>(), W.kept.as<uint32_t>(), kept_count);
+        check_launch("sift_select_kernel");
+        scan_kernel<<<1, 1024, 0, st>>>(kept_count, nb, W.qofs.as<uint32_t>(), W.info.as<uint32_t>());
+        check_launch("scan_kernel");
+        uint32_t info[6];
+        HIP_CHECK(hipMemcpyAsync(info, W.info.p, 24, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hc.data(), kept_count, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (info[4] & 16u) fail(SLIDEO_ERR_CAPACITY, "SIFT: more than %d scale-space extrema in a frame", sp.cand_cap);
+        if (info[4] & 32u) fail(SLIDEO_ERR_CAPACITY, "SIFT: more than %d keypoints in a frame before retainBest", sp.raw_cap);
+        const uint32_t total = info[0];
+        for (int i = 0; i < nb; ++i) counts_host[f0 + i] = hc[i];
+        if (row0 + rows + (int64_t)total > capacity_total) { rows += total; continue; }      // (keeps counting: the caller learns the size it needs)
+        if (total > 0) {
+            sift_describe_kernel<<<cdiv((int)total, 4), 256, 0, st>>>(g, sp, nb, W.gauss.as<float>(), W.raw.as<SiftRaw>(), W.kept.as<uint32_t>(), W.qofs.as<uint32_t>(),
+                                                                      kp_dev + row0 + rows, desc_dev + (size_t)(row0 + rows) * 128);
+            check_launch("sift_describe_kernel");
+        }
+        rows += total;
+    }
+    return rows;
+}
+
+}  // namespace
+
+void slideo_sift_config_default(slideo_sift_config* c) {
+    if (!c) return;
+    c->nfeatures = 0; c->n_octave_layers = 3; c->contrast_threshold = 0.04; c->edge_threshold = 10; c->sigma = 1.6;
+}
+
+int32_t slideo_sift_frames_dev(slideo_matcher* m, const slideo_sift_config* cfg, int32_t n_frames, const uint8_t* frames_dev, int32_t width,
+                               int32_t height, int32_t stride_bytes, int64_t frame_stride_bytes, int64_t capacity_total, void* kp_dev,
+                               void* desc_dev, uint32_t* qofs_out, float* kernel_ms) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (n_frames < 0 || !qofs_out || (n_frames > 0 && (!frames_dev || !kp_dev || !desc_dev))) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    validate_image(width, height, stride_bytes);
+    sift_check_cfg(cfg, width, height);
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    if (kernel_ms) { *kernel_ms = 0.f; HIP_CHECK(hipEventRecord(S.ev[0], S.st)); }
+    std::vector<uint32_t> counts((size_t)std::max(n_frames, 1), 0);
+    const int64_t rows = sift_batch(m, frames_dev, n_frames, width, height, stride_bytes, frame_stride_bytes, *cfg, 0, capacity_total,
+                                    static_cast<slideo_keypoint*>(kp_dev), static_cast<uint8_t*>(desc_dev), counts.data(), S.st);
+    if (kernel_ms) HIP_CHECK(hipEventRecord(S.ev[1], S.st));
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    if (kernel_ms) HIP_CHECK(hipEventElapsedTime(kernel_ms, S.ev[0], S.ev[1]));
+    qofs_out[0] = 0;
+    for (int i = 0; i < n_frames; ++i) qofs_out[i + 1] = qofs_out[i] + counts[i];
+    if (rows > capacity_total) fail(SLIDEO_ERR_CAPACITY, "SIFT found %lld keypoints, capacity %lld", (long long)rows, (long long)capacity_total);
+    API_CATCH(m)
+}
+
+int32_t slideo_sift_bgr8(slideo_matcher* m, const slideo_sift_config* cfg, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride_bytes,
+                         slideo_keypoint* kp, uint8_t* desc128, int32_t capacity, int32_t* n_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!bgr || !n_out) fail(SLIDEO_ERR_INVALID_ARG, "null image/n_out");
+    validate_image(width, height, stride_bytes);
+    sift_check_cfg(cfg, width, height);
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    const size_t fb = (size_t)height * stride_bytes;
+    m->kept.valid = false;
+    S.d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, S.st));
+    const int64_t cap = std::max<int64_t>(capacity, 0);
+    m->sift.kp.reserve(std::max<size_t>((size_t)cap * sizeof(slideo_keypoint), 64));
+    m->sift.desc.reserve(std::max<size_t>((size_t)cap * 128, 128));
+    uint32_t cnt = 0;
+    const int64_t rows = sift_batch(m, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, *cfg, 0, cap,
+                                    m->sift.kp.as<slideo_keypoint>(), m->sift.desc.as<uint8_t>(), &cnt, S.st);
+    *n_out = (int32_t)rows;
+    if (rows > cap) fail(SLIDEO_ERR_CAPACITY, "image has %lld SIFT keypoints, capacity %d", (long long)rows, capacity);
+    if (rows > 0) {
+        if (kp) HIP_CHECK(hipMemcpyAsync(kp, m->sift.kp.p, (size_t)rows * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, S.st));
+        if (desc128) HIP_CHECK(hipMemcpyAsync(desc128, m->sift.desc.p, (size_t)rows * 128, hipMemcpyDeviceToHost, S.st));
+    }
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    API_CATCH(m)
+}
+
+int32_t slideo_sift_layer_bgr8(slideo_matcher* m, const slideo_sift_config* cfg, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride_bytes,
+                               int32_t octave, int32_t layer, int32_t dog, float* out, int64_t out_capacity, int32_t* lw, int32_t* lh) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!bgr || !out || !lw || !lh) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    validate_image(width, height, stride_bytes);
+    sift_check_cfg(cfg, width, height);
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    const SiftGeom g = sift_geom(width, height);
+    if (octave < 0 || octave >= g.n_oct || layer < 0 || layer >= (dog ? SIFT_NL + 2 : SIFT_NL + 3)) fail(SLIDEO_ERR_INVALID_ARG, "no such pyramid layer");
+    const size_t fb = (size_t)height * stride_bytes;
+    m->kept.valid = false;
+    S.d_stage.reserve(fb + 16);
+    HIP_CHECK(hipMemcpyAsync(S.d_stage.p, bgr, fb, hipMemcpyHostToDevice, S.st));
+    sift_pyramids(m, S.d_stage.as<uint8_t>(), 1, width, height, stride_bytes, (int64_t)fb, *cfg, g, S.st);
+    const int64_t lsz = (int64_t)g.ow[octave] * g.oh[octave];
+    *lw = g.ow[octave]; *lh = g.oh[octave];
+    if (lsz > out_capacity) fail(SLIDEO_ERR_CAPACITY, "layer has %lld values", (long long)lsz);
+    const float* src = dog ? m->sift.dog.as<float>() + g.d_ofs[octave] + lsz * layer : m->sift.gauss.as<float>() + g.g_ofs[octave] + lsz * layer;
+    HIP_CHECK(hipMemcpyAsync(out, src, (size_t)lsz * 4, hipMemcpyDeviceToHost, S.st));
+    HIP_CHECK(hipStreamSynchronize(S.st));
     API_CATCH(m)
 }
 
