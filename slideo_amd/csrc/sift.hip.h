@@ -132,6 +132,84 @@ __global__ __launch_bounds__(256) void sift_blur_kernel(const float* __restrict_
     }
 }
 
+// The same filter for a tap count known at compile time (N = 7 .. 27, what cvRound(8 sigma + 1) | 1 gives for the pyramid's sigmas):
+// register-blocked sliding windows.  Row pass: a thread computes 8 horizontally adjacent outputs of one row from the N + 7 inputs
+// it reads once (8 N fused multiply-adds per N + 7 LDS reads instead of N per output); column pass: 8 vertically adjacent
+// outputs of one column from 8 + 2 R row-pass values held in registers.  Per output the accumulation order is the generic
+// kernel's (tap 0 .. N - 1; centre, then pairs outward): bit-identical results.  Tile 64 x 64; LDS pitches are 1 (mod 32) so
+// that the 8 x 8 (segment, row) lanes of a wave spread over all banks; the taps live in VGPRs (a scalar operand halves the
+// FMA issue rate on this chip).
+template <int N, bool FMA>
+__global__ __launch_bounds__(256) void sift_blur_fast_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
+                                                             float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp) {
+    constexpr int R = N / 2, TW = 64, TH = 64, IW = TW + 2 * R, IH = TH + 2 * R;
+    constexpr int PIN = ((IW + 30) / 32) * 32 + 1, PROW = TW + 1;
+    constexpr int IN_DW = ((IH * PIN + 63) / 64) * 64;              // whole wave-instructions of the LDS-DMA fill
+    __shared__ float s_in[IN_DW];
+    __shared__ float s_row[IH * PROW];
+    const int tiles_x = (w + TW - 1) / TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* S = src + (int64_t)blockIdx.y * src_frame;
+    // The input tile goes global -> LDS by LDS-DMA (global_load_lds: no staging registers, every wave's ~35 requests in flight at
+    // once; a loop of load -> store pairs waited for each round trip and a tile took 24 us).  One instruction fills 64
+    // consecutive LDS dwords from 64 per-lane addresses: lane l of chunk `base` owns LDS dword base + l = (row, column) of the
+    // padded tile; pad columns and the tail re-read a valid pixel.
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int base = wave * 64; base < IN_DW; base += 256) {
+            const int L = base + lane;
+            const int yy = min(L / PIN, IH - 1), xx = min(L - (L / PIN) * PIN, IW - 1);
+            const float* ga = S + (int64_t)sift_reflect101(y0 - R + yy, h) * w + sift_reflect101(x0 - R + xx, w);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga, (__attribute__((address_space(3))) void*)&s_in[base], 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float k[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { k[j] = tp.k[j]; asm volatile("" : "+v"(k[j])); }
+    __syncthreads();
+    auto mad = [](float a, float b, float c) -> float { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
+    for (int task = threadIdx.x; task < IH * (TW / 8); task += 256) {
+        const int row = task >> 3, xg = task & 7;
+        const float* p = s_in + row * PIN + xg * 8;
+        float acc[8];
+#pragma unroll
+        for (int t = 0; t < N + 7; ++t) {
+            const float v = p[t];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int j = t - o;
+                if (j == 0) acc[o] = k[0] * v;
+                else if (j > 0 && j < N) acc[o] = mad(k[j], v, acc[o]);
+            }
+        }
+        float* q = s_row + row * PROW + xg * 8;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) q[o] = acc[o];
+    }
+    __syncthreads();
+    float* D = dst + (int64_t)blockIdx.y * dst_frame;
+    for (int task = threadIdx.x; task < TW * (TH / 8); task += 256) {
+        const int x = task & (TW - 1), yg = task / TW;
+        const int gx = x0 + x;
+        float c[8 + 2 * R];
+#pragma unroll
+        for (int t = 0; t < 8 + 2 * R; ++t) c[t] = s_row[(yg * 8 + t) * PROW + x];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float sacc = k[R] * c[o + R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) sacc = mad(k[R + j], c[o + R + j] + c[o + R - j], sacc);
+            const int gy = y0 + yg * 8 + o;
+            if (gx < w && gy < h) {
+                D[(int64_t)gy * w + gx] = sacc;
+                if (dog) dog[(int64_t)blockIdx.y * dog_frame + (int64_t)gy * w + gx] = sacc - s_in[(yg * 8 + o + R) * PIN + x + R];
+            }
+        }
+    }
+}
+
 // dst(x, y) = src(2x, 2y).  grid (ceil(dw / 256), dh, n)
 __global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict__ src, int64_t src_frame, int sw, float* __restrict__ dst,
                                                         int64_t dst_frame, int dw, int dh) {
@@ -140,44 +218,57 @@ __global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict_
     dst[(int64_t)blockIdx.z * dst_frame + (int64_t)y * dw + x] = src[(int64_t)blockIdx.z * src_frame + (int64_t)(2 * y) * sw + 2 * x];
 }
 
-// candidate = o << 28 | layer << 26 | r << 13 | c.  grid (ceil(ow / 64), ceil(oh / 4), n * 3 layers), block 256 (64 x 4)
+// candidate = o << 28 | layer << 26 | r << 13 | c.  grid (ceil(ow / 64), ceil(oh / 32), n * 3 layers), block 256 = 64 columns x 4
+// row groups, 8 rows per thread (one pixel per thread made 18 M four-instruction waves per launch: dispatch bound; the 8 values
+// of a thread are requested together, and almost every pixel ends at the threshold test).
+constexpr int SIFT_EX_ROWS = 8;
 __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParams sp, int o, const float* __restrict__ dogp,
                                                            uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t* __restrict__ flags) {
     const int f = blockIdx.z / SIFT_NL, layer = 1 + blockIdx.z % SIFT_NL;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = blockIdx.y * (4 * SIFT_EX_ROWS) + (threadIdx.x >> 6) * SIFT_EX_ROWS;
     const int w = g.ow[o], h = g.oh[o];
-    if (c < SIFT_BORDER || c >= w - SIFT_BORDER || r < SIFT_BORDER || r >= h - SIFT_BORDER) return;
+    if (c < SIFT_BORDER || c >= w - SIFT_BORDER) return;
     const int64_t lsz = (int64_t)w * h;
     const float* img = dogp + (int64_t)f * g.d_frame + g.d_ofs[o] + lsz * layer;
     const float* prev = img - lsz;
     const float* next = img + lsz;
-    const int64_t p = (int64_t)r * w + c;
-    const float val = img[p];
-    if (!(fabsf(val) > (float)sp.threshold)) return;
-    bool ext = true;
-    if (val > 0) {
+    float vals[SIFT_EX_ROWS];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int64_t q = p + dy * w + dx;
-                if (dy || dx) ext = ext && (val >= img[q]);
-                ext = ext && (val >= prev[q]) && (val >= next[q]);
-            }
-    } else {
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int64_t q = p + dy * w + dx;
-                if (dy || dx) ext = ext && (val <= img[q]);
-                ext = ext && (val <= prev[q]) && (val <= next[q]);
-            }
+    for (int i = 0; i < SIFT_EX_ROWS; ++i) {
+        const int r = r0 + i;
+        vals[i] = (r >= SIFT_BORDER && r < h - SIFT_BORDER) ? img[(int64_t)r * w + c] : 0.f;       // (0 fails the threshold test)
     }
-    if (!ext) return;
-    const uint32_t slot = atomicAdd(&cand_count[f], 1u);
-    if (slot >= (uint32_t)sp.cand_cap) { atomicOr(flags, 16u); return; }
-    cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)layer << 26) | ((uint32_t)r << 13) | (uint32_t)c;
+#pragma unroll
+    for (int i = 0; i < SIFT_EX_ROWS; ++i) {
+        const float val = vals[i];
+        if (!(fabsf(val) > (float)sp.threshold)) continue;
+        const int r = r0 + i;
+        const int64_t p = (int64_t)r * w + c;
+        bool ext = true;
+        if (val > 0) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int64_t q = p + dy * w + dx;
+                    if (dy || dx) ext = ext && (val >= img[q]);
+                    ext = ext && (val >= prev[q]) && (val >= next[q]);
+                }
+        } else {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int64_t q = p + dy * w + dx;
+                    if (dy || dx) ext = ext && (val <= img[q]);
+                    ext = ext && (val <= prev[q]) && (val <= next[q]);
+                }
+        }
+        if (!ext) continue;
+        const uint32_t slot = atomicAdd(&cand_count[f], 1u);
+        if (slot >= (uint32_t)sp.cand_cap) { atomicOr(flags, 16u); continue; }
+        cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)layer << 26) | ((uint32_t)r << 13) | (uint32_t)c;
+    }
 }
 
 // Matx33f::solve(b, DECOMP_LU) (matx.hpp Matx_FastSolveOp<float, 3, 3, 1>): Cramer's rule in f32; singular -> 0

@@ -1626,6 +1626,7 @@ int32_t slideo_knn_l2_u8(slideo_matcher* m, const uint8_t* q, int32_t nq, const 
 }
 
 // ---- SIFT (csrc/sift.hip.h) --------------------------------------------------------------------------------------------
+extern "C++" {
 namespace {
 
 SiftGeom sift_geom(int w, int h) {
@@ -1665,11 +1666,32 @@ void sift_check_cfg(const slideo_sift_config* sc, int w, int h) {
     if (w > 4095 || h > 4095) fail(SLIDEO_ERR_UNSUPPORTED, "SIFT image %dx%d: sides must be <= 4095", w, h);
 }
 
+template <int N>
+void sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n, const SiftTaps& tp, hipStream_t st) {
+    const dim3 grid(cdiv(w, 64) * cdiv(h, 64), n);
+    if (fma) sift_blur_fast_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    else sift_blur_fast_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+}
+
 void sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n,
                       const SiftTaps& tp, hipStream_t st) {
-    const dim3 grid(cdiv(w, SIFT_BT_W) * cdiv(h, SIFT_BT_H), n);
-    if (m->cfg.ocv.blur != 1) sift_blur_kernel<true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
-    else sift_blur_kernel<false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    const bool fma = m->cfg.ocv.blur != 1;
+    static const bool generic_only = std::getenv("SLIDEO_SIFT_BLUR_GENERIC") != nullptr;        // A/B and the equality test
+    bool fast = !generic_only && w >= 32 && h >= 32;
+    if (fast) {
+        switch (tp.n) {
+#define SLIDEO_SIFT_CASE(N) case N: sift_blur_fast<N>(fma, src, sf, dst, df, dog, dgf, w, h, n, tp, st); break;
+            SLIDEO_SIFT_CASE(7) SLIDEO_SIFT_CASE(9) SLIDEO_SIFT_CASE(11) SLIDEO_SIFT_CASE(13) SLIDEO_SIFT_CASE(15) SLIDEO_SIFT_CASE(17)
+            SLIDEO_SIFT_CASE(19) SLIDEO_SIFT_CASE(21) SLIDEO_SIFT_CASE(23) SLIDEO_SIFT_CASE(25) SLIDEO_SIFT_CASE(27)
+#undef SLIDEO_SIFT_CASE
+            default: fast = false;
+        }
+    }
+    if (!fast) {
+        const dim3 grid(cdiv(w, SIFT_BT_W) * cdiv(h, SIFT_BT_H), n);
+        if (fma) sift_blur_kernel<true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+        else sift_blur_kernel<false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    }
     check_launch("sift_blur_kernel");
 }
 
@@ -1739,7 +1761,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
         HIP_CHECK(hipMemsetAsync(W.info.p, 0, 32, st));
         for (int o = 0; o < g.n_oct; ++o) {
             if (g.ow[o] <= 2 * SIFT_BORDER || g.oh[o] <= 2 * SIFT_BORDER) continue;
-            sift_extrema_kernel<<<dim3(cdiv(g.ow[o], 64), cdiv(g.oh[o], 4), nb * SIFT_NL), 256, 0, st>>>(g, sp, o, W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
+            sift_extrema_kernel<<<dim3(cdiv(g.ow[o], 64), cdiv(g.oh[o], 4 * SIFT_EX_ROWS), nb * SIFT_NL), 256, 0, st>>>(g, sp, o, W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
             check_launch("sift_extrema_kernel");
         }
         // (the candidate count is on the device: the grid covers the capacity, surplus waves leave at once)
@@ -1777,6 +1799,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
 }
 
 }  // namespace
+}  // extern "C++"
 
 void slideo_sift_config_default(slideo_sift_config* c) {
     if (!c) return;

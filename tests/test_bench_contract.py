@@ -75,22 +75,27 @@ def test_strong_scaling_mode():
     assert j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 24 and j["value"] > 0
 
 
-def test_cfg2_l2_knn_line():
-    """--workload cfg2 (BASELINE configs[2]): the L2 k-NN stage on the int8 matrix cores, checked against numpy inside the run."""
+def test_cfg2_sift_l2_line():
+    """--workload cfg2 (BASELINE configs[2]) end to end at a small size: SIFT on the device feeding the L2 k-NN on the int8 matrix
+    cores; frame 0's SIFT output bit-exact against the CPU restatement, sampled neighbours against numpy, inside the run."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--batch", "8", "--pages", "20",
                         "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
-    assert j["dtype"] == "i8" and j["roofline"]["bound"] == "mfma" and j["roofline"]["kernel"] == "knn_l2_kernel"
-    assert j["config"]["checked_against_numpy"] is True and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["roofline"]["bound"] == "mfma" and j["roofline"]["kernel"] == "knn_l2_kernel" and j["sift_stage"]["bound"] == "hbm"
+    ck = j["config"]["checked"]
+    assert ck["knn_vs_numpy_64_queries"] is True and ck["sift_frame0_bit_exact_vs_cpu_restatement"] is True
+    assert ck["page_by_ratio_test_votes_vs_truth"] >= 0.75 and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
 
 
-def test_cfg2_l2_knn_full_size():
-    """BASELINE configs[2] at its full size: 256 frames x 1000 SIFT-shaped descriptors against 500 pages x 1850 (256 k x 925 k
-    squared-L2 pairs on the int8 matrix cores), 64 sampled queries re-computed in numpy inside the run."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "3", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+def test_cfg2_full_size():
+    """BASELINE configs[2] at its full size: 256 1080p frames x SIFT-1000 against the SIFT descriptors of 500 pages."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
-    assert j["config"]["train_descriptors_M"] == 925000 and j["config"]["query_descriptors_per_step"] == 256000
-    assert j["config"]["checked_against_numpy"] is True and j["roofline"]["frac"] > 0.3
+    c = j["config"]
+    assert c["frames_per_step_per_gpu"] == 256 and c["pages"] == 500 and c["train_descriptors_M"] > 400000 and c["query_descriptors_per_step"] > 200000
+    assert c["checked"]["knn_vs_numpy_64_queries"] is True and c["checked"]["sift_frame0_bit_exact_vs_cpu_restatement"] is True
+    assert c["checked"]["page_by_ratio_test_votes_vs_truth"] >= 0.9 and j["roofline"]["frac"] > 0.2
