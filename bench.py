@@ -238,6 +238,10 @@ def main():
     ap.add_argument("--hdlt", type=int, default=0, choices=[0, 1],
                     help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors, "
                          "1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample)")
+    ap.add_argument("--matcher", default="exact", choices=["exact", "lsh"],
+                    help="descriptor index: exact brute force (default; north_star) or the LSH candidate rule of the reference's FLANN index "
+                         "(slideo_config.matcher 1: 6 tables, 12-bit keys, multi-probe 1 — recall < 1, and on these descriptors SLOWER than the exact "
+                         "matrix-core search: the skewed buckets make a fifth of all rows candidates of a query)")
     ap.add_argument("--persp", type=float, default=-1.0, help="projective component of the synthetic frames (0 = similarity frames; default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
@@ -304,7 +308,7 @@ def main():
         frames, truth, _ = synth.frames(pages, B, fw, fh, first=rank * B, threads=gen_threads)
     t_gen = time.time() - t0
 
-    cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt)
+    cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0)
     m = _capi.Matcher(cfg, device=local_rank)
     m.set_knn_engine(args.knn)
     args.inflight = min(args.inflight or m.max_in_flight(), m.max_in_flight())
@@ -394,7 +398,8 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
-                   "train_descriptors_M": int(M), "train_descriptors_unique": int(Mu), "frames_per_step_per_gpu": B, "knn": "exact brute force, k=30, engine=%s" % args.knn,
+                   "train_descriptors_M": int(M), "train_descriptors_unique": int(Mu), "frames_per_step_per_gpu": B,
+                   "knn": ("exact brute force, k=30, engine=%s" % args.knn) if args.matcher == "exact" else "LSH candidates (6 tables x 12 bits, multi-probe 1), k=30 nearest candidates",
                    "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
@@ -486,7 +491,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt)
+        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0)
         budget = host_cpu_budget()
         cores = max(1, min(ncpu, budget["usable"]))
         db = pyoracle.PageDB(ocfg)

@@ -1,6 +1,6 @@
 //! Hand-written declarations of include/slideo_amd.h (ABI 4) — what bindgen would emit for the entry points this crate
 //! uses.  Field order and types mirror the C structs exactly; tests/test_capi_load.py pins the C side's layout
-//! (sizeof(slideo_config) == 144) and `assert_abi()` below pins the version at run time.
+//! (sizeof(slideo_config) == 160) and `assert_abi()` below pins the version at run time.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_char;
 
@@ -49,6 +49,11 @@ pub struct slideo_config {
     pub ratio_test: f32,
     /// 0 = the reference's estimateAffinePartial2D (default); 1 = 8-DOF homography (extension)
     pub verify_model: i32,
+    /// 0 = exact brute-force k-NN (default); 1 = the LSH candidate rule of the reference's FLANN index
+    pub matcher: i32,
+    pub lsh_tables: i32,
+    pub lsh_key_bits: i32,
+    pub lsh_multi_probe: i32,
     pub ocv: slideo_ocv_variants,
 }
 
@@ -125,6 +130,6 @@ pub fn assert_abi() {
         "libslideo_amd.so has ABI {} but this crate was written for ABI {}",
         v, SLIDEO_ABI_VERSION
     );
-    assert_eq!(std::mem::size_of::<slideo_config>(), 144);
+    assert_eq!(std::mem::size_of::<slideo_config>(), 160);
     assert_eq!(std::mem::size_of::<slideo_verdict>(), 16);
 }

@@ -32,6 +32,7 @@
  *   pages                  <= 16384       the vote kernel keeps one counter per page in LDS
  *   knn_k                  1..32          the per-query list lives in registers (the reference uses 30)
  *   max_candidate_pages    1..64, max_rated 1..16, nlevels 1..16, ransac_max_iters 1..1000000
+ *   lsh_tables 1..8, lsh_key_bits 1..16, lsh_multi_probe 0..2 (matcher 1)
  *   page / frame area      >= small_area  to_small_image (mo/image_utils.rs:8-20) only ever SHRINKS here; for an image below
  *                                         120 000 px OpenCV's INTER_AREA turns into a bilinear upscale, which is not restated
  *                                         (the reference's frames are >= 640x360)
@@ -175,6 +176,19 @@ typedef struct slideo_config {
      *       Levenberg-Marquardt steps on the 8 parameters; the mask is not recomputed), followed by
      *       warpPerspective(nearest, WARP_INVERSE_MAP) (imgproc/src/imgwarp.cpp) in the re-projection. */
     int32_t verify_model;         /* 0 */
+    /* The descriptor index.  0 = exact brute-force Hamming k-NN (north_star; what this library is built around).
+     * 1 = LSH-compatible approximate search: the candidate rule of the index the reference really builds —
+     * FlannBasedMatcher over FLANN's LshIndex with table_number 6, key_size 12, multi_probe_level 1 (mo/flann.rs:14-26):
+     * lsh_tables hash tables, each keyed by lsh_key_bits descriptor bits (cv::randShuffle of the 256 bit positions on
+     * cv::RNG's default state, the first lsh_key_bits of it, as flann/lsh_table.h does — recalled), a train row is a
+     * CANDIDATE of a query iff in some table its key differs from the query's in at most lsh_multi_probe bits; the
+     * result is the knn_k nearest candidates by (distance, row).  (FLANN's KNNUniqueResultSet breaks distance ties
+     * at the k-th place by visiting order; here ties go to the lower row: canonical)  Recall < 1, like
+     * the reference's; `SearchParams.checks` (32, mo/flann.rs:21) is ignored by LshIndex and has no counterpart. */
+    int32_t matcher;              /* 0 */
+    int32_t lsh_tables;           /* 6  (mo/flann.rs:16) */
+    int32_t lsh_key_bits;         /* 12 (mo/flann.rs:17) */
+    int32_t lsh_multi_probe;      /* 1  (mo/flann.rs:18) */
     /* which restatement of each OpenCV primitive to run (all 0 / 4164903690 by default) */
     slideo_ocv_variants ocv;
 } slideo_config;
@@ -367,6 +381,11 @@ int32_t     slideo_pyramid_level_bgr8(slideo_matcher* m, const uint8_t* bgr, int
 int32_t     slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq,
                                const uint8_t* t, int32_t nt, int32_t k,
                                int32_t* idx_out, uint16_t* dist_out);
+
+/* The LSH-compatible search (slideo_config.matcher 1) as a tap: the k nearest (distance, row) among the rows of t that are
+ * LSH candidates of each query under cfg's lsh_* parameters.  Same output format as slideo_knn_hamming. */
+int32_t     slideo_knn_lsh(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k,
+                           int32_t* idx_out, uint16_t* dist_out);
 
 /* North-star extension without a counterpart in the reference (BASELINE configs[2], SURVEY §8(d) "cfg2" / §8(f) N4):
  * exact squared-L2 k-NN between 128-dimensional u8 descriptors (SIFT-shaped: OpenCV's SIFT descriptors are

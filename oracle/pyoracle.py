@@ -30,7 +30,8 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
-        ("verify_model", C.c_int32), ("ocv", OcvVariants),
+        ("verify_model", C.c_int32), ("matcher", C.c_int32), ("lsh_tables", C.c_int32), ("lsh_key_bits", C.c_int32),
+        ("lsh_multi_probe", C.c_int32), ("ocv", OcvVariants),
     ]
 
 
@@ -233,6 +234,17 @@ def knn_hamming(q, t, k):
     dist = np.empty((q.shape[0], k), np.uint16)
     lib().so_knn_hamming(_p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist))
     return idx, dist
+
+
+def knn_lsh(q, t, k, cfg):
+    """slideo_config.matcher 1: the k nearest (distance, row) among each query's LSH candidates; also the tables' bit positions."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.uint16)
+    bits = np.zeros(cfg.lsh_tables * cfg.lsh_key_bits, np.int32)
+    lib().so_knn_lsh(_p(q), q.shape[0], _p(t), t.shape[0], k, C.byref(cfg), _p(idx), _p(dist), _p(bits))
+    return idx, dist, bits.reshape(cfg.lsh_tables, cfg.lsh_key_bits)
 
 
 def knn_hamming_blocked(q, t, k):

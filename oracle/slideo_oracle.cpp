@@ -475,7 +475,9 @@ static bool config_supported(const slideo_config& c) {
            c.ocv.gray >= 0 && c.ocv.gray <= 1 && c.ocv.blur >= 0 && c.ocv.blur <= 3 && c.ocv.resize >= 0 && c.ocv.resize <= 1 &&
            c.ocv.atan >= 0 && c.ocv.atan <= 1 && c.ocv.warp >= 0 && c.ocv.warp <= 1 && c.ocv.area >= 0 && c.ocv.area <= 1 &&
            c.ocv.lm >= 0 && c.ocv.lm <= 1 && c.ocv.hdlt >= 0 && c.ocv.hdlt <= 1 &&
-           c.verify_model >= 0 && c.verify_model <= 1;
+           c.verify_model >= 0 && c.verify_model <= 1 && c.matcher >= 0 && c.matcher <= 1 &&
+           (c.matcher == 0 || (c.lsh_tables >= 1 && c.lsh_tables <= 8 && c.lsh_key_bits >= 1 && c.lsh_key_bits <= 16 && c.lsh_multi_probe >= 0 &&
+                               c.lsh_multi_probe <= 2 && !(c.ratio_test > 0.f)));
 }
 
 struct Pyramid {
@@ -1549,8 +1551,72 @@ struct Page {
 
 }  // namespace
 
+namespace {
+// slideo_config.matcher 1 — the candidate rule of FLANN's LshIndex as the reference configures it (mo/flann.rs:14-26:
+// table_number 6, key_size 12, multi_probe_level 1), flann/lsh_index.h + lsh_table.h RECALLED: table i hashes a descriptor by
+// key_size of its 256 bits (cv::randShuffle of the bit positions on the thread's default cv::RNG, first key_size of the
+// shuffled array; keys pack the bits in ascending position order); a query probes, in every table, the buckets whose key is
+// within multi_probe_level bits of its own; the candidates are scored exactly and the k best returned.  Departure: FLANN's
+// KNNUniqueResultSet rejects a candidate whose distance EQUALS the current k-th, so ties at the k-th place depend on the
+// visiting order; here the result is the k smallest (distance, row) of the candidate set (canonical).
+struct LshIdx {
+    int ntab = 0, kb = 0, mp = 0;
+    std::vector<int> bit;                         // [ntab][kb] ascending
+    std::vector<std::vector<int32_t>> ofs, rows;  // per table: bucket offsets (2^kb + 1), rows grouped by key (ascending inside a bucket)
+    uint32_t key(int t, const uint8_t* d) const {
+        uint32_t k = 0;
+        for (int b = 0; b < kb; ++b) { const int p = bit[(size_t)t * kb + b]; k |= (uint32_t)((d[p >> 3] >> (p & 7)) & 1) << b; }
+        return k;
+    }
+    void build(const slideo_config& c, const uint8_t* train, int M) {
+        ntab = c.lsh_tables; kb = c.lsh_key_bits; mp = c.lsh_multi_probe;
+        bit.assign((size_t)ntab * kb, 0);
+        CvRng rng(0xffffffffULL, c.ocv.rng_mul);          // cv::theRNG()'s initial state
+        for (int t = 0; t < ntab; ++t) {
+            int a[256];
+            for (int i = 0; i < 256; ++i) a[i] = i;
+            for (int i = 0; i < 256; ++i) { const int j = (int)(rng.next() % 256u); std::swap(a[j], a[i]); }     // cv::randShuffle_<int>
+            std::sort(a, a + kb);
+            for (int b = 0; b < kb; ++b) bit[(size_t)t * kb + b] = a[b];
+        }
+        ofs.assign(ntab, std::vector<int32_t>()); rows.assign(ntab, std::vector<int32_t>());
+        for (int t = 0; t < ntab; ++t) {
+            std::vector<int32_t>& o = ofs[t];
+            o.assign(((size_t)1 << kb) + 1, 0);
+            std::vector<uint32_t> k(M);
+            for (int i = 0; i < M; ++i) { k[i] = key(t, train + (size_t)i * 32); o[k[i] + 1]++; }
+            for (size_t i = 0; i + 1 < o.size(); ++i) o[i + 1] += o[i];
+            std::vector<int32_t> cur(o.begin(), o.end() - 1);
+            rows[t].assign(M, 0);
+            for (int i = 0; i < M; ++i) rows[t][cur[k[i]]++] = i;
+        }
+    }
+    void knn(const uint8_t* q, const uint8_t* train, int k, int32_t* idx, uint16_t* dist) const {
+        std::vector<uint32_t> cand;
+        for (int t = 0; t < ntab; ++t) {
+            const uint32_t qk = key(t, q);
+            for (uint32_t m = 0; m < (1u << kb); ++m) {
+                if (__builtin_popcount(m) > mp) continue;
+                const uint32_t b = qk ^ m;
+                for (int32_t j = ofs[t][b]; j < ofs[t][b + 1]; ++j) {
+                    const int32_t row = rows[t][j];
+                    cand.push_back(((uint32_t)hamming256(q, train + (size_t)row * 32) << 23) | (uint32_t)row);
+                }
+            }
+        }
+        std::sort(cand.begin(), cand.end());
+        cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+        for (int r = 0; r < k; ++r) {
+            idx[r] = r < (int)cand.size() ? (int32_t)(cand[r] & 0x7FFFFFu) : -1;
+            dist[r] = r < (int)cand.size() ? (uint16_t)(cand[r] >> 23) : (uint16_t)65535;
+        }
+    }
+};
+}  // namespace
+
 struct so_pagedb {
     slideo_config cfg;
+    LshIdx lsh;
     std::vector<Page> pages;
     std::vector<uint8_t> train;       // M x 32
     std::vector<uint64_t> train_blocked;   // the same rows in knn_hamming_blocked's layout
@@ -1575,7 +1641,10 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
     if (K == 0) return;
     std::vector<int32_t> idx((size_t)K * k);
     std::vector<uint16_t> dist((size_t)K * k);
-    knn_hamming_blocked(fr.desc.data(), K, db.train_blocked.data(), M, k, idx.data(), dist.data());  // :266 (== knn_hamming)
+    if (c.matcher == 1)                                       // the reference's index: LSH candidates only
+        for (int qi = 0; qi < K; ++qi) db.lsh.knn(fr.desc.data() + (size_t)qi * 32, db.train.data(), k, idx.data() + (size_t)qi * k, dist.data() + (size_t)qi * k);
+    else
+        knn_hamming_blocked(fr.desc.data(), K, db.train_blocked.data(), M, k, idx.data(), dist.data());  // :266 (== knn_hamming)
     int P = (int)db.pages.size();
     // tolerance vote, mo/lib.rs:268-282: d < best * 1.05 (f32, strict)
     std::vector<std::vector<Vote>> votes(P);
@@ -1697,6 +1766,7 @@ void so_config_default(slideo_config* c) {
     c->changed_similarity = 0.98f;                                 // mo/video_capture.rs:98
     c->ratio_test = 0.0f;                                          // extension, off
     c->verify_model = 0;                                           // the reference's estimateAffinePartial2D
+    c->matcher = 0; c->lsh_tables = 6; c->lsh_key_bits = 12; c->lsh_multi_probe = 1;   // exact search; mo/flann.rs:16-18
     std::memset(&c->ocv, 0, sizeof(c->ocv));                       // every OpenCV-variant switch at its default (0)
     c->ocv.rng_mul = 4164903690u;                                  // CV_RNG_COEFF
 }
@@ -1803,6 +1873,12 @@ int so_orb_bgr8(const uint8_t* bgr, int w, int h, int stride, const slideo_confi
 
 void so_knn_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint16_t* dist) {
     knn_hamming(q, nq, t, nt, k, idx, dist);
+}
+// slideo_config.matcher 1 on plain arrays: the k nearest LSH candidates of each query; bits_out (may be null): the tables' bit positions
+void so_knn_lsh(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, const slideo_config* c, int32_t* idx, uint16_t* dist, int32_t* bits_out) {
+    LshIdx L; L.build(*c, t, nt);
+    for (int i = 0; i < nq; ++i) L.knn(q + (size_t)i * 32, t, k, idx + (size_t)i * k, dist + (size_t)i * k);
+    if (bits_out) for (size_t i = 0; i < L.bit.size(); ++i) bits_out[i] = L.bit[i];
 }
 // the cache-blocked / vectorised form the frame path uses; simd: 1 = AVX-512 VPOPCNTDQ was used
 int so_knn_hamming_blocked(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint16_t* dist) {
@@ -1957,6 +2033,7 @@ int so_pagedb_finalize(so_pagedb* db) {   // mo/flann.rs:65-71 (exact index = th
         db->page_ofs.push_back((int32_t)db->train_page.size());
     }
     knn_block_train(db->train.data(), (int)db->train_page.size(), db->train_blocked);
+    if (db->cfg.matcher == 1) db->lsh.build(db->cfg, db->train.data(), (int)db->train_page.size());
     db->finalized = true;
     return db->train_page.empty() ? 6 : 0;
 }

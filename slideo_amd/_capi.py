@@ -32,7 +32,8 @@ class Config(C.Structure):
         ("ransac_confidence", C.c_double), ("refine_iters", C.c_int32), ("max_rated", C.c_int32),
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
-        ("verify_model", C.c_int32),
+        ("verify_model", C.c_int32), ("matcher", C.c_int32), ("lsh_tables", C.c_int32), ("lsh_key_bits", C.c_int32),
+        ("lsh_multi_probe", C.c_int32),
         ("ocv", OcvVariants),
     ]
 
@@ -72,7 +73,7 @@ EXPORTS = [
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
     "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
-    "slideo_sift_config_default", "slideo_sift_bgr8", "slideo_sift_frames_dev", "slideo_sift_layer_bgr8",
+    "slideo_sift_config_default", "slideo_sift_bgr8", "slideo_sift_frames_dev", "slideo_sift_layer_bgr8", "slideo_knn_lsh",
 ]
 
 _lib = None
@@ -381,6 +382,15 @@ class Matcher:
         ms = C.c_float()
         self._check(lib().slideo_l2_knn_dev(self._h, C.c_void_p(q_dev), nq, k, C.c_void_p(idx_dev), C.c_void_p(dist_dev), C.byref(ms)))
         return ms.value
+
+    def knn_lsh(self, q, t, k):
+        """The LSH-compatible search (slideo_config.matcher 1) under this matcher's lsh_* parameters."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.uint16)
+        self._check(lib().slideo_knn_lsh(self._h, _p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist)))
+        return idx, dist
 
     def knn_l2_u8(self, q, t, k):
         """Exact squared-L2 k-NN of 128-dim u8 descriptors on the matrix cores (north-star extension, see the header)."""

@@ -206,7 +206,38 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (o.lm != 0) { *why = "ocv.lm: only 0 (Gaussian elimination) is implemented on the GPU; the CPU restatement has 1"; return false; }
     if (o.hdlt < 0 || o.hdlt > 1) { *why = "ocv.hdlt must be 0 or 1"; return false; }
     if (c.verify_model < 0 || c.verify_model > 1) { *why = "verify_model must be 0 (similarity) or 1 (homography)"; return false; }
+    if (c.matcher < 0 || c.matcher > 1) { *why = "matcher must be 0 (exact) or 1 (LSH-compatible)"; return false; }
+    if (c.matcher == 1 && (c.lsh_tables < 1 || c.lsh_tables > 8 || c.lsh_key_bits < 1 || c.lsh_key_bits > 16 || c.lsh_multi_probe < 0 || c.lsh_multi_probe > 2)) {
+        *why = "lsh_tables must be 1..8, lsh_key_bits 1..16, lsh_multi_probe 0..2"; return false;
+    }
+    if (c.matcher == 1 && c.ratio_test > 0.f) { *why = "the ratio test needs the exact two nearest rows: matcher 0"; return false; }
     return true;
+}
+
+// ---- slideo_config.matcher 1: FLANN LshIndex's tables (flann/lsh_table.h LshTable<unsigned char>::initialize, recalled) --------
+// Table i is keyed by key_bits bit positions of the 256-bit descriptor: cv::randShuffle of the positions 0..255 (for i < 256:
+// j = rng % 256, swap(a[j], a[i])) on the thread's default cv::RNG (state 0xffffffff), continuing from table to table, and the
+// first key_bits positions of the shuffled array; a key packs those bits in ascending position order (getKey walks the mask).
+constexpr int LSH_MAX_TABLES = 8, LSH_MAX_BITS = 16;
+struct LshParams { int32_t ntab, kb, mp; int32_t bit[LSH_MAX_TABLES][LSH_MAX_BITS]; };
+
+inline LshParams lsh_params(const slideo_config& c) {
+    LshParams L{};
+    L.ntab = c.lsh_tables; L.kb = c.lsh_key_bits; L.mp = c.lsh_multi_probe;
+    CvRng rng(0xffffffffULL, c.ocv.rng_mul);
+    for (int t = 0; t < L.ntab; ++t) {
+        int a[256];
+        for (int i = 0; i < 256; ++i) a[i] = i;
+        for (int i = 0; i < 256; ++i) { const int j = (int)(rng.next() % 256u); std::swap(a[j], a[i]); }
+        std::sort(a, a + L.kb);
+        for (int b = 0; b < L.kb; ++b) L.bit[t][b] = a[b];
+    }
+    return L;
+}
+inline uint32_t lsh_key_host(const LshParams& L, int t, const uint8_t* desc) {
+    uint32_t k = 0;
+    for (int b = 0; b < L.kb; ++b) { const int p = L.bit[t][b]; k |= (uint32_t)((desc[p >> 3] >> (p & 7)) & 1) << b; }
+    return k;
 }
 
 // Builds the pyramid geometry + resize tables for a w x h input.

@@ -18,6 +18,7 @@
 #include "knn.hip.h"
 #include "knn_tile.hip.h"
 #include "knn_l2.hip.h"
+#include "knn_lsh.hip.h"
 #include "orb.hip.h"
 #include "slideo_amd.h"
 #include "verify.hip.h"
@@ -125,6 +126,7 @@ struct slideo_matcher {
     // train-set de-duplication (knn.hip.h knn_expand_dups_kernel): the matrix-core engine searches the Mu unique rows, keys carry
     // the lowest original row of a group, d_grp_next chains the equal rows.  SLIDEO_KNN_DEDUP=0 searches all M rows.
     DevBuf d_utrain, d_grp_next;
+    struct LshSet { DevBuf ofs, rows, keys; LshDev dev{}; bool ready = false; } lsh;      // slideo_config.matcher 1 (knn_lsh.hip.h)
     int64_t Mu = -1;
     int knn_dedup = 1;
     int host_unit = 32;              // frames per unit of a HOST-memory batch (SLIDEO_HOST_UNIT; 0 = the device-path rule)
@@ -482,6 +484,29 @@ void prepare_train_bits(const uint8_t* t_host, const uint32_t* t_dev, int nt, Tr
     HIP_CHECK(hipStreamSynchronize(st));                                 // the host vectors die here
 }
 
+// slideo_config.matcher 1: the tables of FLANN's LshIndex over `nt` host rows (geom.h lsh_params / lsh_key_host), uploaded
+void build_lsh_set(const slideo_config& c, const uint8_t* t_host, int nt, slideo_matcher::LshSet& S, hipStream_t st) {
+    const LshParams P = lsh_params(c);
+    const int nb = 1 << P.kb;
+    std::vector<uint16_t> keys((size_t)std::max(nt, 1) * P.ntab);
+    std::vector<int32_t> ofs((size_t)P.ntab * (nb + 1), 0), rows((size_t)P.ntab * std::max(nt, 1));
+    for (int tb = 0; tb < P.ntab; ++tb) {
+        int32_t* o = ofs.data() + (size_t)tb * (nb + 1);
+        for (int i = 0; i < nt; ++i) { const uint32_t k = lsh_key_host(P, tb, t_host + (size_t)i * 32); keys[(size_t)i * P.ntab + tb] = (uint16_t)k; o[k + 1]++; }
+        for (int i = 0; i < nb; ++i) o[i + 1] += o[i];
+        std::vector<int32_t> cur(o, o + nb);
+        for (int i = 0; i < nt; ++i) rows[(size_t)tb * std::max(nt, 1) + cur[keys[(size_t)i * P.ntab + tb]]++] = i;      // rows ascend inside a bucket
+    }
+    S.ofs.reserve(ofs.size() * 4 + 16); S.rows.reserve(rows.size() * 4 + 16); S.keys.reserve(keys.size() * 2 + 16);
+    HIP_CHECK(hipMemcpyAsync(S.ofs.p, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.keys.p, keys.data(), keys.size() * 2, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    S.dev.p = P; S.dev.nbuckets = nb; S.dev.ofs = S.ofs.as<int32_t>(); S.dev.rows = S.rows.as<int32_t>(); S.dev.keys = S.keys.as<uint16_t>();
+    S.dev.M = std::max(nt, 1);
+    S.ready = true;
+}
+
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // The matrix-core engine has two wave shapes (knn_tile.hip.h).  One block of 1024 queries per CU at 2 waves/SIMD (engine 2)
 // keeps more than half of every SIMD's registers and 88 KB of LDS per CU free for the other units' ORB / verify kernels
@@ -704,6 +729,12 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         // (the ratio test needs the exact two nearest rows: exact lists)
         const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
         const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
+        if (c.matcher == 1) {
+            // the reference's index: only the LSH candidates of a query are scored (knn_lsh.hip.h); same key lists out
+            knn_lsh_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), 4), 256, 0, st>>>(m->lsh.dev, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(),
+                                                                                   S.d_keys.as<uint32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
+            check_launch("knn_lsh_kernel");
+        } else
         run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
         if (dedup) {
@@ -925,6 +956,7 @@ void slideo_config_default(slideo_config* c) {
     c->min_similarity = 0.5f; c->small_area = 300 * 400; c->changed_similarity = 0.98f;
     c->ratio_test = 0.0f;
     c->verify_model = 0;                             // the reference's estimateAffinePartial2D
+    c->matcher = 0; c->lsh_tables = 6; c->lsh_key_bits = 12; c->lsh_multi_probe = 1;      // exact search; mo/flann.rs:16-18
     std::memset(&c->ocv, 0, sizeof(c->ocv));         // every OpenCV-variant switch at its default
     c->ocv.rng_mul = 4164903690u;                    // CV_RNG_COEFF
 }
@@ -1187,7 +1219,8 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         std::vector<int32_t> order((size_t)M), grp_next((size_t)M, -1), urow;
         for (int64_t i = 0; i < M; ++i) order[i] = (int32_t)i;
         m->Mu = M;
-        if (m->knn_dedup) {
+        if (m->cfg.matcher == 1) build_lsh_set(m->cfg, train.data(), (int)M, m->lsh, m->stream);
+        if (m->knn_dedup && m->cfg.matcher == 0) {
             const uint64_t* t64 = reinterpret_cast<const uint64_t*>(train.data());
             auto less = [&](int32_t a, int32_t b) {
                 const uint64_t* x = t64 + (size_t)a * 4; const uint64_t* y = t64 + (size_t)b * 4;
@@ -1488,6 +1521,36 @@ int32_t slideo_knn_hamming(slideo_matcher* m, const uint8_t* q, int32_t nq, cons
     DevBuf tapb, tap_side, tap_nminh, tap_perm;
     if (knn_engine_for(m, nq) != 1 && nt > 0) prepare_train_bits(t, m->d_tapt.as<uint32_t>(), nt, TrainBits{&tapb, &tap_side, &tap_nminh, &tap_perm}, st);
     run_knn(m, S, m->d_tapq.as<uint32_t>(), nq, TrainOps{m->d_tapt.as<uint32_t>(), tapb.as<uint4>(), tap_side.as<uint32_t>(), tap_nminh.as<float4>()}, nt, 0.f);
+    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
+    knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
+    check_launch("knn_unpack_kernel");
+    HIP_CHECK(hipMemcpyAsync(idx_out, m->d_tapidx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(dist_out, m->d_tapdist.p, (size_t)nq * k * 2, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    API_CATCH(m)
+}
+
+int32_t slideo_knn_lsh(slideo_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t k, int32_t* idx_out, uint16_t* dist_out) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (nq < 0 || nt < 0 || k < 1 || k > KLIST) fail(SLIDEO_ERR_INVALID_ARG, "bad nq/nt/k (k must be 1..%d)", KLIST);
+    if ((nq && !q) || (nt && !t) || (nq && (!idx_out || !dist_out))) fail(SLIDEO_ERR_INVALID_ARG, "null argument");
+    if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
+    if (m->cfg.lsh_tables < 1 || m->cfg.lsh_tables > 8 || m->cfg.lsh_key_bits < 1 || m->cfg.lsh_key_bits > 16 || m->cfg.lsh_multi_probe < 0 || m->cfg.lsh_multi_probe > 2)
+        fail(SLIDEO_ERR_UNSUPPORTED, "lsh_tables must be 1..8, lsh_key_bits 1..16, lsh_multi_probe 0..2");
+    if (nq == 0) return SLIDEO_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    Slot& S = m->slots[0];
+    hipStream_t st = S.st;
+    slideo_matcher::LshSet set;
+    build_lsh_set(m->cfg, t, nt, set, st);
+    m->d_tapq.reserve((size_t)nq * 32); m->d_tapt.reserve(std::max<size_t>((size_t)nt * 32, 64) + 64);
+    HIP_CHECK(hipMemcpyAsync(m->d_tapq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt) HIP_CHECK(hipMemcpyAsync(m->d_tapt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    S.d_keys.reserve((size_t)nq * KLIST * 4);
+    knn_lsh_kernel<KLIST><<<cdiv(nq, 4), 256, 0, st>>>(set.dev, m->d_tapq.as<uint32_t>(), nq, m->d_tapt.as<uint32_t>(), S.d_keys.as<uint32_t>(), nullptr);
+    check_launch("knn_lsh_kernel");
     m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 2);
     knn_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(S.d_keys.as<uint32_t>(), nq, KLIST, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint16_t>());
     check_launch("knn_unpack_kernel");

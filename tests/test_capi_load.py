@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(capi):
 def test_config_struct_matches_oracle_layout(capi, oracle):
     import ctypes as C
     a, b = capi.default_config(), oracle.default_config()
-    assert C.sizeof(a) == C.sizeof(b) == 144        # ABI 4: + verify_model, + ocv.hdlt
+    assert C.sizeof(a) == C.sizeof(b) == 160        # ABI 4: + verify_model, matcher, lsh_*, ocv.hdlt
     assert bytes(a) == bytes(b)
 
 
