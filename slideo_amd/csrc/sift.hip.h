@@ -33,7 +33,7 @@ namespace slideo {
 constexpr int SIFT_MAX_OCT = 12;
 constexpr int SIFT_NL = 3;                      // nOctaveLayers (the only value the kernels implement)
 constexpr int SIFT_BORDER = 5, SIFT_STEPS = 5, SIFT_BINS = 36;
-constexpr int SIFT_MAX_TAPS = 32;               // cvRound(8 sigma + 1) | 1 <= 27 for sigma <= 3.1
+constexpr int SIFT_MAX_TAPS = 40;               // cvRound(8 s + 1) | 1 of the widest layer blur s = 1.93 sigma: 27 taps at sigma 1.6, 39 at 2.4
 constexpr int SIFT_BT_W = 64, SIFT_BT_H = 32;   // blur tile (outputs) per 256-thread block
 constexpr double SIFT_FIXD = 1048576.0;         // 2^20
 

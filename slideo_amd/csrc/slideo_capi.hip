@@ -508,17 +508,11 @@ void build_lsh_set(const slideo_config& c, const uint8_t* t_host, int nt, slideo
 }
 
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
-// The matrix-core engine has two wave shapes (knn_tile.hip.h).  One block of 1024 queries per CU at 2 waves/SIMD (engine 2)
-// keeps more than half of every SIMD's registers and 88 KB of LDS per CU free for the other units' ORB / verify kernels
-// during the whole launch.  It needs enough queries to put a block on most CUs without splitting the train set; below that
-// (64 4K frames = 125 blocks) the 512-query blocks of engine 3 fill the chip better.
+// Engine 0 ("mfma") = the 2-tile wave shape (knn_tile2_kernel: 4 waves/SIMD, two 512-query blocks per CU) at every size: since the
+// {0,1} operand alphabet it runs the headline launch in 10.0 ms alone against 11.3 for the 4-tile shape and the step is 2 %
+// shorter.  The 4-tile shape (engine 2) and the VALU popcount kernel (engine 1) stay selectable for A/B: identical results.
 int knn_engine_for(const slideo_matcher* m, int nq) {
     if (m->knn_engine != 0) return m->knn_engine;
-    // The 2-tile shape (4 waves/SIMD, two 512-query blocks per CU) for every size: since the {0,1} operand alphabet it runs the
-    // headline launch in 10.0 ms alone against 11.3 for the 4-tile shape (four waves per SIMD interleave their max trees with
-    // each other's MFMAs better than two waves with twice the accumulators do), 12.5 against 15.0 ms inside the timed region,
-    // and the step is 2 % shorter.  (Round 1's kernels were equally fast alone and the 4-tile shape won by leaving registers to
-    // the other units' kernels; it stays selectable: slideo_matcher_set_knn_engine 2.)
     (void)nq;
     return 3;
 }

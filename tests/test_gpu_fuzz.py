@@ -74,3 +74,54 @@ def test_end_to_end_random_decks(capi, oracle, synth, seed):
         v = m.match_frames(frames)
         _compare_traces(m, db, frames, v)
     m.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_end_to_end_random_decks_extension_modes(capi, oracle, synth, seed):
+    """The same sweep over the round-3 modes: 8-DOF homography verification (both sample solvers, perspective frames), the
+    LSH-compatible index, duplicated pages (train-set de-duplication) — traces against the oracle."""
+    rng = np.random.default_rng(3000 + seed)
+    pw, ph = int(rng.integers(600, 1100)), int(rng.integers(360, 700))
+    fw, fh = int(rng.integers(480, 1000)), int(rng.integers(300, 640))
+    fh = max(fh, 120000 // fw + 1)
+    npages, nframes = int(rng.integers(2, 6)), int(rng.integers(3, 7))
+    pages = synth.pages(npages, pw, ph, seed=int(rng.integers(1, 1 << 30)))
+    if rng.integers(0, 2):
+        pages = np.concatenate([pages, pages[: int(rng.integers(1, npages + 1))]])                  # repeated pages: equal train rows
+    mode = seed % 4
+    over = dict(nfeatures=int(rng.choice([300, 800, 1500])), min_rating=float(rng.choice([8.0, 20.0])))
+    fseed = int(rng.integers(1, 1 << 30))
+    if mode in (0, 1):
+        over.update(verify_model=1, ocv_hdlt=mode, ransac_max_iters=int(rng.choice([200, 2000])), refine_iters=int(rng.choice([0, 10])))
+        frames, truth, _ = synth.frames_persp(pages, nframes, fw, fh, persp=float(rng.choice([0.0, 0.1, 0.25])), seed=fseed)
+    elif mode == 2:
+        over.update(matcher=1, lsh_multi_probe=int(rng.integers(0, 3)), lsh_key_bits=int(rng.choice([8, 12, 14])), lsh_tables=int(rng.integers(1, 8)))
+        frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=fseed)
+    else:
+        over.update(vote_tolerance=float(rng.choice([1.0, 1.05, 1.2])), knn_k=int(rng.choice([5, 30, 32])))
+        frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=fseed)
+    m, db = _build_both(capi, oracle, capi.default_config(**over), oracle.default_config(**over), pages)
+    assert m.descriptor_count == db.descriptor_count
+    if m.descriptor_count > 0:
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=mode in (0, 1))
+    m.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sift_random_sizes_contents_configs(capi, oracle, synth, seed):
+    """SIFT (csrc/sift.hip.h) over random sizes / contents / parameters: keypoints and descriptors bit-exact."""
+    rng = np.random.default_rng(4000 + seed)
+    sc = dict(nfeatures=int(rng.choice([0, 50, 400])), contrast_threshold=float(rng.choice([0.02, 0.04, 0.09])),
+              edge_threshold=float(rng.choice([6.0, 10.0, 20.0])), sigma=float(rng.choice([1.2, 1.6, 2.0])))
+    over = dict(ocv_blur=int(rng.integers(0, 2)), ocv_gray=int(rng.integers(0, 2)), ocv_atan=int(rng.integers(0, 2)))
+    m = capi.Matcher(capi.default_config(**over))
+    ocfg = oracle.default_config(**over)
+    for _ in range(2):
+        w, h = int(rng.integers(40, 700)), int(rng.integers(40, 500))
+        img = _image(rng, synth, max(w, 131), max(h, 131))[:h, :w].copy()
+        gk, gd = m.sift(img, capi.sift_config(**sc))
+        ok, od, _ = oracle.sift(img, oracle.sift_config(**sc), ocfg)
+        assert len(gk) == len(ok), (w, h, sc)
+        assert np.array_equal(gk, ok.view(gk.dtype)) and np.array_equal(gd, od), (w, h, sc)
+    m.close()
