@@ -163,4 +163,30 @@ __global__ __launch_bounds__(256) void knn_lsh_kernel(LshDev L, const uint32_t* 
     if (lane < KLIST) out[(size_t)qi * KLIST + lane] = key;
 }
 
+// keys of the queries under the tables of L: qkeys [nq][ntab] u16 (what KtHammingLsh::accept compares the rows' keys with).
+// grid ceil(nq_grid / 256); nq_dev != null: the query count lives on the device.
+__global__ __launch_bounds__(256) void lsh_query_keys_kernel(LshParams P, const uint32_t* __restrict__ q, int nq, uint16_t* __restrict__ qkeys,
+                                                             const uint32_t* __restrict__ nq_dev) {
+    if (nq_dev) nq = (int)*nq_dev;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    uint32_t d[8];
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)i * 8);
+        const uint4 a = p[0], b = p[1];
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    }
+    for (int tb = 0; tb < P.ntab; ++tb) {
+        uint32_t k = 0;
+        for (int b = 0; b < P.kb; ++b) {
+            const int pos = P.bit[tb][b];
+            uint32_t w = d[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) w = (pos >> 5) == e ? d[e] : w;
+            k |= ((w >> (pos & 31)) & 1u) << b;
+        }
+        qkeys[(size_t)i * P.ntab + tb] = (uint16_t)k;
+    }
+}
+
 }  // namespace slideo

@@ -87,9 +87,12 @@ typedef int knl_v16i __attribute__((ext_vector_type(16)));
 
 // Hamming distance of 256-bit descriptors (the hot path): {0,1} FP4 operands, f32 accumulators, u32 keys d << 23 | row,
 // lists of 32; a row qualifies iff dot - |t| / 2 > h, h = (|q| - B - 1) / 2 (header).
+struct KtNoCtx {};
 struct KtHamming {
     typedef knn_v16f Acc; typedef knn_v8i Bop; typedef uint32_t Key; typedef float Thr;
-    static constexpr bool hamming = true;
+    typedef KtNoCtx Ctx;                                 // per-launch context of the row filter (none)
+    static constexpr bool hamming = true, filtered = false;
+    static __device__ __forceinline__ bool accept(const Ctx&, uint32_t, int) { return true; }
     static constexpr int KL = 32, QBYTES = 32;
     static __device__ __forceinline__ Acc mfma(Acc acc, const uint4& f, const Bop& b) {
         const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
@@ -115,10 +118,29 @@ constexpr int KNL_PAD_NORM = 1 << 30;
 constexpr int KNL_THR_OPEN = -(1 << 30) + (1 << 24);        // below every real row's score (>= -3 * 2^21), above every pad row's (-2^30)
 constexpr unsigned long long KNL_EMPTY = ~0ull;
 template <int KL> __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsigned long long key);
+// The Hamming engine restricted to the LSH CANDIDATES of each query (slideo_config.matcher 1, knn_lsh.hip.h): a row that passes
+// the distance test enters a list only if, in some table, its key differs from the query's in at most `mp` bits.  The test
+// sits in the slow path (a few pairs per thousand), so the stream runs at the exact engine's rate; thresholds follow the
+// lists, which hold candidates only — the result is the k nearest candidates, what knn_lsh_kernel computes by gathering.
+struct KtLshCtx { const uint16_t* rkeys; const uint16_t* qkeys; int32_t ntab, mp; };
+struct KtHammingLsh : KtHamming {
+    typedef KtLshCtx Ctx;
+    static constexpr bool filtered = true;
+    static __device__ __forceinline__ bool accept(const Ctx& c, uint32_t row, int q) {
+        const uint16_t* rk = c.rkeys + (size_t)row * c.ntab;
+        const uint16_t* qk = c.qkeys + (size_t)q * c.ntab;
+        bool ok = false;
+        for (int e = 0; e < c.ntab; ++e) ok = ok || __popc((uint32_t)rk[e] ^ (uint32_t)qk[e]) <= c.mp;
+        return ok;
+    }
+};
+
 template <int KL_>
 struct KtL2 {
     typedef knl_v16i Acc; typedef knl_v4i Bop; typedef unsigned long long Key; typedef int Thr;
-    static constexpr bool hamming = false;
+    typedef KtNoCtx Ctx;
+    static constexpr bool hamming = false, filtered = false;
+    static __device__ __forceinline__ bool accept(const Ctx&, uint32_t, int) { return true; }
     static constexpr int KL = KL_, QBYTES = 128;
     static __device__ __forceinline__ Acc mfma(Acc acc, const uint4& f, const Bop& b) {
         const knl_v4i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w};
@@ -162,7 +184,7 @@ template <int NT, typename M>
 __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
                                               const uint32_t* __restrict__ side, const uint4* __restrict__ nminh, int nt_pad,
                                               int st_per_seg, typename M::Key* __restrict__ out, typename M::Key* __restrict__ pend_ws,
-                                              float prune_tol, const uint32_t* __restrict__ nq_dev) {
+                                              float prune_tol, const uint32_t* __restrict__ nq_dev, typename M::Ctx ctx = typename M::Ctx()) {
     typedef typename M::Acc Acc;
     typedef typename M::Key Key;
     typedef typename M::Thr Thr;
@@ -367,7 +389,9 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                     const float v = acc[r];
                     const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;              // exact: halves of small integers
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
-                        if (hit) {
+                        bool take = hit;
+                        if constexpr (M::filtered) { if (hit) take = M::accept(ctx, sd[KT_ST_ROWS + ro], min(qbase + 32 * qt + ql, nq - 1)); }
+                        if (take) {
                             const float d = nq_i + nrm - 2.f * v;
                             P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | sd[KT_ST_ROWS + ro];
                             ++c;
@@ -518,6 +542,14 @@ void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __res
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
     knn_tile_body<2, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
                                 prune_tol, nq_dev);
+}
+// the same engine over the LSH candidates only (KtHammingLsh)
+__global__ __launch_bounds__(KT_THREADS, 4)
+void knn_tile2_lsh_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
+                          const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
+                          uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev, KtLshCtx ctx) {
+    knn_tile_body<2, KtHammingLsh>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
+                                   prune_tol, nq_dev, ctx);
 }
 
 }  // namespace slideo

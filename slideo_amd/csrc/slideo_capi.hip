@@ -69,7 +69,7 @@ struct Slot {
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
-    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys;
     PinBuf h_info, h_out;
     OrbOut orb;
     // unit in flight
@@ -129,6 +129,7 @@ struct slideo_matcher {
     struct LshSet { DevBuf ofs, rows, keys; LshDev dev{}; bool ready = false; } lsh;      // slideo_config.matcher 1 (knn_lsh.hip.h)
     int64_t Mu = -1;
     int knn_dedup = 1;
+    int lsh_gather = 0;              // SLIDEO_LSH_ENGINE=gather: matcher 1 through knn_lsh_kernel (buckets gathered) instead of the filtered matrix-core stream
     int host_unit = 32;              // frames per unit of a HOST-memory batch (SLIDEO_HOST_UNIT; 0 = the device-path rule)
     // every H2D copy of frame units goes through ONE stream, in submission order: copies issued on the units' own streams run
     // concurrently and share the link, so the first unit's frames arrive when all of them have (measured: 39 - 45 ms per 256
@@ -723,11 +724,28 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         // (the ratio test needs the exact two nearest rows: exact lists)
         const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
         const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
-        if (c.matcher == 1) {
-            // the reference's index: only the LSH candidates of a query are scored (knn_lsh.hip.h); same key lists out
+        if (c.matcher == 1 && (m->lsh_gather || knn_engine_for(m, (int)qplan) == 1)) {
+            // the reference's index, gathered: only the LSH candidates of a query are scored (knn_lsh.hip.h); same key lists out
             knn_lsh_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), 4), 256, 0, st>>>(m->lsh.dev, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(),
                                                                                    S.d_keys.as<uint32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
             check_launch("knn_lsh_kernel");
+        } else if (c.matcher == 1) {
+            // the same result from the matrix-core stream over ALL rows with the candidate rule applied where a row passes the
+            // distance test (KtHammingLsh): a fifth of all rows are candidates of a query on these descriptors (skewed buckets),
+            // so gathering them is 60x slower than streaming everything
+            const uint32_t* nqd = async ? S.d_qofs.as<uint32_t>() + n : nullptr;
+            S.d_qkeys.reserve(std::max<size_t>((size_t)qtot * c.lsh_tables * 2, 64));
+            lsh_query_keys_kernel<<<cdiv((int)std::max(qtot, 1u), 256), 256, 0, st>>>(m->lsh.dev.p, S.d_desc.as<uint32_t>(), (int)qtot, S.d_qkeys.as<uint16_t>(), nqd);
+            check_launch("lsh_query_keys_kernel");
+            const KnnPlan p = knn_plan(m, (int)qplan, nt_knn, (int)qtot);
+            const KtLshCtx ctx{m->lsh.dev.keys, S.d_qkeys.as<uint16_t>(), c.lsh_tables, c.lsh_multi_probe};
+            knn_tile2_lsh_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(S.d_desc.as<uint32_t>(), (int)qplan, T.txb, T.side, T.nminh, knn_pad_rows(nt_knn), p.per_seg,
+                                                                                 S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune, nqd, ctx);
+            check_launch("knn_tile2_lsh_kernel");
+            if (p.nseg > 1) {
+                knn_merge_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), (int)qplan, p.nseg, nqd);
+                check_launch("knn_merge_kernel");
+            }
         } else
         run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
@@ -983,6 +1001,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_KNN_ENGINE")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) mm->knn_engine = v; }
     if (const char* e = std::getenv("SLIDEO_ASYNC_SUBMIT")) mm->async_submit = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_KNN_DEDUP")) mm->knn_dedup = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
     if (const char* e = std::getenv("SLIDEO_HOST_UNIT")) mm->host_unit = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_PYR_CHAIN")) mm->pyr_chain = std::atoi(e) != 0;
