@@ -444,7 +444,12 @@ def main():
             # `traffic` = HBM bytes per launch (a number, or null where it was not measured); the passes behind it in traffic_detail
             common = {"traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
                       "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
-                      "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream", "hbm_view": hbm_view}
+                      "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream",
+                      "launch_overlap_note": "with several batches in flight a launch shares the CUs with the ORB / verification kernels of the other "
+                                             "batches AND, a step being shorter than two launches, with the next batch's kNN launch whose blocks "
+                                             "back-fill its tail: avg_launch_ms in the timed region is an occupancy figure (it approaches ms_per_step); "
+                                             "the kernel's own rate is one_batch_in_flight (DESIGN.md section 3)",
+                      "hbm_view": hbm_view}
             if args.knn != "valu":
                 # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
                 flops = 2.0 * 256 * pairs_per_launch

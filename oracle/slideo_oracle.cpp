@@ -44,6 +44,15 @@
  * plain so_knn_hamming (tests/test_oracle_primitives.py), so that bench.py's CPU leg
  * is not a strawman.
  *
+ * North-star options WITHOUT a reference counterpart (off by default, same PARITY UNPINNED status — OpenCV 4.5.2
+ * recalled, pinned by hand-computable cases and numpy / SciPy cross-checks in tests/test_oracle_{homography,sift,lsh}.py):
+ *   - verify_model 1: find_homography (calib3d fundam.cpp / ptsetreg.cpp / levmarq.cpp, core lapack.cpp JacobiImpl_: RANSAC
+ *     with getSubset / checkSubset, normalised DLT, refit + LMSolver) and warp_perspective_nn_bgr8 (imgwarp.cpp
+ *     WarpPerspectiveInvoker); ocv.hdlt 1 = the 8x8 elimination form of the 4-point model;
+ *   - matcher 1: LshIdx, the candidate rule of FLANN's LshIndex as the reference configures it (mo/flann.rs:14-26);
+ *   - sift_oracle.h: cv::SIFT::detectAndCompute (its own header lists what is restated and the two departures);
+ *   - ratio_test, so_knn_l2_u8 (BFMatcher NORM_L2 on u8 descriptors).
+ *
  * Build: see oracle/Makefile.  All floating point is compiled with
  * -ffp-contract=off so that results do not depend on FMA availability (the FMA
  * variants call fma() explicitly).

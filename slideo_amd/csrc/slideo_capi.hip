@@ -65,7 +65,7 @@ struct OrbOut {            // where the last ORB run of a slot left its results 
 struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_up = nullptr;
+    hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_up = nullptr, ev_knn = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
@@ -150,6 +150,10 @@ struct slideo_matcher {
     int pyr_chain = 0;               // SLIDEO_PYR_CHAIN=1: fused pyramid launches (pyr_chain_kernel) instead of gray_kernel + one resize_kernel per level.
                                      // Off: measured SLOWER — 1.24 + 0.69 + 0.2 ms for the three launches against 0.41 + 1.2 ms
     hipEvent_t last_orb_ev = nullptr;
+    // The search kernels of consecutive units take turns too (SLIDEO_KNN_CHAIN): two launches that share the CUs each last twice
+    // as long for the same throughput
+    int knn_chain = 0;
+    hipEvent_t last_knn_ev = nullptr;
 
     // workspaces
     Slot slots[NSLOTS];
@@ -541,6 +545,8 @@ KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0) {
         // empty slots do).  Measured (r01): 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
         // 3 segments 23.5 ms; 239 query blocks x 517 k rows (128 1080p frames): 2 segments 6.24 ms, 3 segments 6.65 ms
         int nseg = p.qblocks >= 384 ? 1 : std::min(std::max(512 / std::max(p.qblocks, 1), 1), n_st);
+        static const int nseg_env = [] { const char* e = getenv("SLIDEO_KNN_NSEG"); return e ? atoi(e) : 0; }();   // (experiments)
+        if (nseg_env > 0) nseg = std::min(nseg_env, n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
         p.qblocks = cdiv(nq_grid, knn_qpb<2>());
@@ -717,6 +723,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     const int P = (int)m->pages.size();
     HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
     uint32_t* flags = S.d_flags.as<uint32_t>();   // zeroed by orb_stage1
+    if (m->knn_chain && m->last_knn_ev && m->last_knn_ev != S.ev_knn) HIP_CHECK(hipStreamWaitEvent(st, m->last_knn_ev, 0));
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
         // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
@@ -749,6 +756,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
         } else
         run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
         if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
+        if (m->knn_chain) { HIP_CHECK(hipEventRecord(S.ev_knn, st)); m->last_knn_ev = S.ev_knn; }
         if (dedup) {
             knn_expand_dups_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(
                 S.d_keys.as<uint32_t>(), (int)qtot, m->d_grp_next.as<int32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
@@ -1004,6 +1012,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
     if (const char* e = std::getenv("SLIDEO_HOST_UNIT")) mm->host_unit = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("SLIDEO_ORB_CHAIN")) mm->orb_chain = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SLIDEO_KNN_CHAIN")) mm->knn_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_PYR_CHAIN")) mm->pyr_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
@@ -1011,6 +1020,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         for (auto& e : S.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_orb, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&S.ev_knn, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
     }
     HIP_CHECK(hipStreamCreateWithFlags(&mm->copy_st, hipStreamNonBlocking));
@@ -1059,6 +1069,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
         for (auto& e : S.ev) if (e) (void)hipEventDestroy(e);
         if (S.ev_in) (void)hipEventDestroy(S.ev_in);
         if (S.ev_orb) (void)hipEventDestroy(S.ev_orb);
+        if (S.ev_knn) (void)hipEventDestroy(S.ev_knn);
         if (S.ev_up) (void)hipEventDestroy(S.ev_up);
     }
     if (m->copy_st) (void)hipStreamDestroy(m->copy_st);
