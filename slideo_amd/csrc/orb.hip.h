@@ -295,10 +295,16 @@ __device__ __forceinline__ int level_of_tile(const PyrGeom& g, int tile, bool bl
 }
 
 // Tile = FAST_TW x FAST_TH outputs; scores are needed on a 1-px halo (FAST_SW x FAST_SH, FAST_SW = 128 so that a
-// score row is exactly two wave-widths) and raw pixels on a 4-px halo, fetched as aligned dwords.
+// score row is exactly two wave-widths) and raw pixels on a 4-px halo.  The raw tile starts at pixel x0 - 5 (unaligned
+// dword loads from the pyramid), so that score position sx sits at raw column sx + FAST_XO with FAST_XO = 4: the four
+// positions 4j .. 4j + 3 of a row, and the pixels three rows above and below them, are each ONE aligned LDS dword.
 constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (halo 1)
-constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;  // raw tile: halo 4 + up to 3 bytes alignment slack, rounded to a multiple of 4
-static_assert(FAST_SW == 128 && FAST_RW % 4 == 0, "fast_kernel maps one score row onto two wave-widths");
+constexpr int FAST_XO = 4;                                    // raw column of score position 0
+// raw tile: columns 0 .. FAST_SW - 1 + FAST_XO + 3 are needed (135); the row pitch is 35 dwords — ODD, so that the per-position
+// byte reads of phases A2 / B, whose lanes often sit in one column on consecutive rows (a vertical edge), spread over the banks
+// (34 dwords: LDS bank-conflict cycles x 5)
+constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;
+static_assert(FAST_SW == 128 && FAST_RW % 4 == 0 && (FAST_RW / 4) % 2 == 1 && FAST_RW >= FAST_SW + FAST_XO + 3, "fast_kernel maps one score row onto two wave-widths");
 
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short fast_us2 __attribute__((ext_vector_type(2)));
@@ -310,11 +316,11 @@ __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsi
 // tile i's have been committed to LDS, so the global-load latency (the longest single wait of a tile: about 10 k of
 // its 25 k cycles, per-wave s_memtime profile) overlaps tile i's three phases.
 constexpr int FAST_TPB = 8;
-constexpr int FAST_STAGE_CAP = 1024;                                   // survivors staged per block before one list append
+constexpr int FAST_STAGE_CAP = 128;                                    // survivors staged per block before one list append (a tile keeps ~10; LDS: 8 blocks per CU)
 constexpr int FAST_NDW = FAST_RW / 4;                                  // dwords per raw row
 constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dwords per thread and tile
 
-struct FastTile { int l, x0, y0, xa, xoff; };
+struct FastTile { int l, x0, y0; };
 
 // host-side twin of fast_tile_geo: the per-tile table fast_kernel reads (one 16-byte scalar load per tile instead of a loop
 // over the levels' descriptors and an integer division)
@@ -323,14 +329,14 @@ inline int4 fast_tile_entry(const PyrGeom& g, int tile_id) {
     for (int i = 1; i < g.nlevels; ++i) if (g.lv[i].ftx * g.lv[i].fty > 0 && tile_id >= g.lv[i].ftile0) l = i;
     const LevelGeom& L = g.lv[l];
     const int tile = tile_id - L.ftile0, ty = tile / (L.ftx > 0 ? L.ftx : 1), tx = tile - ty * L.ftx;
-    const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH, xa = (x0 - 4) & ~3;
-    return make_int4(l, x0, y0, xa | (((x0 - 4) - xa) << 16));
+    const int x0 = L.rx0 + tx * FAST_TW, y0 = L.ry0 + ty * FAST_TH;
+    return make_int4(l, x0, y0, 0);
 }
 
 __device__ __forceinline__ FastTile fast_tile_geo(const int4* __restrict__ tab, int tile_id) {
     const int4 e = tab[tile_id];
     FastTile T;
-    T.l = e.x; T.x0 = e.y; T.y0 = e.z; T.xa = e.w & 0xffff; T.xoff = e.w >> 16;
+    T.l = e.x; T.x0 = e.y; T.y0 = e.z;
     return T;
 }
 
@@ -341,23 +347,23 @@ __device__ __forceinline__ FastTile fast_tile_geo(const PyrGeom& g, int tile_id)
     const int tile = tile_id - L.ftile0;
     const int ty = tile / L.ftx, tx = tile - ty * L.ftx;
     T.x0 = L.rx0 + tx * FAST_TW; T.y0 = L.ry0 + ty * FAST_TH;
-    T.xa = (T.x0 - 4) & ~3; T.xoff = (T.x0 - 4) - T.xa;                // raw columns start at the dword-aligned xa <= x0-4
     return T;
 }
 
-// raw tile: rows y0-4 .. y0+TH+3, aligned dword loads, clamped to the level (clamped values are never scored)
+// raw tile: rows y0-4 .. y0+TH+3, columns from x0 - 1 - FAST_XO: UNALIGNED dword loads (x0 >= edge_threshold >= 5, so the first
+// byte is inside the row), the byte offset clamped to the row's pitch — a clamped dword holds shifted pixels, all of them right
+// of the level's last column but 3, which no needed position taps (those lie edge_threshold inside).  Rows clamped to the level.
 __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTile& T, const uint8_t* __restrict__ frame_pyr,
                                                  uint32_t (&v)[FAST_NLD]) {
     const LevelGeom& L = g.lv[T.l];
     const uint8_t* img = frame_pyr + L.ofs;
-    const int maxd = (L.pitch >> 2) - 1;
+    const int xs = T.x0 - 1 - FAST_XO, maxo = L.pitch - 4;
 #pragma unroll
     for (int k = 0; k < FAST_NLD; ++k) {
         const int i = min((int)threadIdx.x + 256 * k, FAST_NDW * FAST_RH - 1);
         const int ry = i / FAST_NDW, rd = i - ry * FAST_NDW;
         const int gy = min(max(T.y0 - 4 + ry, 0), L.h - 1);
-        const int gd = min((T.xa >> 2) + rd, maxd);
-        v[k] = reinterpret_cast<const uint32_t*>(img + (int64_t)gy * L.pitch)[gd];
+        __builtin_memcpy(&v[k], img + (int64_t)gy * L.pitch + min(xs + 4 * rd, maxo), 4);
     }
 }
 
@@ -366,8 +372,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
                                                    uint32_t* __restrict__ hist, const int4* __restrict__ tile_tab) {
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
-    constexpr int FAST_Q1W = ((FAST_SH + 3) / 4) * FAST_SW;            // a wave's private share of queue1: its score rows (sy % 4 == wave)
-    __shared__ uint16_t queue[4 * FAST_Q1W];
+    // a wave's private share of the queue: its score rows (sy % 4 == wave), back to back
+    constexpr int FAST_QR0 = (FAST_SH + 3) / 4, FAST_QR1 = (FAST_SH + 2) / 4, FAST_QR2 = (FAST_SH + 1) / 4;
+    __shared__ uint16_t queue[FAST_SH * FAST_SW];
     __shared__ uint32_t qcnt[4];
     // survivors of the block's tiles are staged in LDS and appended to the level's candidate list with ONE returning
     // global atomic per flush (a flush per tile kept every tile waiting for its own round trip); same for the histogram
@@ -418,7 +425,8 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     fast_issue_loads(g, Tn, frame_pyr, pre);
     const int l = T.l;
     const LevelGeom& L = g.lv[l];
-    const int x0 = T.x0, y0 = T.y0, xoff = T.xoff;
+    const int x0 = T.x0, y0 = T.y0;
+    constexpr int xoff = FAST_XO - 3;
     __syncthreads();
     // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...,
     // lane covers sx = lane and lane + 64 (no divisions, constant LDS offsets).  Every arc of 9 contains one pixel of
@@ -430,44 +438,59 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     // |a - v| = sat(a - v) | sat(v - a), "either pixel of a pair differs" = max of the two, "every pair" = min over the
     // pairs, "> t" = a saturating subtract of t that leaves a non-zero half.  No short-circuit operators: a stage's
     // LDS reads are issued together.
+    // A1 — the vertical pair on every position, FOUR positions per lane: lanes 0..31 take positions 4j .. 4j + 3 of score row
+    // sy, lanes 32..63 those of row sy + 4; centre, top (-3 rows) and bottom (+3 rows) pixels are one aligned ds_read_b32 each.
+    // First a sufficient wave-level reject: the sum of a lane's four |top - centre| (v_sad_u8), and of its four
+    // |bottom - centre|, both <= t means every one of them is — a flat stretch leaves the whole wave after 3 + 3 instructions.
+    // Otherwise the exact test on the even and the odd bytes as packed u16: max(|top - v|, |bottom - v|) =
+    // max(sat(max(top, bottom) - v), sat(v - min(top, bottom))), "> t" = a saturating subtract of t that leaves a non-zero half.
+    // Survivors (5 - 10 % of the positions of a text frame) are queued; every wave appends to its own quarter of the queue
+    // with a wave-uniform count: no atomics, no waits.
     const fast_us2 tt = {(unsigned short)t, (unsigned short)t};
-    auto pk = [](int lo, int hi) { return fast_us2{(unsigned short)lo, (unsigned short)hi}; };
-    auto absd = [](fast_us2 a, fast_us2 v) { return __builtin_elementwise_sub_sat(a, v) | __builtin_elementwise_sub_sat(v, a); };
-    const uint32_t in0 = (x0 - 1 + lane <= L.rx1) ? 0xFFFFu : 0u, in1 = (x0 - 1 + lane + 64 <= L.rx1) ? 0xFFFF0000u : 0u;
-    const uint32_t inmask = in0 | in1;
-    // two score rows (sy, sy + 4) per round, so that each of the two dependent LDS round trips of a round — the vertical
-    // pair, then the other six pixels — serves 256 positions
-    auto stage1 = [&](const uint8_t* c0, const uint8_t* c1, fast_us2& v, fast_us2& m1) {
-        v = pk(c0[0], c1[0]);
-        m1 = __builtin_elementwise_max(absd(pk(c0[-3 * FAST_RW], c1[-3 * FAST_RW]), v), absd(pk(c0[3 * FAST_RW], c1[3 * FAST_RW]), v));
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(m1, tt)) & inmask;
-    };
-    // A1 — the vertical pair on every position, packed two positions per register; survivors (5 - 10 % of the positions of a
-    // text frame) are queued.  The other three pairs used to be tested here too, by the whole wave whenever ANY of its 256
-    // positions survived the first — 16 of the kernel's 29 instructions per pixel; now only the survivors take them (A2).
-    // Every wave appends to its own quarter of the queue with a wave-uniform count: no atomics, no waits.
     uint32_t myn = 0;
-    uint16_t* const myq = queue + wave * FAST_Q1W;
+    const int qbase = (wave == 0 ? 0 : wave == 1 ? FAST_QR0 : wave == 2 ? FAST_QR0 + FAST_QR1 : FAST_QR0 + FAST_QR1 + FAST_QR2) * FAST_SW;
+    uint16_t* const myq = queue + qbase;
     auto push1 = [&](bool cond, uint32_t val) {
         const uint64_t mk = __builtin_amdgcn_ballot_w64(cond);
         if (mk == 0ull) return;                                          // wave-uniform
         if (cond) myq[myn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)val;
         myn += (uint32_t)__popcll(mk);
     };
-    for (int sy = wave; sy < FAST_SH; sy += 8) {
-        if (y0 - 1 + sy > L.ry1) break;
-        const int syb = min(sy + 4, FAST_SH - 1);                       // (a clamped second row repeats work, never queues)
-        const bool rowb = sy + 4 < FAST_SH && y0 - 1 + sy + 4 <= L.ry1;
-        const uint8_t* a0 = &raw[sy + 3][lane + 3 + xoff];
-        const uint8_t* b0 = &raw[syb + 3][lane + 3 + xoff];
-        fast_us2 va, ma, vb, mb;
-        const uint32_t s1a = stage1(a0, a0 + 64, va, ma);
-        const uint32_t s1b = rowb ? stage1(b0, b0 + 64, vb, mb) : (stage1(b0, b0 + 64, vb, mb), 0u);
-        if (__builtin_amdgcn_ballot_w64((s1a | s1b) != 0u) == 0ull) continue;
-        push1((s1a & 0xFFFFu) != 0u, (uint32_t)(sy * FAST_SW + lane));
-        push1((s1a >> 16) != 0u, (uint32_t)(sy * FAST_SW + lane + 64));
-        push1((s1b & 0xFFFFu) != 0u, (uint32_t)(syb * FAST_SW + lane));
-        push1((s1b >> 16) != 0u, (uint32_t)(syb * FAST_SW + lane + 64));
+    {
+        const int half = lane >> 5, j4 = (lane & 31) * 4;
+        // positions of this lane inside the keep-region's halo: x0 - 1 + j4 + k <= L.rx1
+        const int nin = min(max(L.rx1 - (x0 - 1) - j4 + 1, 0), 4);
+        const uint32_t vmask = nin >= 4 ? 0xFu : ((1u << nin) - 1u);
+        const uint32_t* const raw32 = reinterpret_cast<const uint32_t*>(&raw[0][0]) + ((j4 + FAST_XO) >> 2);
+        auto ev = [](uint32_t x) { return __builtin_bit_cast(fast_us2, __builtin_amdgcn_perm(0u, x, 0x0c020c00u)); };   // bytes (b0, 0, b2, 0)
+        auto od = [](uint32_t x) { return __builtin_bit_cast(fast_us2, __builtin_amdgcn_perm(0u, x, 0x0c030c01u)); };   // bytes (b1, 0, b3, 0)
+        for (int sy = wave; sy < FAST_SH; sy += 8) {
+            if (y0 - 1 + sy > L.ry1) break;
+            const int syl = min(sy + 4 * half, FAST_SH - 1);                // (a clamped second row repeats work, never queues)
+            const bool rowok = sy + 4 * half < FAST_SH && y0 - 1 + syl <= L.ry1;
+            const uint32_t* const c32 = raw32 + (syl + 3) * FAST_NDW;
+            const uint32_t vc = c32[0], vt = c32[-3 * FAST_NDW], vb = c32[3 * FAST_NDW];
+            const uint32_t sad = max(__builtin_amdgcn_sad_u8(vt, vc, 0u), __builtin_amdgcn_sad_u8(vb, vc, 0u));
+            if (__builtin_amdgcn_ballot_w64(rowok && sad > (uint32_t)t) == 0ull) continue;
+            uint32_t fl = 0;
+            {
+                const fast_us2 ce = ev(vc), te = ev(vt), be = ev(vb), co = od(vc), to = od(vt), bo = od(vb);
+                const fast_us2 de = __builtin_elementwise_max(__builtin_elementwise_sub_sat(__builtin_elementwise_max(te, be), ce),
+                                                              __builtin_elementwise_sub_sat(ce, __builtin_elementwise_min(te, be)));
+                const fast_us2 dd = __builtin_elementwise_max(__builtin_elementwise_sub_sat(__builtin_elementwise_max(to, bo), co),
+                                                              __builtin_elementwise_sub_sat(co, __builtin_elementwise_min(to, bo)));
+                const uint32_t re = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(de, tt));
+                const uint32_t ro = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(dd, tt));
+                fl = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
+                fl = rowok ? (fl & vmask) : 0u;
+            }
+            if (__builtin_amdgcn_ballot_w64(fl != 0u) == 0ull) continue;
+            const uint32_t p0 = (uint32_t)(syl * FAST_SW + j4);
+            push1((fl & 1u) != 0u, p0);
+            push1((fl & 2u) != 0u, p0 + 1);
+            push1((fl & 4u) != 0u, p0 + 2);
+            push1((fl & 8u) != 0u, p0 + 3);
+        }
     }
     // A2 — the horizontal pair and the two diagonals, one survivor per lane, by the wave that queued it (score rows are dealt
     // to the waves modulo 4, so the shares are balanced): its quarter of the queue is compacted in place — a chunk's 64 reads
@@ -497,7 +520,8 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const uint32_t qc1 = qcnt[0], qc2 = qc1 + qcnt[1], qc3 = qc2 + qcnt[2];
     auto qat = [&](uint32_t kq) -> int {
         const uint32_t r = (kq >= qc1) + (kq >= qc2) + (kq >= qc3);
-        return queue[r * FAST_Q1W + kq - (r == 0 ? 0u : r == 1 ? qc1 : r == 2 ? qc2 : qc3)];
+        return queue[(r == 0 ? 0u : r == 1 ? (uint32_t)FAST_QR0 * FAST_SW - qc1 : r == 2 ? (uint32_t)(FAST_QR0 + FAST_QR1) * FAST_SW - qc2
+                                                                                            : (uint32_t)(FAST_QR0 + FAST_QR1 + FAST_QR2) * FAST_SW - qc3) + kq];
     };
     // Phase B — segment test + cornerScore<16> on the queued positions only
     const uint32_t nqueued = qc3 + qcnt[3];

@@ -62,31 +62,54 @@ __device__ __forceinline__ int sift_reflect101(int p, int n) {
     return p;
 }
 
-// grid (ceil(2w / 256), 2h, n)
+// One thread per SOURCE pixel (i, j): the 2 x 2 block of outputs (2i .. 2i + 1, 2j .. 2j + 1) taps the 3 x 3 gray values around it —
+// 9 gray conversions for 4 outputs instead of 16, two 8-byte stores.  The interpolation is resize(INTER_LINEAR)'s: per output
+// coordinate (i0, i1, a0, a1) from the same expression as the oracle (borders clamp to weight 1 / 0), t = g0 a0 + g1 a1 per row,
+// then t0 b0 + t1 b1: unfused multiplies and adds.   grid (ceil(w / 256), h, n)
 __global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride, int stride, int w, int h,
                                                         GrayCoef gc, float* __restrict__ out, int64_t out_frame) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= w) return;
     const int W = 2 * w;
-    if (x >= W) return;
     const uint8_t* img = frames + (int64_t)blockIdx.z * frame_stride;
+    const int cm = max(i - 1, 0), cp = min(i + 1, w - 1), rm = max(j - 1, 0), rp = min(j + 1, h - 1);
     auto gray = [&](int yy, int xx) -> float {
         const uint8_t* p = img + (int64_t)yy * stride + 3 * xx;
         return (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1u << (gc.shift - 1))) >> gc.shift);
     };
-    auto coef = [](int d, int n, int& i0, int& i1, float& a0, float& a1) {
+    const float g[3][3] = {{gray(rm, cm), gray(rm, i), gray(rm, cp)}, {gray(j, cm), gray(j, i), gray(j, cp)}, {gray(rp, cm), gray(rp, i), gray(rp, cp)}};
+    // (index into the 3-neighbourhood of source coordinate q around centre `ctr`: 0, 1, 2 = ctr - 1, ctr, ctr + 1 after clamping)
+    auto coef = [](int d, int n, int ctr, int& k0, int& k1, float& a0, float& a1) {
         float f = (float)(((double)d + 0.5) * 0.5 - 0.5);
         int s = (int)floorf(f);
         f -= (float)s;
         if (s < 0) { s = 0; f = 0; }
         if (s >= n - 1) { s = n - 1; f = 0; }
-        i0 = s; i1 = min(s + 1, n - 1); a0 = 1.f - f; a1 = f;
+        const int i0 = s, i1 = min(s + 1, n - 1);
+        k0 = i0 < ctr ? 0 : (i0 > ctr ? 2 : 1); k1 = i1 < ctr ? 0 : (i1 > ctr ? 2 : 1);
+        a0 = 1.f - f; a1 = f;
     };
-    int x0, x1, y0, y1; float a0, a1, b0, b1;
-    coef(x, w, x0, x1, a0, a1);
-    coef(y, h, y0, y1, b0, b1);
-    const float t0 = gray(y0, x0) * a0 + gray(y0, x1) * a1;
-    const float t1 = gray(y1, x0) * a0 + gray(y1, x1) * a1;
-    out[(int64_t)blockIdx.z * out_frame + (int64_t)y * W + x] = t0 * b0 + t1 * b1;
+    auto pick = [](const float (&row)[3], int k) -> float { return k == 0 ? row[0] : (k == 1 ? row[1] : row[2]); };
+    float res[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        int ky0, ky1; float b0, b1;
+        coef(2 * j + dy, h, j, ky0, ky1, b0, b1);
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            int kx0, kx1; float a0, a1;
+            coef(2 * i + dx, w, i, kx0, kx1, a0, a1);
+            const float r0[3] = {g[0][0], g[1][0], g[2][0]}, r1[3] = {g[0][1], g[1][1], g[2][1]}, r2[3] = {g[0][2], g[1][2], g[2][2]};
+            // gray value at (row index ky, column index kx)
+            auto at = [&](int ky, int kx) -> float { return kx == 0 ? pick(r0, ky) : (kx == 1 ? pick(r1, ky) : pick(r2, ky)); };
+            const float t0 = at(ky0, kx0) * a0 + at(ky0, kx1) * a1;
+            const float t1 = at(ky1, kx0) * a0 + at(ky1, kx1) * a1;
+            res[dy][dx] = t0 * b0 + t1 * b1;
+        }
+    }
+    float* o = out + (int64_t)blockIdx.z * out_frame + (int64_t)(2 * j) * W + 2 * i;
+    *reinterpret_cast<float2*>(o) = make_float2(res[0][0], res[0][1]);
+    *reinterpret_cast<float2*>(o + W) = make_float2(res[1][0], res[1][1]);
 }
 
 // grid (tiles_x * tiles_y, n), block 256.  src / dst: layer pointers of frame 0, per-frame strides in floats.
@@ -210,6 +233,125 @@ __global__ __launch_bounds__(256) void sift_blur_fast_kernel(const float* __rest
     }
 }
 
+// The same filter as a STREAM (the default for compile-time tap counts): one wave owns a strip of 64 output columns and walks
+// down `chunk_h` rows of it, eight rows per step.  The tile kernel above pays for its two block barriers and for 58 KB of LDS
+// (two blocks per CU: the fill of one tile is exposed while the other computes) and recomputes the row pass on a (64 + 2R) / 64
+// vertical halo.  Here, per step of 8 rows:
+//   * the 8 input rows (64 + 2R columns, reflected at the image borders element by element) of the NEXT step are requested by
+//     LDS-DMA into the other half of a double buffer (12 instructions of 64 dwords, row pitch 96) — no registers, one step ahead;
+//   * row pass: lane (row r of the 8, segment s of 8) reads the N + 7 floats its 8 outputs need from the buffer (ds_read_b128),
+//     8 N fused multiply-adds in tap order, and hands the 8 results to the column lanes through a 2 KB staging tile;
+//   * column pass — lane = column — keeps the last 8 (LAG + 1) row-pass values of its column in REGISTERS (a window shifted by 8
+//     per step) and produces 8 vertically adjacent outputs (centre, then the symmetric pairs outward), LAG = ceil(2R / 8) steps
+//     behind the row pass; writes the layer and, if asked, the difference to the input layer (one more coalesced read).
+// A row-pass row is computed once per chunk (+ 2R warm-up rows), LDS is 8.2 KB per wave whatever N, no block barrier exists: the
+// four waves of a block are independent strips.  Per output value the operation order is the tile kernel's and the generic
+// kernel's: bit-identical.   grid (ceil(strips * chunks / 4), n), block 256.
+template <int N, bool FMA>
+__global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
+                                                               float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h) {
+    constexpr int R = N / 2, LAG = (2 * R + 7) / 8, WIN = 8 * (LAG + 1), IW = 64 + 2 * R, IP = 96, NV4 = (N + 7 + 3) / 4, SP = 68;
+    static_assert(IW <= IP && 4 * NV4 + 56 <= IP, "input row pitch");
+    __shared__ __attribute__((aligned(16))) float s_in[4][2][8 * IP];
+    __shared__ __attribute__((aligned(16))) float s_st[4][8 * SP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strips_x = (w + 63) >> 6, chunks = (h + chunk_h - 1) / chunk_h;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= strips_x * chunks) return;                                  // (wave-uniform)
+    const int cy = task / strips_x, sx = task - cy * strips_x;
+    const int x0 = sx * 64, y0 = cy * chunk_h, y1 = min(h, y0 + chunk_h);
+    const float* S = src + (int64_t)blockIdx.y * src_frame;
+    float* D = dst + (int64_t)blockIdx.y * dst_frame;
+    float* G = dog ? dog + (int64_t)blockIdx.y * dog_frame : nullptr;
+    float* const IN = s_in[wave][0];
+    float* const ST = s_st[wave];
+    float k[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { k[j] = tp.k[j]; asm volatile("" : "+v"(k[j])); }
+    auto mad = [](float a, float b, float c) -> float { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
+    // DMA map: 8 rows x 96 dwords = 12 instructions of 64 dwords; instruction 3m + u fills dwords 64 (3m + u) .. + 63 = rows 2m, 2m + 1:
+    //   u = 0: row 2m, columns 0..63;  u = 1: lanes 0..31 row 2m columns 64..95, lanes 32..63 row 2m + 1 columns 0..31;  u = 2: row 2m + 1, columns 32..95
+    int colofs[3]; bool second[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int d = 64 * u + lane, col = d >= IP ? d - IP : d;
+        second[u] = d >= IP;
+        colofs[u] = sift_reflect101(x0 - R + min(col, IW - 1), w);
+    }
+    auto dma_rows = [&](int tb, int buf) {                                   // input rows tb .. tb + 7 -> IN[buf]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ra = sift_reflect101(tb + 2 * m, h), rb = sift_reflect101(tb + 2 * m + 1, h);       // (scalar)
+            const float* pa = S + (int64_t)ra * w;
+            const float* pb = S + (int64_t)rb * w;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const float* ga = (second[u] ? pb : pa) + colofs[u];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                                 (__attribute__((address_space(3))) void*)(IN + buf * (8 * IP) + 64 * (3 * m + u)), 4, 0, 0);
+            }
+        }
+    };
+    const int rr = lane >> 3, sg = lane & 7;
+    const int gx = x0 + lane;
+    const int nY = (y1 - y0 + 7) >> 3, M = nY + LAG;
+    float c[WIN];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t) c[t] = 0.f;
+    dma_rows(y0 - R, 0);
+    for (int m = 0; m < M; ++m) {
+        const int buf = m & 1;
+        if (m + 1 < M) { dma_rows(y0 - R + 8 * (m + 1), buf ^ 1); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {   // row pass
+            float v[4 * NV4];
+            const float4* p = reinterpret_cast<const float4*>(IN + buf * (8 * IP) + rr * IP + 8 * sg);
+#pragma unroll
+            for (int q = 0; q < NV4; ++q) { const float4 t4 = p[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+            float acc[8];
+#pragma unroll
+            for (int t = 0; t < N + 7; ++t) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const int j = t - o;
+                    if (j == 0) acc[o] = k[0] * v[t];
+                    else if (j > 0 && j < N) acc[o] = mad(k[j], v[t], acc[o]);
+                }
+            }
+            float4* q = reinterpret_cast<float4*>(ST + rr * SP + 8 * sg);
+            q[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            q[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // window: c[u] = row-pass value of row y0 - R + 8 (m - LAG) + u
+#pragma unroll
+        for (int t = 0; t < WIN - 8; ++t) c[t] = c[t + 8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) c[WIN - 8 + t] = ST[t * SP + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (m >= LAG) {
+            const int Y = y0 + 8 * (m - LAG);
+            float sv[8];
+            if (G) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) sv[o] = S[(int64_t)min(Y + o, h - 1) * w + min(gx, w - 1)];
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float sacc = k[R] * c[o + R];
+#pragma unroll
+                for (int j = 1; j <= R; ++j) sacc = mad(k[R + j], c[o + R + j] + c[o + R - j], sacc);
+                const int gy = Y + o;
+                if (gx < w && gy < y1) {
+                    D[(int64_t)gy * w + gx] = sacc;
+                    if (G) G[(int64_t)gy * w + gx] = sacc - sv[o];
+                }
+            }
+        }
+    }
+}
+
 // dst(x, y) = src(2x, 2y).  grid (ceil(dw / 256), dh, n)
 __global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict__ src, int64_t src_frame, int sw, float* __restrict__ dst,
                                                         int64_t dst_frame, int dw, int dh) {
@@ -218,56 +360,96 @@ __global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict_
     dst[(int64_t)blockIdx.z * dst_frame + (int64_t)y * dw + x] = src[(int64_t)blockIdx.z * src_frame + (int64_t)(2 * y) * sw + 2 * x];
 }
 
-// candidate = o << 28 | layer << 26 | r << 13 | c.  grid (ceil(ow / 64), ceil(oh / 32), n * 3 layers), block 256 = 64 columns x 4
-// row groups, 8 rows per thread (one pixel per thread made 18 M four-instruction waves per launch: dispatch bound; the 8 values
-// of a thread are requested together, and almost every pixel ends at the threshold test).
-constexpr int SIFT_EX_ROWS = 8;
-__global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParams sp, int o, const float* __restrict__ dogp,
+// The difference-of-Gaussians pyramid is NOT stored: DoG layer L of an octave is Gaussian layer L + 1 minus layer L, one f32
+// subtraction of two stored values — the same value whether the blur kernel writes it or a reader recomputes it (the blur
+// kernels can still write it: `dog` argument).  Not storing it takes a third of the blur's HBM traffic and 5 / 11 of the workspace;
+// the readers (extrema, refinement) load two values instead of one.
+struct SiftDog {
+    const float* g; int64_t lsz;                                            // Gaussian layer L (layer L + 1 is lsz floats further)
+    __device__ __forceinline__ float operator[](int64_t i) const { return g[i + lsz] - g[i]; }
+    __device__ __forceinline__ SiftDog operator+(int64_t d) const { return SiftDog{g + d, lsz}; }
+    __device__ __forceinline__ SiftDog operator-(int64_t d) const { return SiftDog{g - d, lsz}; }
+};
+
+// candidate = o << 28 | layer << 26 | r << 13 | c.
+// A point is an extremum iff it is the maximum (or minimum) of the 27 values around it in (x, y, layer) — itself included, so
+// "val >= all 26 neighbours" is "val >= max27".  The 3 x 3 x 3 maximum is separable: a thread owns one column and walks down the
+// rows of ALL FIVE difference layers of the octave (six Gaussian layers: one load each per row, five subtractions), the horizontal 3-maximum / 3-minimum through its
+// neighbours' registers (DPP wave shifts), the vertical one over a 3-row register ring, the layer one across the rings — every
+// pyramid value is read from memory exactly once (the one-thread-per-point form re-read 27 values wherever a wave held a point above
+// the threshold, i.e. almost everywhere on a text frame, and was bound by the texture path: 30 ms per 256 frames).
+// A wave covers 64 columns and emits for its lanes 1 .. 62; block = 4 waves = 4 column groups; grid (ceil(cols / 248),
+// ceil(rows / SIFT_EX_RCH), n), cols / rows = the octave's sides minus the 5-px borders.
+constexpr int SIFT_EX_RCH = 34;                 // output rows per block (+ 2 halo rows = 36 row steps, a multiple of the 3-slot ring)
+
+__device__ __forceinline__ float sift_wave_shr1(float v) {      // lane i <- lane i - 1 (lane 0 keeps its own)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float sift_wave_shl1(float v) {      // lane i <- lane i + 1 (lane 63 keeps its own)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+__global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParams sp, int o, const float* __restrict__ gauss,
                                                            uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t* __restrict__ flags) {
-    const int f = blockIdx.z / SIFT_NL, layer = 1 + blockIdx.z % SIFT_NL;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = blockIdx.y * (4 * SIFT_EX_ROWS) + (threadIdx.x >> 6) * SIFT_EX_ROWS;
+    const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = g.ow[o], h = g.oh[o];
-    if (c < SIFT_BORDER || c >= w - SIFT_BORDER) return;
+    const int c = SIFT_BORDER - 1 + (blockIdx.x * 4 + wave) * 62 + lane;          // this lane's column (lanes 0 / 63: halo only)
+    if (c - lane + 1 >= w - SIFT_BORDER) return;                                   // (wave-uniform: no output column in this group)
+    const int ry0 = SIFT_BORDER + blockIdx.y * SIFT_EX_RCH;
     const int64_t lsz = (int64_t)w * h;
-    const float* img = dogp + (int64_t)f * g.d_frame + g.d_ofs[o] + lsz * layer;
-    const float* prev = img - lsz;
-    const float* next = img + lsz;
-    float vals[SIFT_EX_ROWS];
+    const float* base = gauss + (int64_t)f * g.g_frame + g.g_ofs[o] + min(c, w - 1);
+    const bool col_ok = lane >= 1 && lane <= 62 && c < w - SIFT_BORDER;
+    const float thr = (float)sp.threshold;
+    float val[5][3], hx[5][3], hn[5][3];
+    auto load_row = [&](int i, float (&v)[5]) {
+        const int r = min(ry0 - 1 + i, h - 1);
+        float gl[6];
 #pragma unroll
-    for (int i = 0; i < SIFT_EX_ROWS; ++i) {
-        const int r = r0 + i;
-        vals[i] = (r >= SIFT_BORDER && r < h - SIFT_BORDER) ? img[(int64_t)r * w + c] : 0.f;       // (0 fails the threshold test)
-    }
+        for (int L = 0; L < 6; ++L) gl[L] = base[lsz * L + (int64_t)r * w];
 #pragma unroll
-    for (int i = 0; i < SIFT_EX_ROWS; ++i) {
-        const float val = vals[i];
-        if (!(fabsf(val) > (float)sp.threshold)) continue;
-        const int r = r0 + i;
-        const int64_t p = (int64_t)r * w + c;
-        bool ext = true;
-        if (val > 0) {
+        for (int L = 0; L < 5; ++L) v[L] = gl[L + 1] - gl[L];
+    };
+    auto step = [&](auto slot_tag, int i, const float (&v)[5]) {
+        constexpr int S = decltype(slot_tag)::value, S1 = (S + 2) % 3;           // S1 = the slot of the previous row (the centre row)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int64_t q = p + dy * w + dx;
-                    if (dy || dx) ext = ext && (val >= img[q]);
-                    ext = ext && (val >= prev[q]) && (val >= next[q]);
-                }
-        } else {
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int64_t q = p + dy * w + dx;
-                    if (dy || dx) ext = ext && (val <= img[q]);
-                    ext = ext && (val <= prev[q]) && (val <= next[q]);
-                }
+        for (int L = 0; L < 5; ++L) {
+            const float a = sift_wave_shr1(v[L]), b = sift_wave_shl1(v[L]);
+            val[L][S] = v[L];
+            hx[L][S] = fmaxf(fmaxf(a, v[L]), b);
+            hn[L][S] = fminf(fminf(a, v[L]), b);
         }
-        if (!ext) continue;
-        const uint32_t slot = atomicAdd(&cand_count[f], 1u);
-        if (slot >= (uint32_t)sp.cand_cap) { atomicOr(flags, 16u); continue; }
-        cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)layer << 26) | ((uint32_t)r << 13) | (uint32_t)c;
+        if (i < 2) return;
+        const int rc = ry0 + i - 2;                                               // centre row of this step
+        if (rc >= h - SIFT_BORDER) return;                                        // (uniform)
+        float vx[5], vn[5];
+#pragma unroll
+        for (int L = 0; L < 5; ++L) {
+            vx[L] = fmaxf(fmaxf(hx[L][0], hx[L][1]), hx[L][2]);
+            vn[L] = fminf(fminf(hn[L][0], hn[L][1]), hn[L][2]);
+        }
+#pragma unroll
+        for (int L = 1; L <= 3; ++L) {
+            const float x = val[L][S1];
+            const float mx = fmaxf(fmaxf(vx[L - 1], vx[L]), vx[L + 1]), mn = fminf(fminf(vn[L - 1], vn[L]), vn[L + 1]);
+            const bool ext = col_ok && fabsf(x) > thr && (x > 0 ? x >= mx : x <= mn);
+            if (ext) {
+                const uint32_t slot = atomicAdd(&cand_count[f], 1u);
+                if (slot >= (uint32_t)sp.cand_cap) atomicOr(flags, 16u);
+                else cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)L << 26) | ((uint32_t)rc << 13) | (uint32_t)c;
+            }
+        }
+    };
+    using S0 = std::integral_constant<int, 0>; using S1t = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    float va[5], vb[5], vc[5];
+    load_row(0, va); load_row(1, vb); load_row(2, vc);
+    for (int i = 0; i < SIFT_EX_RCH + 2; i += 3) {
+        if (ry0 + i - 2 >= h - SIFT_BORDER) break;                                // (uniform: nothing left to emit)
+        float na[5], nb[5], nc[5];                                                // the next three rows, requested before this trio is used
+        load_row(i + 3, na); load_row(i + 4, nb); load_row(i + 5, nc);
+        step(S0{}, i, va); step(S1t{}, i + 1, vb); step(S2{}, i + 2, vc);
+#pragma unroll
+        for (int L = 0; L < 5; ++L) { va[L] = na[L]; vb[L] = nb[L]; vc[L] = nc[L]; }
     }
 }
 
@@ -286,7 +468,7 @@ __device__ __forceinline__ void sift_solve3(const float (&a)[3][3], const float 
 __device__ __forceinline__ float sift_expf(float x) { return (float)exp((double)x); }
 
 // grid (cand_cap / 4, n), block 256 = 4 waves, one candidate per wave
-__global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams sp, const float* __restrict__ gauss, const float* __restrict__ dogp,
+__global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams sp, const float* __restrict__ gauss,
                                                           const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_count,
                                                           SiftRaw* __restrict__ raw, uint32_t* __restrict__ raw_count, uint32_t* __restrict__ flags) {
     __shared__ unsigned long long s_hist[4][SIFT_BINS];
@@ -300,15 +482,15 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams
     int layer = (int)((cw >> 26) & 3), r = (int)((cw >> 13) & 8191), c = (int)(cw & 8191);
     const int w = g.ow[octv], h = g.oh[octv];
     const int64_t lsz = (int64_t)w * h;
-    const float* dbase = dogp + (int64_t)f * g.d_frame + g.d_ofs[octv];
+    const SiftDog dbase{gauss + (int64_t)f * g.g_frame + g.g_ofs[octv], lsz};
     const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
     float xi = 0, xr = 0, xc = 0;
     int it = 0;
     bool ok = true;
     for (; it < SIFT_STEPS; ++it) {
-        const float* img = dbase + lsz * layer;
-        const float* prev = img - lsz;
-        const float* next = img + lsz;
+        const SiftDog img = dbase + lsz * layer;
+        const SiftDog prev = img - lsz;
+        const SiftDog next = img + lsz;
         const int64_t p = (int64_t)r * w + c;
         const float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + w] - img[p - w]) * deriv_scale, (next[p] - prev[p]) * deriv_scale};
         const float v2 = img[p] * 2;
@@ -331,9 +513,9 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams
     if (!ok || it >= SIFT_STEPS) return;
     slideo_keypoint kpt;
     {
-        const float* img = dbase + lsz * layer;
-        const float* prev = img - lsz;
-        const float* next = img + lsz;
+        const SiftDog img = dbase + lsz * layer;
+        const SiftDog prev = img - lsz;
+        const SiftDog next = img + lsz;
         const int64_t p = (int64_t)r * w + c;
         const float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + w] - img[p - w]) * deriv_scale, (next[p] - prev[p]) * deriv_scale};
         const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;

@@ -1755,9 +1755,21 @@ void sift_check_cfg(const slideo_sift_config* sc, int w, int h) {
 
 template <int N>
 void sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n, const SiftTaps& tp, hipStream_t st) {
-    const dim3 grid(cdiv(w, 64) * cdiv(h, 64), n);
-    if (fma) sift_blur_fast_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
-    else sift_blur_fast_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+    static const bool tiles = std::getenv("SLIDEO_SIFT_BLUR_TILES") != nullptr;                   // A/B: the 64 x 64 tile kernel
+    if (tiles) {
+        const dim3 grid(cdiv(w, 64) * cdiv(h, 64), n);
+        if (fma) sift_blur_fast_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+        else sift_blur_fast_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
+        return;
+    }
+    // streams: one wave per (64-column strip, chunk of rows); chunks sized so that a launch has ~16 k waves (several rounds of the chip: a short tail)
+    const int strips = cdiv(w, 64);
+    static const int target_waves = [] { const char* e = std::getenv("SLIDEO_SIFT_WAVES"); return e ? std::max(atoi(e), 1) : 16384; }();
+    const int chunks = std::min(std::max(cdiv(target_waves, strips * std::max(n, 1)), 1), cdiv(h, 64));
+    const int chunk_h = (cdiv(h, chunks) + 7) & ~7;
+    const dim3 grid(cdiv(strips * cdiv(h, chunk_h), 4), n);
+    if (fma) sift_blur_stream_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h);
+    else sift_blur_stream_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h);
 }
 
 void sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n,
@@ -1789,14 +1801,12 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
     const int64_t base_frame = (int64_t)g.ow[0] * g.oh[0];
     W.base.reserve((size_t)base_frame * nb * 4);
     W.gauss.reserve((size_t)g.g_frame * nb * 4 + 64);
-    W.dog.reserve((size_t)g.d_frame * nb * 4 + 64);
     const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
-    sift_base_kernel<<<dim3(cdiv(2 * w, 256), 2 * h, nb), 256, 0, st>>>(frames_dev, fs, stride, w, h, gc, W.base.as<float>(), base_frame);
+    sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, w, h, gc, W.base.as<float>(), base_frame);
     check_launch("sift_base_kernel");
     const float sigma = (float)sc.sigma;
     const float sig_diff = std::sqrt(std::max(sigma * sigma - 0.5f * 0.5f * 4, 0.01f));
     float* G = W.gauss.as<float>();
-    float* D = W.dog.as<float>();
     sift_blur_launch(m, W.base.as<float>(), base_frame, G + g.g_ofs[0], g.g_frame, nullptr, 0, g.ow[0], g.oh[0], nb, sift_taps(sig_diff), st);
     double sig[SIFT_NL + 3];
     sig[0] = sc.sigma;
@@ -1811,7 +1821,7 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
             check_launch("sift_half_kernel");
         }
         for (int i = 1; i < SIFT_NL + 3; ++i)
-            sift_blur_launch(m, G + g.g_ofs[o] + lsz * (i - 1), g.g_frame, G + g.g_ofs[o] + lsz * i, g.g_frame, D + g.d_ofs[o] + lsz * (i - 1), g.d_frame,
+            sift_blur_launch(m, G + g.g_ofs[o] + lsz * (i - 1), g.g_frame, G + g.g_ofs[o] + lsz * i, g.g_frame, nullptr, 0,      // (the DoG layers are not stored: SiftDog)
                              ow, oh, nb, sift_taps(sig[i]), st);
     }
 }
@@ -1828,7 +1838,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
     sp.threshold = (int)std::floor(0.5 * sc.contrast_threshold / SIFT_NL * 255);
     sp.atan_fma = m->cfg.ocv.atan; sp.blur_fma = m->cfg.ocv.blur != 1;
     // frames per pass under a 24 GB budget for the pyramids (486 MB per 1080p frame)
-    const size_t per = ((size_t)g.g_frame + (size_t)g.d_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
+    const size_t per = ((size_t)g.g_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
     const int nb_max = (int)std::max<size_t>(1, ((size_t)24 << 30) / std::max<size_t>(per, 1));
     int64_t rows = 0;
     for (int f0 = 0; f0 < n; f0 += nb_max) {
@@ -1848,7 +1858,8 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
         HIP_CHECK(hipMemsetAsync(W.info.p, 0, 32, st));
         for (int o = 0; o < g.n_oct; ++o) {
             if (g.ow[o] <= 2 * SIFT_BORDER || g.oh[o] <= 2 * SIFT_BORDER) continue;
-            sift_extrema_kernel<<<dim3(cdiv(g.ow[o], 64), cdiv(g.oh[o], 4 * SIFT_EX_ROWS), nb * SIFT_NL), 256, 0, st>>>(g, sp, o, W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
+            sift_extrema_kernel<<<dim3(cdiv(g.ow[o] - 2 * SIFT_BORDER, 4 * 62), cdiv(g.oh[o] - 2 * SIFT_BORDER, SIFT_EX_RCH), nb), 256, 0, st>>>(
+                g, sp, o, W.gauss.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
             check_launch("sift_extrema_kernel");
         }
         // (the candidate count is on the device: the grid covers the capacity, surplus waves leave at once)
@@ -1858,7 +1869,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
         uint32_t maxc = 0;
         for (int i = 0; i < nb; ++i) maxc = std::max(maxc, std::min(hc[i], (uint32_t)sp.cand_cap));
         if (maxc > 0) {
-            sift_refine_kernel<<<dim3(cdiv((int)maxc, 4), nb), 256, 0, st>>>(g, sp, W.gauss.as<float>(), W.dog.as<float>(), W.cand.as<uint32_t>(), cand_count,
+            sift_refine_kernel<<<dim3(cdiv((int)maxc, 4), nb), 256, 0, st>>>(g, sp, W.gauss.as<float>(), W.cand.as<uint32_t>(), cand_count,
                                                                             W.raw.as<SiftRaw>(), raw_count, flags);
             check_launch("sift_refine_kernel");
         }
@@ -1967,9 +1978,15 @@ int32_t slideo_sift_layer_bgr8(slideo_matcher* m, const slideo_sift_config* cfg,
     const int64_t lsz = (int64_t)g.ow[octave] * g.oh[octave];
     *lw = g.ow[octave]; *lh = g.oh[octave];
     if (lsz > out_capacity) fail(SLIDEO_ERR_CAPACITY, "layer has %lld values", (long long)lsz);
-    const float* src = dog ? m->sift.dog.as<float>() + g.d_ofs[octave] + lsz * layer : m->sift.gauss.as<float>() + g.g_ofs[octave] + lsz * layer;
+    const float* src = m->sift.gauss.as<float>() + g.g_ofs[octave] + lsz * layer;
     HIP_CHECK(hipMemcpyAsync(out, src, (size_t)lsz * 4, hipMemcpyDeviceToHost, S.st));
+    std::vector<float> upper;
+    if (dog) {              // DoG layer L = Gaussian layer L + 1 - layer L (not stored on the device: sift.hip.h SiftDog)
+        upper.resize((size_t)lsz);
+        HIP_CHECK(hipMemcpyAsync(upper.data(), src + lsz, (size_t)lsz * 4, hipMemcpyDeviceToHost, S.st));
+    }
     HIP_CHECK(hipStreamSynchronize(S.st));
+    if (dog) for (int64_t i = 0; i < lsz; ++i) out[i] = upper[(size_t)i] - out[i];
     API_CATCH(m)
 }
 
