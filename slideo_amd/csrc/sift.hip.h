@@ -5,7 +5,7 @@
 // Every float operation below is written in the oracle's order, so the whole extractor is bit-exact against it: pyramid layers,
 // keypoints and the 128 descriptor bytes.
 //
-//   sift_base_kernel      BGR -> gray (u8, the ORB path's coefficients) -> f32, 2x bilinear upsample (firstOctave = -1)
+//   sift_base_kernel      gray (u8, the ORB path's gray_kernel) -> f32, 2x bilinear upsample (firstOctave = -1)
 //   sift_blur_kernel      GaussianBlur on f32 = sepFilter2D: row pass (taps in order) and column pass (centre, then symmetric
 //                         pairs) through LDS in ONE launch per layer, BORDER_REFLECT_101; optionally writes the DoG layer
 //                         (this layer minus its input) in the same pass — the difference pyramid costs no read of its own
@@ -62,22 +62,34 @@ __device__ __forceinline__ int sift_reflect101(int p, int n) {
     return p;
 }
 
-// One thread per SOURCE pixel (i, j): the 2 x 2 block of outputs (2i .. 2i + 1, 2j .. 2j + 1) taps the 3 x 3 gray values around it —
-// 9 gray conversions for 4 outputs instead of 16, two 8-byte stores.  The interpolation is resize(INTER_LINEAR)'s: per output
-// coordinate (i0, i1, a0, a1) from the same expression as the oracle (borders clamp to weight 1 / 0), t = g0 a0 + g1 a1 per row,
-// then t0 b0 + t1 b1: unfused multiplies and adds.   grid (ceil(w / 256), h, n)
-__global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride, int stride, int w, int h,
-                                                        GrayCoef gc, float* __restrict__ out, int64_t out_frame) {
+// The gray image first (gray_kernel, orb.hip.h: the ORB path's conversion, u8, pitch `gp`), then one thread per SOURCE pixel
+// (i, j): the 2 x 2 block of outputs (2i .. 2i + 1, 2j .. 2j + 1) taps the 3 x 3 gray values around it — three unaligned 4-byte loads
+// (reading the BGR frame directly cost 27 byte loads per thread: bound by the texture path at 30 us per 1080p frame).
+// The interpolation is resize(INTER_LINEAR)'s: per output coordinate (i0, i1, a0, a1) from the same expression as the oracle
+// (borders clamp to weight 1 / 0), t = g0 a0 + g1 a1 per row, then t0 b0 + t1 b1: unfused multiplies and adds.
+// grid (ceil(w / 256), h, n); the gray rows must be readable 2 bytes past column w - 1 (pitch >= w + 2 or a following row).
+__global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restrict__ gray, int64_t gray_frame, int gp, int w, int h,
+                                                        float* __restrict__ out, int64_t out_frame) {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= w) return;
     const int W = 2 * w;
-    const uint8_t* img = frames + (int64_t)blockIdx.z * frame_stride;
-    const int cm = max(i - 1, 0), cp = min(i + 1, w - 1), rm = max(j - 1, 0), rp = min(j + 1, h - 1);
-    auto gray = [&](int yy, int xx) -> float {
-        const uint8_t* p = img + (int64_t)yy * stride + 3 * xx;
-        return (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1u << (gc.shift - 1))) >> gc.shift);
-    };
-    const float g[3][3] = {{gray(rm, cm), gray(rm, i), gray(rm, cp)}, {gray(j, cm), gray(j, i), gray(j, cp)}, {gray(rp, cm), gray(rp, i), gray(rp, cp)}};
+    const uint8_t* img = gray + (int64_t)blockIdx.z * gray_frame;
+    const int rm = max(j - 1, 0), rp = min(j + 1, h - 1);
+    float g[3][3];
+    {
+        const int rows[3] = {rm, j, rp};
+        const int xs = max(i - 1, 0);                                       // bytes xs, xs + 1, xs + 2 = columns i - 1, i, i + 1 (i = 0: 0, 1, 2)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            uint32_t v;
+            __builtin_memcpy(&v, img + (int64_t)rows[q] * gp + xs, 4);
+            const float b0 = (float)(v & 255u), b1 = (float)((v >> 8) & 255u), b2 = (float)((v >> 16) & 255u);
+            // columns (cm, i, cp) = (max(i - 1, 0), i, min(i + 1, w - 1))
+            g[q][0] = b0;
+            g[q][1] = i >= 1 ? b1 : b0;
+            g[q][2] = i >= 1 ? (i + 1 <= w - 1 ? b2 : b1) : (w > 1 ? b1 : b0);
+        }
+    }
     // (index into the 3-neighbourhood of source coordinate q around centre `ctr`: 0, 1, 2 = ctr - 1, ctr, ctr + 1 after clamping)
     auto coef = [](int d, int n, int ctr, int& k0, int& k1, float& a0, float& a1) {
         float f = (float)(((double)d + 0.5) * 0.5 - 0.5);
@@ -91,6 +103,15 @@ __global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restric
     };
     auto pick = [](const float (&row)[3], int k) -> float { return k == 0 ? row[0] : (k == 1 ? row[1] : row[2]); };
     float res[2][2];
+    if (i >= 1 && i <= w - 2 && j >= 1 && j <= h - 2) {
+        // interior: the coefficient expression gives (i - 1, i; 0.25, 0.75) for output 2i and (i, i + 1; 0.75, 0.25) for 2i + 1 —
+        // exactly (1 - 0.75 = 0.25 and 1 - 0.25 = 0.75 in f32) — and the same in y: no selection needed
+        float ta[3], tb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { ta[q] = g[q][0] * 0.25f + g[q][1] * 0.75f; tb[q] = g[q][1] * 0.75f + g[q][2] * 0.25f; }
+        res[0][0] = ta[0] * 0.25f + ta[1] * 0.75f; res[0][1] = tb[0] * 0.25f + tb[1] * 0.75f;
+        res[1][0] = ta[1] * 0.75f + ta[2] * 0.25f; res[1][1] = tb[1] * 0.75f + tb[2] * 0.25f;
+    } else
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         int ky0, ky1; float b0, b1;
@@ -233,26 +254,35 @@ __global__ __launch_bounds__(256) void sift_blur_fast_kernel(const float* __rest
     }
 }
 
+// LDS accesses the compiler does not see.  It orders every LDS access it knows of after every LDS-DMA in flight (s_waitcnt
+// vmcnt(0): it cannot tell the buffers apart), which would serialise a prefetch with the step that issues it — the stream
+// kernel below waits for exactly the DMA it needs, by count, and touches the LDS only through these.
+typedef float sift_f4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ sift_f4 sift_lds_rd128(uint32_t a) { sift_f4 r; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF)); return r; }
+template <int OFF> __device__ __forceinline__ float sift_lds_rd32(uint32_t a) { float r; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF)); return r; }
+template <int OFF> __device__ __forceinline__ void sift_lds_wr128(uint32_t a, sift_f4 v) { asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a), "v"(v), "n"(OFF) : "memory"); }
+__device__ __forceinline__ uint32_t sift_lds_addr(const void* p) { return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p; }
+
 // The same filter as a STREAM (the default for compile-time tap counts): one wave owns a strip of 64 output columns and walks
 // down `chunk_h` rows of it, eight rows per step.  The tile kernel above pays for its two block barriers and for 58 KB of LDS
 // (two blocks per CU: the fill of one tile is exposed while the other computes) and recomputes the row pass on a (64 + 2R) / 64
 // vertical halo.  Here, per step of 8 rows:
 //   * the 8 input rows (64 + 2R columns, reflected at the image borders element by element) of the NEXT step are requested by
-//     LDS-DMA into the other half of a double buffer (12 instructions of 64 dwords, row pitch 96) — no registers, one step ahead;
+//     LDS-DMA into one of three buffers (12 instructions of 64 dwords, row pitch 96) — no registers, two steps ahead;
 //   * row pass: lane (row r of the 8, segment s of 8) reads the N + 7 floats its 8 outputs need from the buffer (ds_read_b128),
 //     8 N fused multiply-adds in tap order, and hands the 8 results to the column lanes through a 2 KB staging tile;
 //   * column pass — lane = column — keeps the last 8 (LAG + 1) row-pass values of its column in REGISTERS (a window shifted by 8
 //     per step) and produces 8 vertically adjacent outputs (centre, then the symmetric pairs outward), LAG = ceil(2R / 8) steps
 //     behind the row pass; writes the layer and, if asked, the difference to the input layer (one more coalesced read).
-// A row-pass row is computed once per chunk (+ 2R warm-up rows), LDS is 8.2 KB per wave whatever N, no block barrier exists: the
+// A row-pass row is computed once per chunk (+ 2R warm-up rows), LDS is 11.4 KB per wave whatever N, no block barrier exists: the
 // four waves of a block are independent strips.  Per output value the operation order is the tile kernel's and the generic
 // kernel's: bit-identical.   grid (ceil(strips * chunks / 4), n), block 256.
 template <int N, bool FMA>
-__global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
+__global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
                                                                float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h) {
     constexpr int R = N / 2, LAG = (2 * R + 7) / 8, WIN = 8 * (LAG + 1), IW = 64 + 2 * R, IP = 96, NV4 = (N + 7 + 3) / 4, SP = 68;
     static_assert(IW <= IP && 4 * NV4 + 56 <= IP, "input row pitch");
-    __shared__ __attribute__((aligned(16))) float s_in[4][2][8 * IP];
+    __shared__ __attribute__((aligned(16))) float s_in[4][3][8 * IP];
     __shared__ __attribute__((aligned(16))) float s_st[4][8 * SP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strips_x = (w + 63) >> 6, chunks = (h + chunk_h - 1) / chunk_h;
@@ -264,10 +294,12 @@ __global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __re
     float* D = dst + (int64_t)blockIdx.y * dst_frame;
     float* G = dog ? dog + (int64_t)blockIdx.y * dog_frame : nullptr;
     float* const IN = s_in[wave][0];
-    float* const ST = s_st[wave];
-    float k[N];
+    const uint32_t in_addr = sift_lds_addr(IN), st_addr = sift_lds_addr(s_st[wave]);
+    // (the taps are symmetric bit for bit — exp(-x^2 / 2 sigma^2) of +-x — so R + 1 registers hold them)
+    float kk[R + 1];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { k[j] = tp.k[j]; asm volatile("" : "+v"(k[j])); }
+    for (int j = 0; j <= R; ++j) { kk[j] = tp.k[j]; asm volatile("" : "+v"(kk[j])); }
+    auto K = [&](int j) -> float { return kk[j <= R ? j : N - 1 - j]; };
     auto mad = [](float a, float b, float c) -> float { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
     // DMA map: 8 rows x 96 dwords = 12 instructions of 64 dwords; instruction 3m + u fills dwords 64 (3m + u) .. + 63 = rows 2m, 2m + 1:
     //   u = 0: row 2m, columns 0..63;  u = 1: lanes 0..31 row 2m columns 64..95, lanes 32..63 row 2m + 1 columns 0..31;  u = 2: row 2m + 1, columns 32..95
@@ -278,10 +310,12 @@ __global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __re
         second[u] = d >= IP;
         colofs[u] = sift_reflect101(x0 - R + min(col, IW - 1), w);
     }
+    // rows -R .. h + 8 LAG + 6: one reflection is enough for h >= 48 (a while loop per row otherwise: branches in every step)
+    auto refl1 = [&](int p) -> int { return h >= 48 ? (p < 0 ? -p : (p >= h ? 2 * (h - 1) - p : p)) : sift_reflect101(p, h); };
     auto dma_rows = [&](int tb, int buf) {                                   // input rows tb .. tb + 7 -> IN[buf]
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int ra = sift_reflect101(tb + 2 * m, h), rb = sift_reflect101(tb + 2 * m + 1, h);       // (scalar)
+            const int ra = refl1(tb + 2 * m), rb = refl1(tb + 2 * m + 1);          // (scalar)
             const float* pa = S + (int64_t)ra * w;
             const float* pb = S + (int64_t)rb * w;
 #pragma unroll
@@ -298,39 +332,93 @@ __global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __re
     float c[WIN];
 #pragma unroll
     for (int t = 0; t < WIN; ++t) c[t] = 0.f;
+    // Vector-memory operations of a wave complete in order, so "at most 8 outstanding" right after [12 DMA loads][8 stores] means the
+    // loads are in: a step's input wait then does not sit through the write acknowledgements of the previous step's outputs
+    // (waiting for everything, the waves spent half their time there).  `stores8`: the previous step issued exactly that sequence.
+    // The input rows are requested TWO steps ahead (three buffers): at the top of step m the operations issued after DMA(m) are, in
+    // order, [stores of step m - 2][DMA(m + 1)][stores of step m - 1], so "at most s2 + 12 + s1 outstanding" means DMA(m) is in
+    // (s = 8 for a step that issued exactly its 8 stores, else 0: a lower bound is always safe).
+    int s1 = 0, s2 = 0, buf = 0;
     dma_rows(y0 - R, 0);
+    if (M > 1) dma_rows(y0 - R + 8, 1);
     for (int m = 0; m < M; ++m) {
-        const int buf = m & 1;
-        if (m + 1 < M) { dma_rows(y0 - R + 8 * (m + 1), buf ^ 1); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int allow = s2 + s1 + (m + 1 < M ? 12 : 0);
+            if (allow >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (allow >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s2 = s1; s1 = 0;
         __builtin_amdgcn_wave_barrier();
         {   // row pass
             float v[4 * NV4];
-            const float4* p = reinterpret_cast<const float4*>(IN + buf * (8 * IP) + rr * IP + 8 * sg);
+            {
+                const uint32_t a = in_addr + (uint32_t)(buf * (8 * IP) + rr * IP + 8 * sg) * 4u;
+                sift_f4 t4[NV4];
+                static_assert(NV4 <= 9, "row-pass reads");
+                t4[0] = sift_lds_rd128<0>(a);
+                if constexpr (NV4 > 1) t4[1] = sift_lds_rd128<16>(a);
+                if constexpr (NV4 > 2) t4[2] = sift_lds_rd128<32>(a);
+                if constexpr (NV4 > 3) t4[3] = sift_lds_rd128<48>(a);
+                if constexpr (NV4 > 4) t4[4] = sift_lds_rd128<64>(a);
+                if constexpr (NV4 > 5) t4[5] = sift_lds_rd128<80>(a);
+                if constexpr (NV4 > 6) t4[6] = sift_lds_rd128<96>(a);
+                if constexpr (NV4 > 7) t4[7] = sift_lds_rd128<112>(a);
+                if constexpr (NV4 > 8) t4[8] = sift_lds_rd128<128>(a);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < NV4; ++q) { const float4 t4 = p[q]; v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+                for (int q = 0; q < NV4; ++q) { asm volatile("" : "+v"(t4[q])); v[4 * q] = t4[q].x; v[4 * q + 1] = t4[q].y; v[4 * q + 2] = t4[q].z; v[4 * q + 3] = t4[q].w; }
+            }
             float acc[8];
 #pragma unroll
             for (int t = 0; t < N + 7; ++t) {
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
                     const int j = t - o;
-                    if (j == 0) acc[o] = k[0] * v[t];
-                    else if (j > 0 && j < N) acc[o] = mad(k[j], v[t], acc[o]);
+                    if (j == 0) acc[o] = K(0) * v[t];
+                    else if (j > 0 && j < N) acc[o] = mad(K(j), v[t], acc[o]);
                 }
             }
-            float4* q = reinterpret_cast<float4*>(ST + rr * SP + 8 * sg);
-            q[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            q[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            const uint32_t a = st_addr + (uint32_t)(rr * SP + 8 * sg) * 4u;
+            sift_lds_wr128<0>(a, sift_f4{acc[0], acc[1], acc[2], acc[3]});
+            sift_lds_wr128<16>(a, sift_f4{acc[4], acc[5], acc[6], acc[7]});
         }
         __builtin_amdgcn_wave_barrier();
-        // window: c[u] = row-pass value of row y0 - R + 8 (m - LAG) + u
+        // window: c[u] = row-pass value of row y0 - R + 8 (m - LAG) + u   (a wave's LDS operations execute in order: the reads
+        // below see the writes above)
 #pragma unroll
         for (int t = 0; t < WIN - 8; ++t) c[t] = c[t + 8];
+        {
+            const uint32_t a = st_addr + (uint32_t)lane * 4u;
+            float nv[8];
+            nv[0] = sift_lds_rd32<0>(a); nv[1] = sift_lds_rd32<SP * 4>(a); nv[2] = sift_lds_rd32<2 * SP * 4>(a); nv[3] = sift_lds_rd32<3 * SP * 4>(a);
+            nv[4] = sift_lds_rd32<4 * SP * 4>(a); nv[5] = sift_lds_rd32<5 * SP * 4>(a); nv[6] = sift_lds_rd32<6 * SP * 4>(a); nv[7] = sift_lds_rd32<7 * SP * 4>(a);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 8; ++t) c[WIN - 8 + t] = ST[t * SP + lane];
+            for (int t = 0; t < 8; ++t) { asm volatile("" : "+v"(nv[t])); c[WIN - 8 + t] = nv[t]; }
+        }
         __builtin_amdgcn_wave_barrier();
-        if (m >= LAG) {
+        if (m + 2 < M) dma_rows(y0 - R + 8 * (m + 2), buf == 0 ? 2 : buf - 1);   // (buffer (m + 2) % 3 = (m - 1) % 3: last read by the previous step's row pass)
+        if (m >= LAG && !G && y0 + 8 * (m - LAG) + 8 <= y1) {
+            // a full block of 8 output rows, layer only: exactly 8 store instructions after the 12 DMA loads
+            const int Y = y0 + 8 * (m - LAG);
+            float res[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float sacc = K(R) * c[o + R];
+#pragma unroll
+                for (int j = 1; j <= R; ++j) sacc = mad(K(R + j), c[o + R + j] + c[o + R - j], sacc);
+                res[o] = sacc;
+            }
+            if (gx < w) {
+                float* o0 = D + (int64_t)Y * w + gx;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) __builtin_nontemporal_store(res[o], o0 + (int64_t)o * w);
+            }
+            s1 = 8;
+        } else if (m >= LAG) {
             const int Y = y0 + 8 * (m - LAG);
             float sv[8];
             if (G) {
@@ -339,9 +427,9 @@ __global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __re
             }
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
-                float sacc = k[R] * c[o + R];
+                float sacc = K(R) * c[o + R];
 #pragma unroll
-                for (int j = 1; j <= R; ++j) sacc = mad(k[R + j], c[o + R + j] + c[o + R - j], sacc);
+                for (int j = 1; j <= R; ++j) sacc = mad(K(R + j), c[o + R + j] + c[o + R - j], sacc);
                 const int gy = Y + o;
                 if (gx < w && gy < y1) {
                     D[(int64_t)gy * w + gx] = sacc;
@@ -349,6 +437,7 @@ __global__ __launch_bounds__(256) void sift_blur_stream_kernel(const float* __re
                 }
             }
         }
+        buf = buf == 2 ? 0 : buf + 1;
     }
 }
 
@@ -378,9 +467,10 @@ struct SiftDog {
 // neighbours' registers (DPP wave shifts), the vertical one over a 3-row register ring, the layer one across the rings — every
 // pyramid value is read from memory exactly once (the one-thread-per-point form re-read 27 values wherever a wave held a point above
 // the threshold, i.e. almost everywhere on a text frame, and was bound by the texture path: 30 ms per 256 frames).
-// A wave covers 64 columns and emits for its lanes 1 .. 62; block = 4 waves = 4 column groups; grid (ceil(cols / 248),
-// ceil(rows / SIFT_EX_RCH), n), cols / rows = the octave's sides minus the 5-px borders.
+// A wave covers 128 columns (two per lane) and emits for all but its first and last; block = 4 waves = 4 column groups; grid
+// (ceil(cols / (4 SIFT_EX_COLS)), ceil(rows / SIFT_EX_RCH), n), cols / rows = the octave's sides minus the 5-px borders.
 constexpr int SIFT_EX_RCH = 34;                 // output rows per block (+ 2 halo rows = 36 row steps, a multiple of the 3-slot ring)
+constexpr int SIFT_EX_COLS = 126;               // output columns per wave
 
 __device__ __forceinline__ float sift_wave_shr1(float v) {      // lane i <- lane i - 1 (lane 0 keeps its own)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
@@ -394,58 +484,64 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParam
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = g.ow[o], h = g.oh[o];
-    const int c = SIFT_BORDER - 1 + (blockIdx.x * 4 + wave) * 62 + lane;          // this lane's column (lanes 0 / 63: halo only)
-    if (c - lane + 1 >= w - SIFT_BORDER) return;                                   // (wave-uniform: no output column in this group)
+    // a lane owns TWO adjacent columns (8-byte loads: 512 B per wave and row); the wave's first and last column are halo
+    const int cw0 = SIFT_BORDER - 1 + (blockIdx.x * 4 + wave) * SIFT_EX_COLS;
+    if (cw0 + 1 >= w - SIFT_BORDER) return;                                        // (wave-uniform: no output column in this group)
+    const int c = cw0 + 2 * lane;
     const int ry0 = SIFT_BORDER + blockIdx.y * SIFT_EX_RCH;
     const int64_t lsz = (int64_t)w * h;
-    const float* base = gauss + (int64_t)f * g.g_frame + g.g_ofs[o] + min(c, w - 1);
-    const bool col_ok = lane >= 1 && lane <= 62 && c < w - SIFT_BORDER;
+    const float* base = gauss + (int64_t)f * g.g_frame + g.g_ofs[o] + min(c, w - 2);
+    const bool ok0 = lane >= 1 && c < w - SIFT_BORDER, ok1 = lane <= 62 && c + 1 < w - SIFT_BORDER;
     const float thr = (float)sp.threshold;
-    float val[5][3], hx[5][3], hn[5][3];
-    auto load_row = [&](int i, float (&v)[5]) {
+    float2 val[5][3], hx[5][3], hn[5][3];
+    auto load_row = [&](int i, float2 (&v)[5]) {
         const int r = min(ry0 - 1 + i, h - 1);
-        float gl[6];
+        float2 gl[6];
 #pragma unroll
-        for (int L = 0; L < 6; ++L) gl[L] = base[lsz * L + (int64_t)r * w];
+        for (int L = 0; L < 6; ++L) __builtin_memcpy(&gl[L], base + lsz * L + (int64_t)r * w, 8);
 #pragma unroll
-        for (int L = 0; L < 5; ++L) v[L] = gl[L + 1] - gl[L];
+        for (int L = 0; L < 5; ++L) v[L] = make_float2(gl[L + 1].x - gl[L].x, gl[L + 1].y - gl[L].y);
     };
-    auto step = [&](auto slot_tag, int i, const float (&v)[5]) {
+    auto emit = [&](bool ext, int L, int rc, int cc) {
+        if (ext) {
+            const uint32_t slot = atomicAdd(&cand_count[f], 1u);
+            if (slot >= (uint32_t)sp.cand_cap) atomicOr(flags, 16u);
+            else cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)L << 26) | ((uint32_t)rc << 13) | (uint32_t)cc;
+        }
+    };
+    auto step = [&](auto slot_tag, int i, const float2 (&v)[5]) {
         constexpr int S = decltype(slot_tag)::value, S1 = (S + 2) % 3;           // S1 = the slot of the previous row (the centre row)
 #pragma unroll
         for (int L = 0; L < 5; ++L) {
-            const float a = sift_wave_shr1(v[L]), b = sift_wave_shl1(v[L]);
+            const float ly = sift_wave_shr1(v[L].y), rx = sift_wave_shl1(v[L].x);  // left neighbour's right column, right neighbour's left column
             val[L][S] = v[L];
-            hx[L][S] = fmaxf(fmaxf(a, v[L]), b);
-            hn[L][S] = fminf(fminf(a, v[L]), b);
+            hx[L][S] = make_float2(fmaxf(fmaxf(ly, v[L].x), v[L].y), fmaxf(fmaxf(v[L].x, v[L].y), rx));
+            hn[L][S] = make_float2(fminf(fminf(ly, v[L].x), v[L].y), fminf(fminf(v[L].x, v[L].y), rx));
         }
         if (i < 2) return;
         const int rc = ry0 + i - 2;                                               // centre row of this step
         if (rc >= h - SIFT_BORDER) return;                                        // (uniform)
-        float vx[5], vn[5];
+        float2 vx[5], vn[5];
 #pragma unroll
         for (int L = 0; L < 5; ++L) {
-            vx[L] = fmaxf(fmaxf(hx[L][0], hx[L][1]), hx[L][2]);
-            vn[L] = fminf(fminf(hn[L][0], hn[L][1]), hn[L][2]);
+            vx[L] = make_float2(fmaxf(fmaxf(hx[L][0].x, hx[L][1].x), hx[L][2].x), fmaxf(fmaxf(hx[L][0].y, hx[L][1].y), hx[L][2].y));
+            vn[L] = make_float2(fminf(fminf(hn[L][0].x, hn[L][1].x), hn[L][2].x), fminf(fminf(hn[L][0].y, hn[L][1].y), hn[L][2].y));
         }
 #pragma unroll
         for (int L = 1; L <= 3; ++L) {
-            const float x = val[L][S1];
-            const float mx = fmaxf(fmaxf(vx[L - 1], vx[L]), vx[L + 1]), mn = fminf(fminf(vn[L - 1], vn[L]), vn[L + 1]);
-            const bool ext = col_ok && fabsf(x) > thr && (x > 0 ? x >= mx : x <= mn);
-            if (ext) {
-                const uint32_t slot = atomicAdd(&cand_count[f], 1u);
-                if (slot >= (uint32_t)sp.cand_cap) atomicOr(flags, 16u);
-                else cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)L << 26) | ((uint32_t)rc << 13) | (uint32_t)c;
-            }
+            const float2 x = val[L][S1];
+            const float mx0 = fmaxf(fmaxf(vx[L - 1].x, vx[L].x), vx[L + 1].x), mn0 = fminf(fminf(vn[L - 1].x, vn[L].x), vn[L + 1].x);
+            const float mx1 = fmaxf(fmaxf(vx[L - 1].y, vx[L].y), vx[L + 1].y), mn1 = fminf(fminf(vn[L - 1].y, vn[L].y), vn[L + 1].y);
+            emit(ok0 && fabsf(x.x) > thr && (x.x > 0 ? x.x >= mx0 : x.x <= mn0), L, rc, c);
+            emit(ok1 && fabsf(x.y) > thr && (x.y > 0 ? x.y >= mx1 : x.y <= mn1), L, rc, c + 1);
         }
     };
     using S0 = std::integral_constant<int, 0>; using S1t = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
-    float va[5], vb[5], vc[5];
+    float2 va[5], vb[5], vc[5];
     load_row(0, va); load_row(1, vb); load_row(2, vc);
     for (int i = 0; i < SIFT_EX_RCH + 2; i += 3) {
         if (ry0 + i - 2 >= h - SIFT_BORDER) break;                                // (uniform: nothing left to emit)
-        float na[5], nb[5], nc[5];                                                // the next three rows, requested before this trio is used
+        float2 na[5], nb[5], nc[5];                                               // the next three rows, requested before this trio is used
         load_row(i + 3, na); load_row(i + 4, nb); load_row(i + 5, nc);
         step(S0{}, i, va); step(S1t{}, i + 1, vb); step(S2{}, i + 2, vc);
 #pragma unroll
@@ -467,21 +563,25 @@ __device__ __forceinline__ void sift_solve3(const float (&a)[3][3], const float 
 
 __device__ __forceinline__ float sift_expf(float x) { return (float)exp((double)x); }
 
-// grid (cand_cap / 4, n), block 256 = 4 waves, one candidate per wave
+// grid (ceil(candidates / 256), n), block 256 = 4 waves, 64 candidates per wave
 __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams sp, const float* __restrict__ gauss,
                                                           const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_count,
                                                           SiftRaw* __restrict__ raw, uint32_t* __restrict__ raw_count, uint32_t* __restrict__ flags) {
     __shared__ unsigned long long s_hist[4][SIFT_BINS];
     __shared__ float s_sm[4][SIFT_BINS];
     const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t ci = blockIdx.x * 4 + wave;
     const uint32_t ncand = min(cand_count[f], (uint32_t)sp.cand_cap);
-    if (ci >= ncand) return;                                            // (wave-uniform; no block barrier below)
-    const uint32_t cw = cand[(size_t)f * sp.cand_cap + ci];
-    const int octv = (int)(cw >> 28);
+    if ((blockIdx.x * 4 + wave) * 64u >= ncand) return;                 // (wave-uniform; no block barrier below)
+    // Phase 1 — adjustLocalExtrema, ONE CANDIDATE PER LANE (a wave per candidate spent its time in the latency of 40 dependent
+    // loads per Newton step on behalf of one lane; most candidates are rejected here).  Phase 2 — the wave walks over its
+    // surviving lanes and builds each one's orientation histogram with all 64 lanes.
+    const uint32_t ci = (blockIdx.x * 4 + wave) * 64u + lane;
+    const bool have = ci < ncand;
+    const uint32_t cw = cand[(size_t)f * sp.cand_cap + min(ci, ncand - 1)];
+    int octv = (int)(cw >> 28);
     int layer = (int)((cw >> 26) & 3), r = (int)((cw >> 13) & 8191), c = (int)(cw & 8191);
-    const int w = g.ow[octv], h = g.oh[octv];
-    const int64_t lsz = (int64_t)w * h;
+    int w = g.ow[octv], h = g.oh[octv];
+    int64_t lsz = (int64_t)w * h;
     const SiftDog dbase{gauss + (int64_t)f * g.g_frame + g.g_ofs[octv], lsz};
     const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
     float xi = 0, xr = 0, xc = 0;
@@ -510,9 +610,11 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams
         c += (int)rintf(xc); r += (int)rintf(xr); layer += (int)rintf(xi);
         if (layer < 1 || layer > SIFT_NL || c < SIFT_BORDER || c >= w - SIFT_BORDER || r < SIFT_BORDER || r >= h - SIFT_BORDER) { ok = false; break; }
     }
-    if (!ok || it >= SIFT_STEPS) return;
-    slideo_keypoint kpt;
-    {
+    bool alive = have && ok && it < SIFT_STEPS;
+    slideo_keypoint kpt{};
+    if (alive) {
+        alive = false;
+        do {
         const SiftDog img = dbase + lsz * layer;
         const SiftDog prev = img - lsz;
         const SiftDog next = img + lsz;
@@ -520,21 +622,35 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams
         const float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + w] - img[p - w]) * deriv_scale, (next[p] - prev[p]) * deriv_scale};
         const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
         const float contr = img[p] * img_scale + t * 0.5f;
-        if (fabsf(contr) * SIFT_NL < sp.contrast_threshold) return;
+        if (fabsf(contr) * SIFT_NL < sp.contrast_threshold) break;
         const float v2 = img[p] * 2.f;
         const float dxx = (img[p + 1] + img[p - 1] - v2) * second_deriv_scale;
         const float dyy = (img[p + w] + img[p - w] - v2) * second_deriv_scale;
         const float dxy = (img[p + w + 1] - img[p + w - 1] - img[p - w + 1] + img[p - w - 1]) * cross_deriv_scale;
         const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
         const float et = sp.edge_threshold;
-        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) return;
+        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) break;
         kpt.x = ((float)c + xc) * (float)(1 << octv);
         kpt.y = ((float)r + xr) * (float)(1 << octv);
         kpt.octave = octv + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
         kpt.size = sp.sigma * (float)pow(2.0, (double)(((float)layer + xi) / SIFT_NL)) * (float)(1 << octv) * 2;      // (f64 pow rounded to f32, as the oracle)
         kpt.response = fabsf(contr);
         kpt.angle = 0;
+        alive = true;
+        } while (false);
     }
+    // Phase 2: the survivors of this wave, one after the other (their state broadcast from the owning lane)
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(alive);
+    const slideo_keypoint kpt_mine = kpt;
+    const int r_mine = r, c_mine = c, layer_mine = layer, octv_mine = octv;
+    while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    auto bi = [&](int v) -> int { return __builtin_amdgcn_readlane(v, src); };
+    auto bf = [&](float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+    r = bi(r_mine); c = bi(c_mine); layer = bi(layer_mine); octv = bi(octv_mine);
+    kpt.x = bf(kpt_mine.x); kpt.y = bf(kpt_mine.y); kpt.size = bf(kpt_mine.size); kpt.angle = 0; kpt.response = bf(kpt_mine.response); kpt.octave = bi(kpt_mine.octave);
+    w = g.ow[octv]; h = g.oh[octv]; lsz = (int64_t)w * h;
     // orientation histogram on the Gaussian layer the extremum ended in
     const float scl_octv = kpt.size * 0.5f / (float)(1 << octv);
     const int radius = (int)rintf(4.5f * scl_octv);
@@ -590,6 +706,8 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(SiftGeom g, SiftParams
             } else atomicOr(flags, 32u);
         }
     }
+    __builtin_amdgcn_wave_barrier();                                    // (s_hist / s_sm are reused by the next survivor)
+    }   // survivors
 }
 
 // One block of 1024 per frame.  items: [n][raw_cap] u64 workspace; kept: [n][raw_cap] u32 (slots of the kept keypoints in

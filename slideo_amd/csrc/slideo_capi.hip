@@ -1802,8 +1802,18 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
     W.base.reserve((size_t)base_frame * nb * 4);
     W.gauss.reserve((size_t)g.g_frame * nb * 4 + 64);
     const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
-    sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, w, h, gc, W.base.as<float>(), base_frame);
-    check_launch("sift_base_kernel");
+    {
+        // gray u8 first (the ORB path's kernel), then the doubled f32 base image from it; W.dog holds the gray frames (the DoG
+        // pyramid itself is not stored: sift.hip.h SiftDog)
+        const int gp = ((w + 15) & ~15) + 16;
+        const int64_t gframe = (int64_t)gp * h;
+        W.dog.reserve((size_t)gframe * nb + 64);
+        const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (fs % 4 == 0);
+        gray_kernel<<<dim3(cdiv(cdiv(w, 4), 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, W.dog.as<uint8_t>(), gframe, w, h, gp, aligned4, gc);
+        check_launch("gray_kernel");
+        sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(W.dog.as<uint8_t>(), gframe, gp, w, h, W.base.as<float>(), base_frame);
+        check_launch("sift_base_kernel");
+    }
     const float sigma = (float)sc.sigma;
     const float sig_diff = std::sqrt(std::max(sigma * sigma - 0.5f * 0.5f * 4, 0.01f));
     float* G = W.gauss.as<float>();
@@ -1858,7 +1868,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
         HIP_CHECK(hipMemsetAsync(W.info.p, 0, 32, st));
         for (int o = 0; o < g.n_oct; ++o) {
             if (g.ow[o] <= 2 * SIFT_BORDER || g.oh[o] <= 2 * SIFT_BORDER) continue;
-            sift_extrema_kernel<<<dim3(cdiv(g.ow[o] - 2 * SIFT_BORDER, 4 * 62), cdiv(g.oh[o] - 2 * SIFT_BORDER, SIFT_EX_RCH), nb), 256, 0, st>>>(
+            sift_extrema_kernel<<<dim3(cdiv(g.ow[o] - 2 * SIFT_BORDER, 4 * SIFT_EX_COLS), cdiv(g.oh[o] - 2 * SIFT_BORDER, SIFT_EX_RCH), nb), 256, 0, st>>>(
                 g, sp, o, W.gauss.as<float>(), W.cand.as<uint32_t>(), cand_count, flags);
             check_launch("sift_extrema_kernel");
         }
@@ -1869,7 +1879,7 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
         uint32_t maxc = 0;
         for (int i = 0; i < nb; ++i) maxc = std::max(maxc, std::min(hc[i], (uint32_t)sp.cand_cap));
         if (maxc > 0) {
-            sift_refine_kernel<<<dim3(cdiv((int)maxc, 4), nb), 256, 0, st>>>(g, sp, W.gauss.as<float>(), W.cand.as<uint32_t>(), cand_count,
+            sift_refine_kernel<<<dim3(cdiv((int)maxc, 256), nb), 256, 0, st>>>(g, sp, W.gauss.as<float>(), W.cand.as<uint32_t>(), cand_count,
                                                                             W.raw.as<SiftRaw>(), raw_count, flags);
             check_launch("sift_refine_kernel");
         }
