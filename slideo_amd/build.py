@@ -46,6 +46,7 @@ def build_hip(force=False, verbose=False):
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-fgpu-rdc" if False else "-fno-gpu-rdc",
            "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC, "-o", HIP_LIB]
+    cmd += os.environ.get("SLIDEO_HIP_EXTRA_FLAGS", "").split()           # (experiments: -D switches of the kernels)
     cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if verbose:
         print(" ".join(cmd))

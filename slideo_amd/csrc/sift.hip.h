@@ -471,13 +471,19 @@ struct SiftDog {
 // (ceil(cols / (4 SIFT_EX_COLS)), ceil(rows / SIFT_EX_RCH), n), cols / rows = the octave's sides minus the 5-px borders.
 constexpr int SIFT_EX_RCH = 34;                 // output rows per block (+ 2 halo rows = 36 row steps, a multiple of the 3-slot ring)
 constexpr int SIFT_EX_COLS = 126;               // output columns per wave
+constexpr int SIFT_EX_STAGE = 512;              // candidates a wave stages in LDS before its one list append
 
+#ifdef SIFT_EX_BPERMUTE
+__device__ __forceinline__ float sift_wave_shr1(float v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ float sift_wave_shl1(float v) { return __shfl_down(v, 1); }
+#else
 __device__ __forceinline__ float sift_wave_shr1(float v) {      // lane i <- lane i - 1 (lane 0 keeps its own)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float sift_wave_shl1(float v) {      // lane i <- lane i + 1 (lane 63 keeps its own)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
+#endif
 
 __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParams sp, int o, const float* __restrict__ gauss,
                                                            uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t* __restrict__ flags) {
@@ -502,12 +508,25 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParam
 #pragma unroll
         for (int L = 0; L < 5; ++L) v[L] = make_float2(gl[L + 1].x - gl[L].x, gl[L + 1].y - gl[L].y);
     };
+    // candidates are staged per wave in LDS and appended to the frame's list with ONE returning global atomic when the wave is done:
+    // a returning atomic inside the loop is followed by s_waitcnt vmcnt(0), i.e. by the whole latency of the 18 row loads requested
+    // ahead — in the third of all row steps that hold a candidate
+    __shared__ uint32_t s_stage[4][SIFT_EX_STAGE];
+    uint32_t nst = 0;                                                              // (wave-uniform)
     auto emit = [&](bool ext, int L, int rc, int cc) {
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(ext);
+        if (mk == 0ull) return;
+        const uint32_t code = ((uint32_t)o << 28) | ((uint32_t)L << 26) | ((uint32_t)rc << 13) | (uint32_t)cc;
+        const uint32_t pos = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         if (ext) {
-            const uint32_t slot = atomicAdd(&cand_count[f], 1u);
-            if (slot >= (uint32_t)sp.cand_cap) atomicOr(flags, 16u);
-            else cand[(size_t)f * sp.cand_cap + slot] = ((uint32_t)o << 28) | ((uint32_t)L << 26) | ((uint32_t)rc << 13) | (uint32_t)cc;
+            if (pos < (uint32_t)SIFT_EX_STAGE) s_stage[wave][pos] = code;
+            else {                                                                 // staging full (a chunk of noise): straight to the list
+                const uint32_t slot = atomicAdd(&cand_count[f], 1u);
+                if (slot >= (uint32_t)sp.cand_cap) atomicOr(flags, 16u);
+                else cand[(size_t)f * sp.cand_cap + slot] = code;
+            }
         }
+        nst += (uint32_t)__builtin_popcountll(mk);
     };
     auto step = [&](auto slot_tag, int i, const float2 (&v)[5]) {
         constexpr int S = decltype(slot_tag)::value, S1 = (S + 2) % 3;           // S1 = the slot of the previous row (the centre row)
@@ -527,14 +546,23 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParam
             vx[L] = make_float2(fmaxf(fmaxf(hx[L][0].x, hx[L][1].x), hx[L][2].x), fmaxf(fmaxf(hx[L][0].y, hx[L][1].y), hx[L][2].y));
             vn[L] = make_float2(fminf(fminf(hn[L][0].x, hn[L][1].x), hn[L][2].x), fminf(fminf(hn[L][0].y, hn[L][1].y), hn[L][2].y));
         }
+        // the six tests of this row (3 layers x 2 columns) branch-free — |x| > thr and (x > 0 ? x >= max27 : x <= min27) is
+        // (x > thr and x >= max27) or (x < -thr and x <= min27) for thr >= 0 — and ONE branch for the rare row that holds an
+        // extremum (a branch per test ran its body for almost every wave: some lane is above the threshold wherever there is an edge)
+        bool e0[4], e1[4];
+        bool any = false;
 #pragma unroll
         for (int L = 1; L <= 3; ++L) {
             const float2 x = val[L][S1];
             const float mx0 = fmaxf(fmaxf(vx[L - 1].x, vx[L].x), vx[L + 1].x), mn0 = fminf(fminf(vn[L - 1].x, vn[L].x), vn[L + 1].x);
             const float mx1 = fmaxf(fmaxf(vx[L - 1].y, vx[L].y), vx[L + 1].y), mn1 = fminf(fminf(vn[L - 1].y, vn[L].y), vn[L + 1].y);
-            emit(ok0 && fabsf(x.x) > thr && (x.x > 0 ? x.x >= mx0 : x.x <= mn0), L, rc, c);
-            emit(ok1 && fabsf(x.y) > thr && (x.y > 0 ? x.y >= mx1 : x.y <= mn1), L, rc, c + 1);
+            e0[L] = ok0 & (((x.x > thr) & (x.x >= mx0)) | ((x.x < -thr) & (x.x <= mn0)));
+            e1[L] = ok1 & (((x.y > thr) & (x.y >= mx1)) | ((x.y < -thr) & (x.y <= mn1)));
+            any |= e0[L] | e1[L];
         }
+        if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+#pragma unroll
+        for (int L = 1; L <= 3; ++L) { emit(e0[L], L, rc, c); emit(e1[L], L, rc, c + 1); }
     };
     using S0 = std::integral_constant<int, 0>; using S1t = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
     float2 va[5], vb[5], vc[5];
@@ -546,6 +574,17 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(SiftGeom g, SiftParam
         step(S0{}, i, va); step(S1t{}, i + 1, vb); step(S2{}, i + 2, vc);
 #pragma unroll
         for (int L = 0; L < 5; ++L) { va[L] = na[L]; vb[L] = nb[L]; vc[L] = nc[L]; }
+    }
+    const uint32_t ns = min(nst, (uint32_t)SIFT_EX_STAGE);
+    if (ns) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&cand_count[f], ns);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < ns; i += 64) {
+            if (base + i >= (uint32_t)sp.cand_cap) { atomicOr(flags, 16u); break; }
+            cand[(size_t)f * sp.cand_cap + base + i] = s_stage[wave][i];
+        }
     }
 }
 
