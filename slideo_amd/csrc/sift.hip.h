@@ -281,8 +281,11 @@ template <int N, bool FMA>
 __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
                                                                float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h) {
     constexpr int R = N / 2, LAG = (2 * R + 7) / 8, WIN = 8 * (LAG + 1), IW = 64 + 2 * R, IP = 96, NV4 = (N + 7 + 3) / 4, SP = 68;
+    // input buffers: three (rows requested two steps ahead) for the wide kernels, which are bound by their arithmetic and by
+    // registers (3 waves per SIMD); two for the narrow ones — 33 instead of 45 KB of LDS per block: 4 instead of 3 waves per SIMD
+    constexpr int NB = N >= 21 ? 3 : 2;
     static_assert(IW <= IP && 4 * NV4 + 56 <= IP, "input row pitch");
-    __shared__ __attribute__((aligned(16))) float s_in[4][3][8 * IP];
+    __shared__ __attribute__((aligned(16))) float s_in[4][NB][8 * IP];
     __shared__ __attribute__((aligned(16))) float s_st[4][8 * SP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strips_x = (w + 63) >> 6, chunks = (h + chunk_h - 1) / chunk_h;
@@ -340,10 +343,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
     // (s = 8 for a step that issued exactly its 8 stores, else 0: a lower bound is always safe).
     int s1 = 0, s2 = 0, buf = 0;
     dma_rows(y0 - R, 0);
-    if (M > 1) dma_rows(y0 - R + 8, 1);
+    if (NB == 3 && M > 1) dma_rows(y0 - R + 8, 1);
     for (int m = 0; m < M; ++m) {
         {
-            const int allow = s2 + s1 + (m + 1 < M ? 12 : 0);
+            // (two buffers: DMA(m + 1) is issued in step m, so only the stores of step m - 1 follow DMA(m))
+            const int allow = NB == 3 ? s2 + s1 + (m + 1 < M ? 12 : 0) : s1;
             if (allow >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
             else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -400,7 +404,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
             for (int t = 0; t < 8; ++t) { asm volatile("" : "+v"(nv[t])); c[WIN - 8 + t] = nv[t]; }
         }
         __builtin_amdgcn_wave_barrier();
-        if (m + 2 < M) dma_rows(y0 - R + 8 * (m + 2), buf == 0 ? 2 : buf - 1);   // (buffer (m + 2) % 3 = (m - 1) % 3: last read by the previous step's row pass)
+        // (the buffer requested into was last read by the previous step's row pass — three buffers — or by this step's — two)
+        if (m + NB - 1 < M) dma_rows(y0 - R + 8 * (m + NB - 1), NB == 3 ? (buf == 0 ? 2 : buf - 1) : buf ^ 1);
         if (m >= LAG && !G && y0 + 8 * (m - LAG) + 8 <= y1) {
             // a full block of 8 output rows, layer only: exactly 8 store instructions after the 12 DMA loads
             const int Y = y0 + 8 * (m - LAG);
@@ -437,7 +442,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
                 }
             }
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NB - 1 ? 0 : buf + 1;
     }
 }
 
