@@ -160,7 +160,7 @@ struct slideo_matcher {
     int next_slot = 0;
     int64_t next_ticket = 1;
     DevBuf d_small, d_ssd, d_prev_small, d_tapq, d_tapt, d_tapidx, d_tapdist;
-    struct SiftWs { DevBuf base, gauss, dog, cand, counts, raw, items, kept, qofs, info, kp, desc; } sift;     // csrc/sift.hip.h
+    struct SiftWs { DevBuf base, gauss, gray, cand, counts, raw, items, kept, qofs, info, kp, desc; } sift;     // csrc/sift.hip.h
 
     // stage profiling (HIP events on the launch streams)
     bool profiling = false;
@@ -1803,15 +1803,15 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
     W.gauss.reserve((size_t)g.g_frame * nb * 4 + 64);
     const GrayCoef gc = m->cfg.ocv.gray == 1 ? GrayCoef{1868u, 9617u, 4899u, 14u} : GrayCoef{3735u, 19235u, 9798u, 15u};
     {
-        // gray u8 first (the ORB path's kernel), then the doubled f32 base image from it; W.dog holds the gray frames (the DoG
+        // gray u8 first (the ORB path's kernel), then the doubled f32 base image from it (the DoG
         // pyramid itself is not stored: sift.hip.h SiftDog)
         const int gp = ((w + 15) & ~15) + 16;
         const int64_t gframe = (int64_t)gp * h;
-        W.dog.reserve((size_t)gframe * nb + 64);
+        W.gray.reserve((size_t)gframe * nb + 64);
         const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (fs % 4 == 0);
-        gray_kernel<<<dim3(cdiv(cdiv(w, 4), 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, W.dog.as<uint8_t>(), gframe, w, h, gp, aligned4, gc);
+        gray_kernel<<<dim3(cdiv(cdiv(w, 4), 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, W.gray.as<uint8_t>(), gframe, w, h, gp, aligned4, gc);
         check_launch("gray_kernel");
-        sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(W.dog.as<uint8_t>(), gframe, gp, w, h, W.base.as<float>(), base_frame);
+        sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(W.gray.as<uint8_t>(), gframe, gp, w, h, W.base.as<float>(), base_frame);
         check_launch("sift_base_kernel");
     }
     const float sigma = (float)sc.sigma;
@@ -1847,9 +1847,11 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
     sp.contrast_threshold = (float)sc.contrast_threshold; sp.edge_threshold = (float)sc.edge_threshold; sp.sigma = (float)sc.sigma;
     sp.threshold = (int)std::floor(0.5 * sc.contrast_threshold / SIFT_NL * 255);
     sp.atan_fma = m->cfg.ocv.atan; sp.blur_fma = m->cfg.ocv.blur != 1;
-    // frames per pass under a 24 GB budget for the pyramids (486 MB per 1080p frame)
+    // frames per pass under a 24 GB budget for the pyramids (265 MB + 33 MB per 1080p frame; SLIDEO_SIFT_WS_MB: tests)
     const size_t per = ((size_t)g.g_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
-    const int nb_max = (int)std::max<size_t>(1, ((size_t)24 << 30) / std::max<size_t>(per, 1));
+    const char* budget_env = std::getenv("SLIDEO_SIFT_WS_MB");          // (read per call: a test squeezes it)
+    const size_t budget = budget_env ? (size_t)std::max(atoll(budget_env), 1ll) << 20 : (size_t)24 << 30;
+    const int nb_max = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
     int64_t rows = 0;
     for (int f0 = 0; f0 < n; f0 += nb_max) {
         const int nb = std::min(nb_max, n - f0);

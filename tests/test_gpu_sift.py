@@ -82,3 +82,28 @@ def test_sift_1080p_and_batch_device_path(capi, oracle, m, synth):
     with pytest.raises(capi.SlideoError) as e:
         m.sift_frames_dev(d.data_ptr(), 3, 1920, 1080, kp.data_ptr(), desc.data_ptr(), 100, capi.sift_config(**sc))
     assert e.value.code == 7
+
+
+def test_sift_sub_batches_equal_single_frames(capi, oracle, synth, monkeypatch):
+    """More frames than one pass holds: the batch entry point walks over sub-batches (24 GB of pyramids each; here the budget is
+    squeezed to two frames per pass) — every frame's rows must be what the single-image entry point returns."""
+    import torch
+    monkeypatch.setenv("SLIDEO_SIFT_WS_MB", "24")                      # 640 x 360: ~11 MB per frame -> 2 frames per pass
+    pages = synth.pages(2)
+    frames, truth, _ = synth.frames(pages, 5, 640, 360, first=7)
+    m = capi.Matcher(capi.default_config())
+    sc = capi.sift_config(nfeatures=300)
+    d = torch.from_numpy(frames).cuda()
+    cap = 5 * 600
+    kp = torch.zeros((cap, 6), dtype=torch.int32, device="cuda")
+    desc = torch.zeros((cap, 128), dtype=torch.uint8, device="cuda")
+    qofs, ms = m.sift_frames_dev(d.data_ptr(), 5, 640, 360, kp.data_ptr(), desc.data_ptr(), cap, sc)
+    hd = desc.cpu().numpy(); hk = kp.cpu().numpy().view(capi.KEYPOINT_DTYPE).reshape(-1)
+    assert len(qofs) == 6 and qofs[0] == 0
+    for i in range(5):
+        k1, d1 = m.sift(frames[i], sc)
+        assert qofs[i + 1] - qofs[i] == len(k1) > 0
+        assert np.array_equal(hd[qofs[i]: qofs[i + 1]], d1) and np.array_equal(hk[qofs[i]: qofs[i + 1]], k1), i
+    ok, od, _ = oracle.sift(frames[3], oracle.sift_config(nfeatures=300))
+    assert np.array_equal(hd[qofs[3]: qofs[4]], od)
+    m.close()
