@@ -650,11 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
             p4[2] = pts[mine ? (qs.y & 0xFFFFu) : 0]; p4[3] = pts[mine ? (qs.y >> 16) : 0];
             double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             int nmodels;
-#ifdef RH_EXPERIMENT_NOMODEL
-            if constexpr (HDLT) { nmodels = mine ? 1 : 0; Hm[0] = Hm[4] = Hm[8] = 1.0; Hm[2] = p4[0].x; }
-#else
             if constexpr (HDLT) nmodels = dlt4_direct(p4, mine, Hm);
-#endif
             else nmodels = dlt4<ST>(p4, A, V, W, mine, Hm);
             if (exact4) {
                 found = __shfl(nmodels, 0) > 0;
@@ -668,9 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Hf[j] = (float)Hm[j];
                 good = 0;
-#ifndef RH_EXPERIMENT_NOSCORE
                 for (int i = 0; i < count; ++i) good += (h_error(Hf, pts[i]) <= thr2) ? 1 : 0;
-#endif
             }
             // ---- sequential acceptance over the phase's iterations ----
             int used = nrun;
