@@ -89,7 +89,7 @@ def run_shard(m, pages, visits, n_samples, rank=0, world=1, batch=256, w=1920, h
         changed_all[a - lo:b - lo] = changed
         idx = np.nonzero(changed)[0]
         if len(idx):
-            v = m.match_frames(stack[idx])
+            v = m.match_kept_frames(idx)                   # the mask call's upload, matched in place (no second H2D copy)
             page_of[a - lo + idx] = v["page_idx"]
         t_gpu += time.time() - t0
     return changed_all, page_of, t_gpu, t_gen
