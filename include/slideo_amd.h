@@ -435,6 +435,17 @@ int32_t     slideo_sift_layer_bgr8(slideo_matcher* m, const slideo_sift_config* 
                                    int32_t stride_bytes, int32_t octave, int32_t layer, int32_t dog, float* out, int64_t out_capacity,
                                    int32_t* lw, int32_t* lh);
 
+/* North-star / BASELINE configs[2] as a COMPLETE matcher (no reference counterpart: the reference extracts ORB only,
+ * mo/feature_extractor.rs:3-4,13): SIFT-128 features instead of ORB for pages and frames, brute-force squared-L2 k-NN (k = 2) on
+ * the int8 matrix cores with Lowe's ratio test — a query votes for its nearest row iff sqrt(d1) < ratio * sqrt(d2) (f32) —
+ * instead of the Hamming k-NN + tolerance vote.  Everything from the per-page vote on (candidate ranking, RANSAC per
+ * verify_model, rating, re-projection, verdict) and every entry point (add_pages, finalize, match_frames*, submit / collect,
+ * changed mask + kept frames, the candidate trace) is the path's own.  Must be called before the first page is added; cfg as
+ * for slideo_sift_bgr8 (nfeatures 0 = all keypoints), 0 < ratio <= 1.  slideo_matcher_get_page_features /
+ * _add_page_features (32-byte descriptors) return SLIDEO_ERR_UNSUPPORTED in this mode; descriptor_count is the number of SIFT
+ * rows.  Parity target: the oracle's so_db_use_sift + so_match_frame. */
+int32_t     slideo_matcher_use_sift(slideo_matcher* m, const slideo_sift_config* cfg, float ratio);
+
 /* to_small_image (mo/image_utils.rs:8-20) of one host image. */
 int32_t     slideo_small_image_bgr8(slideo_matcher* m, const uint8_t* bgr, int32_t width,
                                     int32_t height, int32_t stride_bytes, uint8_t* out,

@@ -384,6 +384,13 @@ class PageDB:
         self._h = lib().so_pagedb_create(C.byref(cfg))
         assert self._h, "unsupported config"
 
+    def use_sift(self, sift_cfg, ratio=0.75):
+        """The product's slideo_matcher_use_sift: SIFT features + squared-L2 2-NN + Lowe's ratio test in front of the path's own
+        vote / RANSAC / re-projection stages.  Before the first page."""
+        rc = lib().so_pagedb_use_sift(C.c_void_p(self._h), C.byref(sift_cfg), C.c_float(ratio))
+        assert rc == 0, rc
+        self._sift = True
+
     def add_page(self, bgr):
         bgr = _img3(bgr)
         h, w, _ = bgr.shape
@@ -410,7 +417,7 @@ class PageDB:
 
     def page_features(self, page):
         n = lib().so_pagedb_get_page_features(C.c_void_p(self._h), page, None, None, 0)
-        kp = np.zeros(n, KEYPOINT_DTYPE); desc = np.zeros((n, 32), np.uint8)
+        kp = np.zeros(n, KEYPOINT_DTYPE); desc = np.zeros((n, 128 if getattr(self, "_sift", False) else 32), np.uint8)
         lib().so_pagedb_get_page_features(C.c_void_p(self._h), page, _p(kp), _p(desc), n)
         return kp, desc
 

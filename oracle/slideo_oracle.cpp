@@ -1553,7 +1553,8 @@ static float similarity_bgr8(const uint8_t* a, const uint8_t* b, int w, int h) {
 // ---------------------------------------------------------------------------
 struct Page {
     int w, h;
-    OrbResult orb;
+    OrbResult orb;                    // (SIFT mode: kp = the SIFT keypoints, desc unused)
+    std::vector<uint8_t> sdesc;       // SIFT mode: 128 bytes per keypoint
     std::vector<uint8_t> small;
     int sw, sh;
 };
@@ -1623,8 +1624,16 @@ struct LshIdx {
 };
 }  // namespace
 
+#include "sift_oracle.h"
+
 struct so_pagedb {
     slideo_config cfg;
+    // so_pagedb_use_sift (the product's slideo_matcher_use_sift): SIFT features, squared-L2 2-NN + Lowe's ratio test in front of
+    // the path's own vote / RANSAC / re-projection stages
+    bool sift = false;
+    so_sift_config sc{};
+    float ratio = 0.75f;
+    std::vector<uint8_t> train128;    // M x 128 (SIFT mode)
     LshIdx lsh;
     std::vector<Page> pages;
     std::vector<uint8_t> train;       // M x 32
@@ -1633,6 +1642,8 @@ struct so_pagedb {
     std::vector<int32_t> page_ofs;    // P+1
     bool finalized = false;
 };
+
+extern "C" void so_knn_l2_u8(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, uint32_t* dist);
 
 namespace {
 
@@ -1644,6 +1655,29 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
     out.page_idx = -1; out.similarity = 0; out.inliers = 0; out.n_keypoints = 0;
     if (trace) trace->clear();
     OrbResult fr;
+    int P = (int)db.pages.size();
+    std::vector<std::vector<Vote>> votes(P);
+    if (db.sift) {
+        // SIFT mode (no reference counterpart): cv::SIFT features, BFMatcher(NORM_L2).knnMatch(k = 2), Lowe's ratio test on the
+        // distances as BFMatcher returns them (f32 square roots); a query with fewer than two neighbours casts no vote
+        SiftResult sr;
+        sift_detect_describe(bgr, w, h, stride, db.sc, c.ocv, sr);
+        fr.kp = sr.kp;
+        const int K = (int)fr.kp.size(), M = (int)db.train_page.size();
+        out.n_keypoints = K;
+        if (K == 0) return;
+        std::vector<int32_t> idx((size_t)K * 2);
+        std::vector<uint32_t> d2((size_t)K * 2);
+        so_knn_l2_u8(sr.desc.data(), K, db.train128.data(), M, 2, idx.data(), d2.data());
+        for (int q = 0; q < K; ++q) {
+            if (idx[(size_t)q * 2] < 0 || idx[(size_t)q * 2 + 1] < 0) continue;
+            const float a = std::sqrt((float)d2[(size_t)q * 2]), b = std::sqrt((float)d2[(size_t)q * 2 + 1]);
+            if (a < db.ratio * b) {
+                const int ti = idx[(size_t)q * 2], pg = db.train_page[ti];
+                votes[pg].push_back({q, ti - db.page_ofs[pg]});
+            }
+        }
+    } else {
     orb_detect_describe(bgr, w, h, stride, c, fr);           // mo/lib.rs:264-265
     int K = (int)fr.kp.size(), M = (int)db.train_page.size(), k = c.knn_k;
     out.n_keypoints = K;
@@ -1654,9 +1688,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
         for (int qi = 0; qi < K; ++qi) db.lsh.knn(fr.desc.data() + (size_t)qi * 32, db.train.data(), k, idx.data() + (size_t)qi * k, dist.data() + (size_t)qi * k);
     else
         knn_hamming_blocked(fr.desc.data(), K, db.train_blocked.data(), M, k, idx.data(), dist.data());  // :266 (== knn_hamming)
-    int P = (int)db.pages.size();
     // tolerance vote, mo/lib.rs:268-282: d < best * 1.05 (f32, strict)
-    std::vector<std::vector<Vote>> votes(P);
     for (int q = 0; q < K; ++q) {
         if (idx[(size_t)q * k] < 0) continue;
         float best = (float)dist[(size_t)q * k];
@@ -1680,6 +1712,7 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
             }
         }
     }
+    }   // ORB / Hamming front end
     // candidate ranking, mo/lib.rs:284-295: stable by count desc over ascending page index
     std::vector<int> cand;
     for (int p = 0; p < P; ++p) if (!votes[p].empty()) cand.push_back(p);
@@ -1753,8 +1786,6 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
 }
 
 }  // namespace
-
-#include "sift_oracle.h"
 
 // ===========================================================================
 // C interface (ctypes)
@@ -2002,10 +2033,19 @@ so_pagedb* so_pagedb_create(const slideo_config* c) {
     so_pagedb* db = new so_pagedb(); db->cfg = *c; return db;
 }
 void so_pagedb_destroy(so_pagedb* db) { delete db; }
+// the product's slideo_matcher_use_sift: before the first page
+int so_pagedb_use_sift(so_pagedb* db, const so_sift_config* sc, float ratio) {
+    if (!db->pages.empty() || db->finalized) return 4;
+    if (sc->n_octave_layers != 3 || !(ratio > 0.f) || !(ratio <= 1.f) || db->cfg.matcher != 0) return 1;
+    db->sift = true; db->sc = *sc; db->ratio = ratio;
+    return 0;
+}
 
 int so_pagedb_add_page(so_pagedb* db, const uint8_t* bgr, int w, int h, int stride) {   // mo/lib.rs:92-131
     if (db->finalized) return 4;
     Page p; p.w = w; p.h = h;
+    if (db->sift) { SiftResult sr; sift_detect_describe(bgr, w, h, stride, db->sc, db->cfg.ocv, sr); p.orb.kp = sr.kp; p.sdesc = sr.desc; }
+    else
     orb_detect_describe(bgr, w, h, stride, db->cfg, p.orb);
     if (!small_image(bgr, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh, db->cfg.ocv.area)) return 5;
     db->pages.push_back(std::move(p));
@@ -2023,6 +2063,8 @@ int so_pagedb_add_pages(so_pagedb* db, const uint8_t* pages, int n, int w, int h
             Page& p = db->pages[base + i];
             p.w = w; p.h = h;
             const uint8_t* img = pages + (size_t)i * page_stride;
+            if (db->sift) { SiftResult sr; sift_detect_describe(img, w, h, stride, db->sc, db->cfg.ocv, sr); p.orb.kp = sr.kp; p.sdesc = sr.desc; }
+            else
             orb_detect_describe(img, w, h, stride, db->cfg, p.orb);
             if (!small_image(img, w, h, stride, db->cfg.small_area, p.small, p.sw, p.sh, db->cfg.ocv.area)) rc[t] = 5;
         }
@@ -2034,15 +2076,18 @@ int so_pagedb_add_pages(so_pagedb* db, const uint8_t* pages, int n, int w, int h
     return 0;
 }
 int so_pagedb_finalize(so_pagedb* db) {   // mo/flann.rs:65-71 (exact index = the concatenation)
-    db->train.clear(); db->train_page.clear(); db->page_ofs.assign(1, 0);
+    db->train.clear(); db->train128.clear(); db->train_page.clear(); db->page_ofs.assign(1, 0);
     for (size_t p = 0; p < db->pages.size(); ++p) {
         const OrbResult& o = db->pages[p].orb;
         db->train.insert(db->train.end(), o.desc.begin(), o.desc.end());
+        db->train128.insert(db->train128.end(), db->pages[p].sdesc.begin(), db->pages[p].sdesc.end());
         db->train_page.insert(db->train_page.end(), o.kp.size(), (int32_t)p);
         db->page_ofs.push_back((int32_t)db->train_page.size());
     }
-    knn_block_train(db->train.data(), (int)db->train_page.size(), db->train_blocked);
-    if (db->cfg.matcher == 1) db->lsh.build(db->cfg, db->train.data(), (int)db->train_page.size());
+    if (!db->sift) {
+        knn_block_train(db->train.data(), (int)db->train_page.size(), db->train_blocked);
+        if (db->cfg.matcher == 1) db->lsh.build(db->cfg, db->train.data(), (int)db->train_page.size());
+    }
     db->finalized = true;
     return db->train_page.empty() ? 6 : 0;
 }
@@ -2052,7 +2097,8 @@ int so_pagedb_get_page_features(const so_pagedb* db, int page, slideo_keypoint* 
     const OrbResult& o = db->pages[page].orb;
     int n = (int)o.kp.size(), m = std::min(n, cap);
     if (kp) std::memcpy(kp, o.kp.data(), (size_t)m * sizeof(slideo_keypoint));
-    if (desc) std::memcpy(desc, o.desc.data(), (size_t)m * 32);
+    if (desc && db->sift) std::memcpy(desc, db->pages[page].sdesc.data(), (size_t)m * 128);
+    else if (desc) std::memcpy(desc, o.desc.data(), (size_t)m * 32);
     return n;
 }
 int so_pagedb_get_train(const so_pagedb* db, uint8_t* train, int64_t cap_rows) {

@@ -63,7 +63,7 @@ CANDIDATE_DTYPE = np.dtype([("page_idx", "<i4"), ("n_votes", "<i4"), ("inliers",
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p)
 
 EXPORTS = [
-    "slideo_abi_version", "slideo_matcher_max_in_flight", "slideo_config_default", "slideo_matcher_create", "slideo_matcher_destroy",
+    "slideo_abi_version", "slideo_matcher_use_sift", "slideo_matcher_max_in_flight", "slideo_config_default", "slideo_matcher_create", "slideo_matcher_destroy",
     "slideo_last_error", "slideo_matcher_add_pages_bgr8", "slideo_matcher_finalize_pages",
     "slideo_matcher_page_count", "slideo_matcher_descriptor_count", "slideo_matcher_get_page_features",
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
@@ -211,13 +211,19 @@ class Matcher:
         """Distinct rows among the train descriptors: what the k-NN stage actually searches (results are those of all rows)."""
         return int(lib().slideo_matcher_unique_descriptor_count(self._h))
 
+    def use_sift(self, sift_cfg, ratio=0.75):
+        """SIFT features + squared-L2 2-NN + Lowe's ratio test in front of the path's own vote / RANSAC / re-projection stages
+        (north-star / configs[2] as a complete matcher).  Before the first page."""
+        self._check(lib().slideo_matcher_use_sift(self._h, C.byref(sift_cfg), C.c_float(ratio)))
+        self._sift = True
+
     def page_features(self, page):
         n = C.c_int32()
         rc = lib().slideo_matcher_get_page_features(self._h, page, None, None, 0, C.byref(n))
         if rc not in (OK, 7):
             self._check(rc)
         kp = np.zeros(n.value, KEYPOINT_DTYPE)
-        desc = np.zeros((n.value, 32), np.uint8)
+        desc = np.zeros((n.value, 128 if getattr(self, "_sift", False) else 32), np.uint8)
         self._check(lib().slideo_matcher_get_page_features(self._h, page, _p(kp), _p(desc), n.value, C.byref(n)))
         return kp, desc
 

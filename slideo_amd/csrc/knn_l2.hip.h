@@ -98,4 +98,28 @@ __global__ void knl_unpack_kernel(const unsigned long long* __restrict__ keys, i
     else { idx[i] = (int32_t)(key & 0xFFFFFFFFull); dist[i] = (uint32_t)(key >> 32); }
 }
 
+// SIFT matcher mode (slideo_matcher_use_sift): Lowe's ratio test on the two nearest rows of the squared-L2 search, written as
+// neighbour lists in the HAMMING key format (knn.hip.h: distance << 23 | row, KNN_EMPTY padding) so that the vote kernel — ratio
+// branch, ratio 1 — and everything after it run unchanged: entry 0 = (0, nearest row), entry 1 = (pass ? 1 : 0, second row), and
+// "0 < 1 * entry 1's distance" is the test's outcome.  pass iff sqrt(d1) < ratio * sqrt(d2) in f32 (BFMatcher returns the square
+// roots as floats; IEEE sqrt: the CPU restatement evaluates the same expression).  A query with fewer than two neighbours casts
+// no vote (knnMatch with k = 2 needs both).   lists: [nq][kl] u64 ascending (d^2 << 32 | row).  grid ceil(nq / 256).
+__global__ __launch_bounds__(256) void l2_ratio_keys_kernel(const unsigned long long* __restrict__ lists, int kl, int nq, float ratio,
+                                                            uint32_t* __restrict__ keys, int klist) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const unsigned long long k0 = lists[(size_t)q * kl], k1 = lists[(size_t)q * kl + 1];
+    uint32_t o0 = KNN_EMPTY, o1 = KNN_EMPTY;
+    if (k0 != KNL_EMPTY) {
+        o0 = (uint32_t)k0 & KNN_IDX_MASK;
+        if (k1 != KNL_EMPTY) {
+            const float d1 = sqrtf((float)(uint32_t)(k0 >> 32)), d2 = sqrtf((float)(uint32_t)(k1 >> 32));
+            o1 = ((d1 < ratio * d2 ? 1u : 0u) << KNN_KEY_SHIFT) | ((uint32_t)k1 & KNN_IDX_MASK);
+        }
+    }
+    uint4* out = reinterpret_cast<uint4*>(keys + (size_t)q * klist);
+    out[0] = make_uint4(o0, o1, KNN_EMPTY, KNN_EMPTY);
+    for (int i = 1; i < klist / 4; ++i) out[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
+}
+
 }  // namespace slideo

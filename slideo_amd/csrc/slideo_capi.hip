@@ -120,6 +120,13 @@ struct slideo_matcher {
     // pages
     std::vector<HostPage> pages;
     bool finalized = false;
+    // slideo_matcher_use_sift: SIFT features + L2 k-NN (k = 2) + ratio test in front of the verify stage.  The SIFT and L2
+    // workspaces are the matcher's (not a slot's): the extraction stages of consecutive units take turns (sift_ev)
+    bool sift_on = false;
+    slideo_sift_config sift_cfg{};
+    float sift_ratio = 0.75f;
+    hipEvent_t sift_ev = nullptr;
+    bool sift_ev_set = false;
     int64_t M = -1;
     DevBuf d_train, d_train_page, d_page_xy, d_pageinfo, d_page_small;
     DevBuf d_trainb, d_train_side, d_train_nminh, d_train_perm;   // {0,1} FP4 operand in norm order + its side arrays (knn_tile.hip.h)
@@ -675,93 +682,16 @@ uint32_t kp_cap_for(const slideo_matcher* m, const PyrGeom& g) {
     return (uint32_t)std::max(1, std::min(cap, std::max(g.cand_per_frame, 1)));
 }
 
-void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
-                 bool allow_async = true) {
+// Everything after the neighbour lists (S.d_keys, Hamming key format) of a unit: the per-page vote, RANSAC (similarity or
+// homography), rating, re-projection, verdicts, and the unit's one D2H copy.  `frames_dev`: the unit's frames (re-projection).
+void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+                 uint32_t qtot) {
     const slideo_config& c = m->cfg;
     hipStream_t st = S.st;
     const bool prof = m->profiling;
-    const PyrGeom& g = geom_for(m, w, h).g;
-    // Capacity-sized (no host wait in the middle of the unit) when the matrix-core kNN runs: every kernel downstream of the ORB
-    // counts reads them on the device.  The VALU engine (A/B only) keeps the exact-size path.
-    const uint32_t kpcap = kp_cap_for(m, g);
-    // (a capacity below quota + margin — the KP_SORT_LDS clamp at nfeatures >= ~7 k — would overflow on every busy frame and run
-    // every unit twice: those configurations take the exact-size path from the start)
-    const bool async = allow_async && m->async_submit && knn_engine_for(m, n * (int)std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures)) != 1 &&
-                       (int64_t)n * kpcap < ((int64_t)1 << 30) &&
-                       (kpcap >= (uint32_t)c.nfeatures + 1024u || kpcap >= (uint32_t)std::max(g.cand_per_frame, 1));
-    S.timed = prof; S.u_frames = frames_dev; S.u_w = w; S.u_h = h; S.u_stride = stride; S.u_fs = frame_stride; S.u_async = async;
-    if (m->orb_chain && m->last_orb_ev && m->last_orb_ev != S.ev_orb) HIP_CHECK(hipStreamWaitEvent(st, m->last_orb_ev, 0));
-    if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
-    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride, false, async ? kpcap : 0xFFFFFFFFu);
-    uint32_t qtot, qplan;
-    if (async) {
-        qtot = (uint32_t)n * kpcap;                                          // capacity
-        qplan = (uint32_t)n * std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures);   // what the kNN plan assumes
-        S.orb.qtot = qtot; S.orb.max_count = kpcap;
-    } else {
-        orb_wait_info(m, S);                  // the other units' kNN / verify keep the GPU busy meanwhile
-        qtot = qplan = S.orb.qtot;
-    }
-    // all workspace before the timed kNN interval
-    // (the matrix-core engine searches the unique rows of the train set, the VALU engine — A/B only — all of them)
-    const bool dedup = m->Mu < m->M && knn_engine_for(m, (int)qplan) != 1;
-    const int nt_knn = (int)(dedup ? m->Mu : m->M);
-    S.u_nt = nt_knn;
-    knn_reserve(m, S, (int)qplan, nt_knn, (int)qtot);
-    S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
-    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
-    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * c.knn_k, 16));
-    S.d_fcs.reserve((size_t)n * sizeof(FrameCands));
-    S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
-    S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
-    S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
-    orb_stage2(m, S, w, h, async);
-    HIP_CHECK(hipEventRecord(S.ev_orb, st));
-    m->last_orb_ev = S.ev_orb;
-    VerifyParams vp = make_vp(c);
-    vp.rng_len = m->rng_len;
     const int P = (int)m->pages.size();
-    HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
-    uint32_t* flags = S.d_flags.as<uint32_t>();   // zeroed by orb_stage1
-    if (m->knn_chain && m->last_knn_ev && m->last_knn_ev != S.ev_knn) HIP_CHECK(hipStreamWaitEvent(st, m->last_knn_ev, 0));
-    if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
+    uint32_t* flags = S.d_flags.as<uint32_t>();
     if (qtot > 0) {
-        // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
-        // current best must still be kept, hence max(tol, 1)
-        // (the ratio test needs the exact two nearest rows: exact lists)
-        const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
-        const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
-        if (c.matcher == 1 && (m->lsh_gather || knn_engine_for(m, (int)qplan) == 1)) {
-            // the reference's index, gathered: only the LSH candidates of a query are scored (knn_lsh.hip.h); same key lists out
-            knn_lsh_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), 4), 256, 0, st>>>(m->lsh.dev, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(),
-                                                                                   S.d_keys.as<uint32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
-            check_launch("knn_lsh_kernel");
-        } else if (c.matcher == 1) {
-            // the same result from the matrix-core stream over ALL rows with the candidate rule applied where a row passes the
-            // distance test (KtHammingLsh): a fifth of all rows are candidates of a query on these descriptors (skewed buckets),
-            // so gathering them is 60x slower than streaming everything
-            const uint32_t* nqd = async ? S.d_qofs.as<uint32_t>() + n : nullptr;
-            S.d_qkeys.reserve(std::max<size_t>((size_t)qtot * c.lsh_tables * 2, 64));
-            lsh_query_keys_kernel<<<cdiv((int)std::max(qtot, 1u), 256), 256, 0, st>>>(m->lsh.dev.p, S.d_desc.as<uint32_t>(), (int)qtot, S.d_qkeys.as<uint16_t>(), nqd);
-            check_launch("lsh_query_keys_kernel");
-            const KnnPlan p = knn_plan(m, (int)qplan, nt_knn, (int)qtot);
-            const KtLshCtx ctx{m->lsh.dev.keys, S.d_qkeys.as<uint16_t>(), c.lsh_tables, c.lsh_multi_probe};
-            knn_tile2_lsh_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(S.d_desc.as<uint32_t>(), (int)qplan, T.txb, T.side, T.nminh, knn_pad_rows(nt_knn), p.per_seg,
-                                                                                 S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune, nqd, ctx);
-            check_launch("knn_tile2_lsh_kernel");
-            if (p.nseg > 1) {
-                knn_merge_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), (int)qplan, p.nseg, nqd);
-                check_launch("knn_merge_kernel");
-            }
-        } else
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
-        if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
-        if (m->knn_chain) { HIP_CHECK(hipEventRecord(S.ev_knn, st)); m->last_knn_ev = S.ev_knn; }
-        if (dedup) {
-            knn_expand_dups_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(
-                S.d_keys.as<uint32_t>(), (int)qtot, m->d_grp_next.as<int32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
-            check_launch("knn_expand_dups_kernel");
-        }
         const size_t lds = (size_t)P * 4 + (((size_t)P + 15) & ~(size_t)15) + (size_t)c.max_candidate_pages * 256 * 4;
         vote_kernel<<<n, 256, lds, st>>>(vp, S.d_keys.as<uint32_t>(), S.d_qofs.as<uint32_t>(), m->d_train_page.as<int32_t>(), P,
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
@@ -826,6 +756,98 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     HIP_CHECK(hipMemcpyAsync(ho + tail + 4, S.d_info.p, 8, hipMemcpyDeviceToHost, st));      // {Qtot, max keypoints per frame}
     if (prof) HIP_CHECK(hipEventRecord(S.ev[4], st));
     S.busy = true; S.n = n;
+}
+void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride);
+void add_pages_sift(slideo_matcher* m, Slot& S, int cnt, int w, int h, int stride, int64_t fb);
+
+void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
+                 bool allow_async = true) {
+    if (m->sift_on) { unit_submit_sift(m, S, frames_dev, n, w, h, stride, frame_stride); return; }
+    const slideo_config& c = m->cfg;
+    hipStream_t st = S.st;
+    const bool prof = m->profiling;
+    const PyrGeom& g = geom_for(m, w, h).g;
+    // Capacity-sized (no host wait in the middle of the unit) when the matrix-core kNN runs: every kernel downstream of the ORB
+    // counts reads them on the device.  The VALU engine (A/B only) keeps the exact-size path.
+    const uint32_t kpcap = kp_cap_for(m, g);
+    // (a capacity below quota + margin — the KP_SORT_LDS clamp at nfeatures >= ~7 k — would overflow on every busy frame and run
+    // every unit twice: those configurations take the exact-size path from the start)
+    const bool async = allow_async && m->async_submit && knn_engine_for(m, n * (int)std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures)) != 1 &&
+                       (int64_t)n * kpcap < ((int64_t)1 << 30) &&
+                       (kpcap >= (uint32_t)c.nfeatures + 1024u || kpcap >= (uint32_t)std::max(g.cand_per_frame, 1));
+    S.timed = prof; S.u_frames = frames_dev; S.u_w = w; S.u_h = h; S.u_stride = stride; S.u_fs = frame_stride; S.u_async = async;
+    if (m->orb_chain && m->last_orb_ev && m->last_orb_ev != S.ev_orb) HIP_CHECK(hipStreamWaitEvent(st, m->last_orb_ev, 0));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
+    orb_stage1(m, S, frames_dev, n, w, h, stride, frame_stride, false, async ? kpcap : 0xFFFFFFFFu);
+    uint32_t qtot, qplan;
+    if (async) {
+        qtot = (uint32_t)n * kpcap;                                          // capacity
+        qplan = (uint32_t)n * std::min<uint32_t>(kpcap, (uint32_t)c.nfeatures);   // what the kNN plan assumes
+        S.orb.qtot = qtot; S.orb.max_count = kpcap;
+    } else {
+        orb_wait_info(m, S);                  // the other units' kNN / verify keep the GPU busy meanwhile
+        qtot = qplan = S.orb.qtot;
+    }
+    // all workspace before the timed kNN interval
+    // (the matrix-core engine searches the unique rows of the train set, the VALU engine — A/B only — all of them)
+    const bool dedup = m->Mu < m->M && knn_engine_for(m, (int)qplan) != 1;
+    const int nt_knn = (int)(dedup ? m->Mu : m->M);
+    S.u_nt = nt_knn;
+    knn_reserve(m, S, (int)qplan, nt_knn, (int)qtot);
+    S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
+    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
+    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * c.knn_k, 16));
+    S.d_fcs.reserve((size_t)n * sizeof(FrameCands));
+    S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
+    S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
+    S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
+    orb_stage2(m, S, w, h, async);
+    HIP_CHECK(hipEventRecord(S.ev_orb, st));
+    m->last_orb_ev = S.ev_orb;
+    VerifyParams vp = make_vp(c);
+    vp.rng_len = m->rng_len;
+    HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
+    if (m->knn_chain && m->last_knn_ev && m->last_knn_ev != S.ev_knn) HIP_CHECK(hipStreamWaitEvent(st, m->last_knn_ev, 0));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
+    if (qtot > 0) {
+        // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
+        // current best must still be kept, hence max(tol, 1)
+        // (the ratio test needs the exact two nearest rows: exact lists)
+        const float prune = (m->knn_exact_lists || m->cfg.ratio_test > 0.f) ? 0.f : std::max(m->cfg.vote_tolerance, 1.0f);
+        const TrainOps T{m->d_train.as<uint32_t>(), m->d_trainb.as<uint4>(), m->d_train_side.as<uint32_t>(), m->d_train_nminh.as<float4>()};
+        if (c.matcher == 1 && (m->lsh_gather || knn_engine_for(m, (int)qplan) == 1)) {
+            // the reference's index, gathered: only the LSH candidates of a query are scored (knn_lsh.hip.h); same key lists out
+            knn_lsh_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), 4), 256, 0, st>>>(m->lsh.dev, S.d_desc.as<uint32_t>(), (int)qtot, m->d_train.as<uint32_t>(),
+                                                                                   S.d_keys.as<uint32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
+            check_launch("knn_lsh_kernel");
+        } else if (c.matcher == 1) {
+            // the same result from the matrix-core stream over ALL rows with the candidate rule applied where a row passes the
+            // distance test (KtHammingLsh): a fifth of all rows are candidates of a query on these descriptors (skewed buckets),
+            // so gathering them is 60x slower than streaming everything
+            const uint32_t* nqd = async ? S.d_qofs.as<uint32_t>() + n : nullptr;
+            S.d_qkeys.reserve(std::max<size_t>((size_t)qtot * c.lsh_tables * 2, 64));
+            lsh_query_keys_kernel<<<cdiv((int)std::max(qtot, 1u), 256), 256, 0, st>>>(m->lsh.dev.p, S.d_desc.as<uint32_t>(), (int)qtot, S.d_qkeys.as<uint16_t>(), nqd);
+            check_launch("lsh_query_keys_kernel");
+            const KnnPlan p = knn_plan(m, (int)qplan, nt_knn, (int)qtot);
+            const KtLshCtx ctx{m->lsh.dev.keys, S.d_qkeys.as<uint16_t>(), c.lsh_tables, c.lsh_multi_probe};
+            knn_tile2_lsh_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(S.d_desc.as<uint32_t>(), (int)qplan, T.txb, T.side, T.nminh, knn_pad_rows(nt_knn), p.per_seg,
+                                                                                 S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune, nqd, ctx);
+            check_launch("knn_tile2_lsh_kernel");
+            if (p.nseg > 1) {
+                knn_merge_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), (int)qplan, p.nseg, nqd);
+                check_launch("knn_merge_kernel");
+            }
+        } else
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
+        if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
+        if (m->knn_chain) { HIP_CHECK(hipEventRecord(S.ev_knn, st)); m->last_knn_ev = S.ev_knn; }
+        if (dedup) {
+            knn_expand_dups_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(
+                S.d_keys.as<uint32_t>(), (int)qtot, m->d_grp_next.as<int32_t>(), async ? S.d_qofs.as<uint32_t>() + n : nullptr);
+            check_launch("knn_expand_dups_kernel");
+        }
+    }
+    unit_verify(m, S, vp, frames_dev, n, w, h, stride, frame_stride, qtot);
 }
 
 void unit_collect(slideo_matcher* m, Slot& S, slideo_verdict* out_host) {
@@ -1024,6 +1046,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         HIP_CHECK(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
     }
     HIP_CHECK(hipStreamCreateWithFlags(&mm->copy_st, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&mm->sift_ev, hipEventDisableTiming));
     mm->stream = mm->slots[0].st;
     OrbTables t{};
     umax_table(cfg->patch_size / 2, t.umax);
@@ -1073,6 +1096,7 @@ void slideo_matcher_destroy(slideo_matcher* m) {
         if (S.ev_up) (void)hipEventDestroy(S.ev_up);
     }
     if (m->copy_st) (void)hipStreamDestroy(m->copy_st);
+    if (m->sift_ev) (void)hipEventDestroy(m->sift_ev);
     delete m;
 }
 
@@ -1139,13 +1163,15 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
         S.d_stage.reserve(fb * cnt + 16);
         for (int j = 0; j < cnt; ++j)
             HIP_CHECK(hipMemcpyAsync(S.d_stage.as<uint8_t>() + fb * j, data[i + j], fb, hipMemcpyHostToDevice, st));
-        run_orb(m, S, S.d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, true);
+        const size_t dbytes = m->sift_on ? 128 : 32;                       // descriptor bytes per keypoint
+        if (m->sift_on) add_pages_sift(m, S, cnt, w, h, stride, (int64_t)fb);     // -> S.d_kp / S.d_desc / S.orb.qofs, like run_orb
+        else run_orb(m, S, S.d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, true);
         const uint32_t qtot = S.orb.qtot;
         std::vector<slideo_keypoint> kp(qtot);
-        std::vector<uint8_t> desc((size_t)qtot * 32);
+        std::vector<uint8_t> desc((size_t)qtot * dbytes);
         if (qtot) {
             HIP_CHECK(hipMemcpyAsync(kp.data(), S.d_kp.p, (size_t)qtot * sizeof(slideo_keypoint), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipMemcpyAsync(desc.data(), S.d_desc.p, (size_t)qtot * 32, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(desc.data(), S.d_desc.p, (size_t)qtot * dbytes, hipMemcpyDeviceToHost, st));
         }
         int sw = 0, sh = 0;
         run_small(m, S.d_stage.as<uint8_t>(), cnt, w, h, stride, (int64_t)fb, sw, sh, st);
@@ -1158,7 +1184,7 @@ int32_t slideo_matcher_add_pages_bgr8(slideo_matcher* m, int32_t n_pages, const 
             pg.w = w; pg.h = h; pg.sw = sw; pg.sh = sh; pg.area_idx = ac;
             const uint32_t a = S.orb.qofs[j], b = S.orb.qofs[j + 1];
             pg.kp.assign(kp.begin() + a, kp.begin() + b);
-            pg.desc.assign(desc.begin() + (size_t)a * 32, desc.begin() + (size_t)b * 32);
+            pg.desc.assign(desc.begin() + (size_t)a * dbytes, desc.begin() + (size_t)b * dbytes);
             pg.small_img.assign(smalls.begin() + (size_t)j * sw * sh * 3, smalls.begin() + (size_t)(j + 1) * sw * sh * 3);
             m->pages.push_back(std::move(pg));
             if (m->progress) m->progress(m->progress_user, (uint64_t)(i + j + 1), total, "Analyzing PDF pages...");   // lib.rs:49-53
@@ -1174,6 +1200,7 @@ int32_t slideo_matcher_add_page_features(slideo_matcher* m, int32_t width, int32
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
     if (m->finalized) fail(SLIDEO_ERR_STATE, "pages cannot be added after finalize");
+    if (m->sift_on) fail(SLIDEO_ERR_UNSUPPORTED, "page features are 32-byte ORB descriptors: not in SIFT mode");
     if (n_keypoints < 0 || (n_keypoints > 0 && (!kp || !desc32)) || !small_bgr) fail(SLIDEO_ERR_INVALID_ARG, "null page feature arrays");
     validate_image(width, height, width * 3);
     HIP_CHECK(hipSetDevice(m->device));
@@ -1202,6 +1229,8 @@ int32_t slideo_matcher_get_page_small(const slideo_matcher* cm, int32_t page_idx
     API_CATCH(m)
 }
 
+void l2_prepare(slideo_matcher::L2Set& L, const uint8_t* t, int nt, hipStream_t st);      // (defined with the L2 entry points below)
+
 int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
@@ -1214,7 +1243,8 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     if (M >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "%lld descriptors exceed 2^23", (long long)M);
     // (the matcher stays open for more pages: the reference's FLANN train on an empty set throws, mo/flann.rs:45-47)
     if (M == 0) fail(SLIDEO_ERR_EMPTY_INDEX, "no page produced a descriptor");
-    std::vector<uint8_t> train((size_t)M * 32);
+    const size_t dbytes = m->sift_on ? 128 : 32;                           // descriptor bytes per row
+    std::vector<uint8_t> train((size_t)M * dbytes);
     std::vector<int32_t> tpage((size_t)M);
     std::vector<float2> xy((size_t)M);
     std::vector<PageInfo> info(P);
@@ -1225,7 +1255,7 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
         PageInfo& pi = info[p];
         pi.w = pg.w; pi.h = pg.h; pi.area_idx = pg.area_idx; pi.sw = pg.sw; pi.sh = pg.sh;
         pi.kp_ofs = (int32_t)row; pi.kp_cnt = (int32_t)pg.kp.size(); pi._pad = 0; pi.small_ofs = sofs;
-        std::memcpy(train.data() + (size_t)row * 32, pg.desc.data(), pg.desc.size());
+        std::memcpy(train.data() + (size_t)row * dbytes, pg.desc.data(), pg.desc.size());
         for (size_t i = 0; i < pg.kp.size(); ++i) { tpage[row + i] = p; xy[row + i] = make_float2(pg.kp[i].x, pg.kp[i].y); }
         std::memcpy(smalls.data() + sofs, pg.small_img.data(), pg.small_img.size());
         row += (int64_t)pg.kp.size(); sofs += (int64_t)pg.small_img.size();
@@ -1235,7 +1265,13 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     m->d_page_xy.reserve(std::max<size_t>(xy.size() * sizeof(float2), 16));
     m->d_pageinfo.reserve(std::max<size_t>(info.size() * sizeof(PageInfo), 16));
     m->d_page_small.reserve(std::max<size_t>(smalls.size(), 16));
-    if (M > 0) {
+    if (M > 0 && m->sift_on) {
+        // SIFT mode: the rows become the train set of the squared-L2 engine (norm order, centred tile-major operand)
+        HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
+        l2_prepare(m->l2, train.data(), (int)M, m->stream);
+        m->Mu = M;
+    } else if (M > 0) {
         HIP_CHECK(hipMemcpy(m->d_train.p, train.data(), train.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(m->d_page_xy.p, xy.data(), xy.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -1908,12 +1944,108 @@ int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, int w, i
     return rows;
 }
 
+// rows of keypoint / descriptor capacity a SIFT-mode unit of n frames reserves (ties at retainBest's threshold are kept)
+int64_t sift_unit_capacity(const slideo_matcher* m, int n) {
+    const int per = m->sift_cfg.nfeatures > 0 ? std::min(m->sift_cfg.nfeatures + 2048, 1 << 15) : (1 << 15);
+    return (int64_t)n * per;
+}
+
+// slideo_matcher_use_sift: a unit = SIFT on the frames -> squared-L2 k-NN (k = 2) against the deck's SIFT rows -> ratio test as
+// Hamming-format neighbour lists (l2_ratio_keys_kernel) -> the common verify stage.  The SIFT and L2 workspaces belong to the
+// matcher, so the extraction stages of consecutive units take turns (event chain); their verify stages overlap the next
+// unit's extraction.  The keypoint counts come back to the host inside sift_batch: the submit blocks for the extraction.
+void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
+    const slideo_config& c = m->cfg;
+    hipStream_t st = S.st;
+    const bool prof = m->profiling;
+    S.timed = prof; S.u_frames = frames_dev; S.u_w = w; S.u_h = h; S.u_stride = stride; S.u_fs = frame_stride; S.u_async = false;
+    if (m->sift_ev_set) HIP_CHECK(hipStreamWaitEvent(st, m->sift_ev, 0));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[0], st));
+    std::vector<uint32_t> counts((size_t)std::max(n, 1), 0);
+    int64_t cap = sift_unit_capacity(m, n), rows = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        S.d_kp.reserve(std::max<size_t>((size_t)cap * sizeof(slideo_keypoint), 64));
+        S.d_desc.reserve(std::max<size_t>((size_t)cap * 128, 128));
+        rows = sift_batch(m, frames_dev, n, w, h, stride, frame_stride, m->sift_cfg, 0, cap, S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(),
+                          counts.data(), st);
+        if (rows <= cap) break;
+        cap = rows;                                                           // (nfeatures 0 on a very busy frame: once more with room)
+    }
+    const uint32_t qtot = (uint32_t)rows;
+    S.orb.qofs.assign((size_t)n + 1, 0);
+    uint32_t mx = 0;
+    for (int i = 0; i < n; ++i) { S.orb.qofs[i + 1] = S.orb.qofs[i] + counts[i]; mx = std::max(mx, counts[i]); }
+    S.orb.qtot = qtot; S.orb.max_count = mx; S.orb.nframes = n;
+    S.u_nt = (int)m->M;
+    S.d_qofs.reserve((size_t)(n + 1) * 4 + 16); S.d_info.reserve(16); S.d_flags.reserve(16);
+    S.h_info.reserve((size_t)(n + 1) * 4 + 16);
+    uint32_t* hq = S.h_info.as<uint32_t>();
+    std::memcpy(hq, S.orb.qofs.data(), (size_t)(n + 1) * 4);
+    hq[n + 1] = qtot; hq[n + 2] = mx;
+    HIP_CHECK(hipMemcpyAsync(S.d_qofs.p, hq, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d_info.p, hq + n + 1, 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(S.d_flags.p, 0, 16, st));
+    S.d_keys.reserve(std::max<size_t>((size_t)qtot * KLIST * 4, 64));
+    S.d_votes.reserve(std::max<size_t>((size_t)qtot * 2 * sizeof(uint2), 16));
+    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * 2 * sizeof(float4), 16));
+    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * 2, 16));
+    S.d_fcs.reserve((size_t)n * sizeof(FrameCands));
+    S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
+    S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
+    S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
+    HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
+    if (qtot > 0) {
+        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, 2, st, S, false);
+        l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(m->l2.d_keys.as<unsigned long long>(), 8, (int)qtot, m->sift_ratio,
+                                                                  S.d_keys.as<uint32_t>(), KLIST);
+        check_launch("l2_ratio_keys_kernel");
+    }
+    if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
+    HIP_CHECK(hipEventRecord(m->sift_ev, st));                               // the matcher's SIFT / L2 workspaces are free again
+    m->sift_ev_set = true;
+    VerifyParams vp = make_vp(c);
+    vp.rng_len = m->rng_len;
+    vp.k = 2; vp.ratio = 1.f;                                                 // (the lists carry the test's outcome: l2_ratio_keys_kernel)
+    unit_verify(m, S, vp, frames_dev, n, w, h, stride, frame_stride, qtot);
+}
+
+// page ingest in SIFT mode: the staged pages (S.d_stage) -> S.d_kp / S.d_desc (128 B rows) / S.orb.qofs, as run_orb leaves them
+void add_pages_sift(slideo_matcher* m, Slot& S, int cnt, int w, int h, int stride, int64_t fb) {
+    sift_check_cfg(&m->sift_cfg, w, h);
+    std::vector<uint32_t> counts((size_t)cnt, 0);
+    int64_t cap = sift_unit_capacity(m, cnt), rows = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        S.d_kp.reserve(std::max<size_t>((size_t)cap * sizeof(slideo_keypoint), 64));
+        S.d_desc.reserve(std::max<size_t>((size_t)cap * 128, 128));
+        rows = sift_batch(m, S.d_stage.as<uint8_t>(), cnt, w, h, stride, fb, m->sift_cfg, 0, cap, S.d_kp.as<slideo_keypoint>(), S.d_desc.as<uint8_t>(),
+                          counts.data(), S.st);
+        if (rows <= cap) break;
+        cap = rows;
+    }
+    HIP_CHECK(hipStreamSynchronize(S.st));
+    S.orb.qofs.assign((size_t)cnt + 1, 0);
+    for (int i = 0; i < cnt; ++i) S.orb.qofs[i + 1] = S.orb.qofs[i] + counts[i];
+    S.orb.qtot = (uint32_t)rows; S.orb.nframes = cnt;
+}
+
 }  // namespace
 }  // extern "C++"
 
 void slideo_sift_config_default(slideo_sift_config* c) {
     if (!c) return;
     c->nfeatures = 0; c->n_octave_layers = 3; c->contrast_threshold = 0.04; c->edge_threshold = 10; c->sigma = 1.6;
+}
+
+int32_t slideo_matcher_use_sift(slideo_matcher* m, const slideo_sift_config* cfg, float ratio) {
+    if (!m) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    if (!m->pages.empty() || m->finalized) fail(SLIDEO_ERR_STATE, "slideo_matcher_use_sift must precede the first page");
+    sift_check_cfg(cfg, 64, 64);
+    if (!(ratio > 0.f) || !(ratio <= 1.f)) fail(SLIDEO_ERR_INVALID_ARG, "ratio must be in (0, 1]");
+    if (m->cfg.matcher != 0) fail(SLIDEO_ERR_UNSUPPORTED, "the LSH index is a Hamming index: not with SIFT features");
+    m->sift_on = true; m->sift_cfg = *cfg; m->sift_ratio = ratio;
+    API_CATCH(m)
 }
 
 int32_t slideo_sift_frames_dev(slideo_matcher* m, const slideo_sift_config* cfg, int32_t n_frames, const uint8_t* frames_dev, int32_t width,

@@ -73,3 +73,30 @@ def test_sift_matches_a_transformed_view(oracle, synth):
     idx2, dist2 = oracle.knn_l2_u8(df, do, 2)
     good2 = np.sqrt(dist2[:, 0].astype(np.float64)) < 0.75 * np.sqrt(dist2[:, 1].astype(np.float64))
     assert good2.sum() < good.sum() / 3
+
+
+def test_sift_matcher_mode_end_to_end_cfg0(oracle, cfg0_data):
+    """so_pagedb_use_sift: SIFT features + squared-L2 2-NN + Lowe's ratio test in front of the path's own stages — the frames of
+    configs[0] are assigned to their pages, the 'no slide' ones to none, and the ratio decides who votes."""
+    from conftest import small_cfg
+    pages, frames, truth, _ = cfg0_data
+    db = oracle.PageDB(small_cfg(oracle))
+    db.use_sift(oracle.sift_config(nfeatures=400), 0.75)
+    for p in pages:
+        db.add_page(p)
+    assert db.finalize() == 0 and db.descriptor_count > 0
+    kp, desc = db.page_features(0)
+    assert desc.shape[1] == 128 and len(kp) == len(desc) > 0
+    v = db.match_frames(frames)
+    assert list(v["page_idx"]) == list(truth)
+    # a stricter ratio lets fewer queries vote
+    loose, strict = [], []
+    for r, acc in ((0.9, loose), (0.5, strict)):
+        d2 = oracle.PageDB(small_cfg(oracle))
+        d2.use_sift(oracle.sift_config(nfeatures=400), r)
+        for p in pages:
+            d2.add_page(p)
+        d2.finalize()
+        _, cands = d2.match_frame_trace(frames[1])
+        acc.append(int(cands["n_votes"].sum()))
+    assert strict[0] < loose[0]
