@@ -1698,6 +1698,7 @@ int32_t slideo_l2_set_train(slideo_matcher* m, const uint8_t* t, int32_t nt) {
     if (!m) return SLIDEO_ERR_INVALID_ARG;
     API_TRY
     if (nt < 0 || (nt && !t)) fail(SLIDEO_ERR_INVALID_ARG, "null train set");
+    if (m->sift_on) fail(SLIDEO_ERR_STATE, "the L2 train set is the page DB's in SIFT mode");
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
     HIP_CHECK(hipSetDevice(m->device));
     require_idle(m);
