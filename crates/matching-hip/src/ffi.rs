@@ -67,6 +67,17 @@ pub struct slideo_verdict {
     pub n_keypoints: i32,
 }
 
+/// slideo_sift_config: cv::SIFT::create's parameters (the north-star's optional extractor, slideo_matcher_use_sift)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct slideo_sift_config {
+    pub nfeatures: i32,
+    pub n_octave_layers: i32,
+    pub contrast_threshold: f64,
+    pub edge_threshold: f64,
+    pub sigma: f64,
+}
+
 #[repr(C)]
 pub struct slideo_matcher {
     _private: [u8; 0],
@@ -101,6 +112,9 @@ extern "C" {
         frame_stride_bytes: i64,
         verdicts_out: *mut slideo_verdict,
     ) -> i32;
+    pub fn slideo_sift_config_default(cfg: *mut slideo_sift_config);
+    /// optional: SIFT + L2 + ratio test in front of the verify stages (before the first page)
+    pub fn slideo_matcher_use_sift(m: *mut slideo_matcher, cfg: *const slideo_sift_config, ratio: f32) -> i32;
     pub fn slideo_match_kept_frames(
         m: *mut slideo_matcher,
         n_sel: i32,

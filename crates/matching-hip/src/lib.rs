@@ -59,11 +59,14 @@ fn check(h: *mut ffi::slideo_matcher, rc: i32) {
 pub struct HipImageVideoMatcher {
     /// HIP device ordinal (one process per GPU: the multi-GPU launcher gives each rank its own)
     pub device: i32,
+    /// Some(ratio): the north-star's SIFT + L2 + Lowe's ratio test front end (slideo_matcher_use_sift) instead of the
+    /// reference's ORB + Hamming + tolerance vote; None (default) = the reference's
+    pub sift_ratio: Option<f32>,
 }
 
 impl Default for HipImageVideoMatcher {
     fn default() -> Self {
-        HipImageVideoMatcher { device: 0 }
+        HipImageVideoMatcher { device: 0, sift_ratio: None }
     }
 }
 
@@ -83,6 +86,11 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
                 std::ptr::null_mut(),
                 ffi::slideo_matcher_create(cfg.as_ptr(), self.device, &mut h),
             );
+            if let Some(ratio) = self.sift_ratio {
+                let mut sc = std::mem::MaybeUninit::<ffi::slideo_sift_config>::uninit();
+                ffi::slideo_sift_config_default(sc.as_mut_ptr());
+                check(h, ffi::slideo_matcher_use_sift(h, sc.as_ptr(), ratio));
+            }
         }
         // Page analysis (mo/lib.rs:43-58).  Pages are decoded on the host and handed over in groups, so that a 1000-page
         // deck does not sit decoded in memory at once; the progress protocol is the reference's and is driven from here

@@ -181,13 +181,17 @@ class HipVideoMatcher:
 class HipImageVideoMatcher:
     """Drop-in for OpenCVImageVideoMatcher (lib.rs:34-73) behind matching::ImageVideoMatcher."""
 
-    def __init__(self, cfg=None, device=0):
-        self._cfg, self._device = cfg, device
+    def __init__(self, cfg=None, device=0, sift=None):
+        """sift = (slideo_sift_config, ratio): the north-star's SIFT + L2 + ratio-test front end instead of the reference's ORB +
+        Hamming + tolerance vote (slideo_matcher_use_sift); None = the reference's."""
+        self._cfg, self._device, self._sift = cfg, device, sift
 
     def create_video_matcher(self, images, progress_reporter: ProgressReporter) -> HipVideoMatcher:
         """images: objects with get_path() (matching::MatchableImage, lib.rs:31-33)."""
         images = list(images)
         m = _capi.Matcher(self._cfg, self._device)
+        if self._sift is not None:
+            m.use_sift(*self._sift)
         m.set_progress(progress_reporter.report)        # "Analyzing PDF pages..." protocol, lib.rs:43-58
         CH = 32
         for i in range(0, len(images), CH):
