@@ -285,11 +285,19 @@ public:
         slideo_config_default(&cfg_);
         if (cfg) cfg_ = *cfg;
     }
+    // ratio > 0: SIFT features + squared-L2 2-NN + Lowe's ratio test instead of the reference's ORB + Hamming + tolerance vote
+    // (slideo_matcher_use_sift); 0 (default) = the reference's
+    HipImageVideoMatcher& with_sift(float ratio) { sift_ratio_ = ratio; return *this; }
     template <class I>
     std::unique_ptr<VideoMatcher<I>> create_video_matcher(std::vector<I> images, ProgressReporter reporter) const {
         auto h = std::make_shared<detail::Handle>();
         int32_t rc = slideo_matcher_create(&cfg_, device_, &h->m);
         if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_last_error(nullptr));
+        if (sift_ratio_ > 0.f) {                                                                    // the north-star's SIFT + L2 + ratio-test front end
+            slideo_sift_config sc;
+            slideo_sift_config_default(&sc);
+            h->check(slideo_matcher_use_sift(h->m, &sc, sift_ratio_));
+        }
         h->check(slideo_matcher_set_progress(h->m, detail::tramp, &reporter));                       // "Analyzing PDF pages..." protocol, mo/lib.rs:43-58
         const size_t CH = 32;
         for (size_t i = 0; i < images.size(); i += CH) {
@@ -305,6 +313,7 @@ public:
     }
 private:
     int device_;
+    float sift_ratio_ = 0.f;
     slideo_config cfg_;
     ImageLoader loader_;
 };
