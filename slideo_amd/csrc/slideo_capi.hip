@@ -1673,24 +1673,31 @@ void l2_prepare(slideo_matcher::L2Set& L, const uint8_t* t, int nt, hipStream_t 
 }
 
 // queries on the device -> idx / dist on the device (m->d_tapidx / d_tapdist); kernel time between two events if asked for
-void l2_query(slideo_matcher* m, slideo_matcher::L2Set& L, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed) {
+// keys / pend: the list and pending-key buffers of this search — the set's own by default (results then unpacked into
+// m->d_tapidx / d_tapdist), a slot's in SIFT matcher mode (the lists are consumed as they are: no unpack)
+void l2_query(slideo_matcher* m, slideo_matcher::L2Set& L, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed,
+              DevBuf* keys = nullptr, DevBuf* pend = nullptr) {
     const int qblocks = cdiv(nq, knn_qpb<2>());
-    L.d_keys.reserve((size_t)nq * KLIST * 8); L.d_pend.reserve((size_t)qblocks * KT_WAVES * knn_pend_words_per_wave<2>() * 8);   // (u64 keys)
-    m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4);
+    const bool own = keys == nullptr;
+    if (own) { keys = &L.d_keys; pend = &L.d_pend; }
+    keys->reserve((size_t)nq * KLIST * 8); pend->reserve((size_t)qblocks * KT_WAVES * knn_pend_words_per_wave<2>() * 8);   // (u64 keys)
+    if (own) { m->d_tapidx.reserve((size_t)nq * k * 4); m->d_tapdist.reserve((size_t)nq * k * 4); }
     if (timed) HIP_CHECK(hipEventRecord(S.ev[0], st));
     const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
         knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                          L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+                                                          keys->as<unsigned long long>(), pend->as<unsigned long long>());
     else if (kl == 16)
         knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                           L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+                                                           keys->as<unsigned long long>(), pend->as<unsigned long long>());
     else
         knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                              L.d_keys.as<unsigned long long>(), L.d_pend.as<unsigned long long>());
+                                                              keys->as<unsigned long long>(), pend->as<unsigned long long>());
     check_launch("knn_l2_kernel");
-    knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(L.d_keys.as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
-    check_launch("knl_unpack_kernel");
+    if (own) {
+        knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(keys->as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
+        check_launch("knl_unpack_kernel");
+    }
     if (timed) HIP_CHECK(hipEventRecord(S.ev[1], st));
 }
 
@@ -1952,9 +1959,9 @@ int64_t sift_unit_capacity(const slideo_matcher* m, int n) {
 }
 
 // slideo_matcher_use_sift: a unit = SIFT on the frames -> squared-L2 k-NN (k = 2) against the deck's SIFT rows -> ratio test as
-// Hamming-format neighbour lists (l2_ratio_keys_kernel) -> the common verify stage.  The SIFT and L2 workspaces belong to the
-// matcher, so the extraction stages of consecutive units take turns (event chain); their verify stages overlap the next
-// unit's extraction.  The keypoint counts come back to the host inside sift_batch: the submit blocks for the extraction.
+// Hamming-format neighbour lists (l2_ratio_keys_kernel) -> the common verify stage.  The SIFT workspace belongs to the matcher,
+// so the extraction stages of consecutive units take turns (event chain); a unit's search (matrix cores, the slot's own list
+// buffers) and verify stages overlap the next unit's extraction.  The keypoint counts come back to the host inside sift_batch: the submit blocks for the extraction.
 void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride) {
     const slideo_config& c = m->cfg;
     hipStream_t st = S.st;
@@ -1995,16 +2002,17 @@ void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int
     S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
     S.h_out.reserve((size_t)n * (sizeof(slideo_verdict) + sizeof(FrameCands)) + 64);
     HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
+    HIP_CHECK(hipEventRecord(m->sift_ev, st));                               // the matcher's SIFT workspace is free again: the next unit's
+    m->sift_ev_set = true;                                                    // extraction runs beside this unit's search (matrix cores) and verify
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
-        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, 2, st, S, false);
-        l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(m->l2.d_keys.as<unsigned long long>(), 8, (int)qtot, m->sift_ratio,
+        // the search writes this SLOT's list / pending buffers (u64 keys; d_blur is unused in this mode)
+        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, 2, st, S, false, &S.d_blur, &S.d_knn_pend);
+        l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(S.d_blur.as<unsigned long long>(), 8, (int)qtot, m->sift_ratio,
                                                                   S.d_keys.as<uint32_t>(), KLIST);
         check_launch("l2_ratio_keys_kernel");
     }
     if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
-    HIP_CHECK(hipEventRecord(m->sift_ev, st));                               // the matcher's SIFT / L2 workspaces are free again
-    m->sift_ev_set = true;
     VerifyParams vp = make_vp(c);
     vp.rng_len = m->rng_len;
     vp.k = 2; vp.ratio = 1.f;                                                 // (the lists carry the test's outcome: l2_ratio_keys_kernel)
