@@ -76,7 +76,15 @@ def test_sift_matcher_state_and_limits(capi, synth):
     m.add_pages(list(pages))
     m.finalize()
     assert m.descriptor_count > 0
-    frames, _, _ = synth.frames(pages, 2, 640, 360, seed=9)
+    frames, _, _ = synth.frames(pages, 4, 640, 360, seed=9)
     v = m.match_frames(frames)
-    assert len(v) == 2
+    assert len(v) == 4
+    # the changed-mask call's upload matched in place (kept frames) gives the same verdicts
+    changed, _, _ = m.changed_mask(frames, None)
+    sel = np.array([3, 0, 2], np.int32)
+    assert np.array_equal(m.match_kept_frames(sel), v[sel])
+    with pytest.raises(capi.SlideoError) as e:                     # the 32-byte page-feature import is ORB's
+        m2 = capi.Matcher(small_cfg(capi)); m2.use_sift(capi.sift_config(), 0.75)
+        m2.add_page_features(640, 360, np.zeros(0, capi.KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((259, 461, 3), np.uint8))
+    assert e.value.code == 5
     m.close()
