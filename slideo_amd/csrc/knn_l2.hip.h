@@ -79,8 +79,13 @@ __device__ __forceinline__ void knl_insert(unsigned long long (&lst)[KL], unsign
 // q: [nq][128] u8; tx: expanded train; side: [n_st][KT_SIDE_U32] (negated norms as i32 | original rows, pad rows -2^30 / -1);
 // tile_norms: [n_st] int4 = the negated norm of the first (smallest-norm) row of each of the super-tile's 4 tiles;
 // out: [nq][KL] u64 keys.  Grid ceil(nq / 512), block 512.
+// (the k <= 32 instance spills 72 registers in its flush at 4 waves per SIMD; at 2 — -DKNL_K32_WAVES=2: 166 registers, no scratch — the
+// launch is 13 % SLOWER, 23.8 against 21.1 ms at the headline pair count: the spill is the cheaper of the two)
+#ifndef KNL_K32_WAVES
+#define KNL_K32_WAVES 4
+#endif
 template <int KL>
-__global__ __launch_bounds__(KT_THREADS, 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
+__global__ __launch_bounds__(KT_THREADS, KL == 32 ? KNL_K32_WAVES : 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
                                                                const uint32_t* __restrict__ side, const uint4* __restrict__ tile_norms,
                                                                int nt_pad, unsigned long long* __restrict__ out,
                                                                unsigned long long* __restrict__ pend_ws) {
