@@ -125,3 +125,35 @@ def test_sift_random_sizes_contents_configs(capi, oracle, synth, seed):
         assert len(gk) == len(ok), (w, h, sc)
         assert np.array_equal(gk, ok.view(gk.dtype)) and np.array_equal(gd, od), (w, h, sc)
     m.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_sift_matcher_random_decks(capi, oracle, synth, seed):
+    """The SIFT matcher mode (slideo_matcher_use_sift) over random deck / frame sizes, SIFT parameters, ratios and both
+    verifiers: page features bit-exact, traces against the oracle in the same mode."""
+    from test_gpu_sift_matcher import _build
+    rng = np.random.default_rng(5000 + seed)
+    pw, ph = int(rng.integers(600, 1000)), int(rng.integers(360, 640))
+    fw, fh = int(rng.integers(480, 900)), int(rng.integers(300, 560))
+    fh = max(fh, 120000 // fw + 1)
+    npages, nframes = int(rng.integers(2, 6)), int(rng.integers(2, 5))
+    pages = synth.pages(npages, pw, ph, seed=int(rng.integers(1, 1 << 30)))
+    if rng.integers(0, 2):
+        pages = np.concatenate([pages, pages[:1]])                                                  # a twin page: equal SIFT rows, d1 = d2
+    sk = dict(nfeatures=int(rng.choice([0, 150, 400])), contrast_threshold=float(rng.choice([0.04, 0.07])), sigma=float(rng.choice([1.4, 1.6])))
+    over = dict(min_rating=float(rng.choice([6.0, 12.0])))
+    homog = bool(seed % 2)
+    if homog:
+        over.update(verify_model=1, ocv_hdlt=int(rng.integers(0, 2)), ransac_max_iters=300)
+        frames, truth, _ = synth.frames_persp(pages, nframes, fw, fh, persp=0.1, seed=int(rng.integers(1, 1 << 30)))
+    else:
+        frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=int(rng.integers(1, 1 << 30)))
+    m, db = _build(capi, oracle, pages, sk, float(rng.choice([0.6, 0.75, 0.9])), **over)
+    assert m.descriptor_count == db.descriptor_count
+    if m.descriptor_count > 1:
+        gk, gd = m.page_features(0)
+        ok, od = db.page_features(0)
+        assert np.array_equal(gd, od) and np.array_equal(gk, ok.view(gk.dtype))
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=homog)
+    m.close()
