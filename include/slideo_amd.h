@@ -441,8 +441,11 @@ int32_t     slideo_sift_layer_bgr8(slideo_matcher* m, const slideo_sift_config* 
  * instead of the Hamming k-NN + tolerance vote.  Everything from the per-page vote on (candidate ranking, RANSAC per
  * verify_model, rating, re-projection, verdict) and every entry point (add_pages, finalize, match_frames*, submit / collect,
  * changed mask + kept frames, the candidate trace) is the path's own.  Must be called before the first page is added; cfg as
- * for slideo_sift_bgr8 (nfeatures 0 = all keypoints), 0 < ratio <= 1.  slideo_matcher_get_page_features /
- * _add_page_features (32-byte descriptors) return SLIDEO_ERR_UNSUPPORTED in this mode; descriptor_count is the number of SIFT
+ * for slideo_sift_bgr8 (nfeatures 0 = all keypoints), 0 < ratio <= 1.  ratio == 0: no ratio test — the path's own tolerance
+ * vote (mo/lib.rs:268-282) on the knn_k nearest rows instead: a neighbour counts iff sqrt(d) < sqrt(d_best) * vote_tolerance
+ * (f32), which — unlike Lowe's test — keeps the matches whose descriptor also sits on a twin page of the same template.
+ * slideo_matcher_get_page_features (here 128 bytes per keypoint) works; slideo_matcher_
+ * add_page_features (32-byte descriptors) returns SLIDEO_ERR_UNSUPPORTED in this mode; descriptor_count is the number of SIFT
  * rows.  Parity target: the oracle's so_db_use_sift + so_match_frame. */
 int32_t     slideo_matcher_use_sift(slideo_matcher* m, const slideo_sift_config* cfg, float ratio);
 

@@ -1666,15 +1666,30 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
         const int K = (int)fr.kp.size(), M = (int)db.train_page.size();
         out.n_keypoints = K;
         if (K == 0) return;
-        std::vector<int32_t> idx((size_t)K * 2);
-        std::vector<uint32_t> d2((size_t)K * 2);
-        so_knn_l2_u8(sr.desc.data(), K, db.train128.data(), M, 2, idx.data(), d2.data());
+        const int kq = db.ratio > 0.f ? 2 : c.knn_k;
+        std::vector<int32_t> idx((size_t)K * kq);
+        std::vector<uint32_t> d2((size_t)K * kq);
+        so_knn_l2_u8(sr.desc.data(), K, db.train128.data(), M, kq, idx.data(), d2.data());
         for (int q = 0; q < K; ++q) {
-            if (idx[(size_t)q * 2] < 0 || idx[(size_t)q * 2 + 1] < 0) continue;
-            const float a = std::sqrt((float)d2[(size_t)q * 2]), b = std::sqrt((float)d2[(size_t)q * 2 + 1]);
-            if (a < db.ratio * b) {
-                const int ti = idx[(size_t)q * 2], pg = db.train_page[ti];
-                votes[pg].push_back({q, ti - db.page_ofs[pg]});
+            if (db.ratio > 0.f) {
+                if (idx[(size_t)q * 2] < 0 || idx[(size_t)q * 2 + 1] < 0) continue;
+                const float a = std::sqrt((float)d2[(size_t)q * 2]), b = std::sqrt((float)d2[(size_t)q * 2 + 1]);
+                if (a < db.ratio * b) {
+                    const int ti = idx[(size_t)q * 2], pg = db.train_page[ti];
+                    votes[pg].push_back({q, ti - db.page_ofs[pg]});
+                }
+                continue;
+            }
+            // ratio 0: the path's tolerance vote (mo/lib.rs:268-282) on the L2 distances
+            if (idx[(size_t)q * kq] < 0) continue;
+            const float lim = std::sqrt((float)d2[(size_t)q * kq]) * c.vote_tolerance;
+            for (int r = 0; r < kq; ++r) {
+                const int ti = idx[(size_t)q * kq + r];
+                if (ti < 0) break;
+                if (std::sqrt((float)d2[(size_t)q * kq + r]) < lim) {
+                    const int pg = db.train_page[ti];
+                    votes[pg].push_back({q, ti - db.page_ofs[pg]});
+                }
             }
         }
     } else {
@@ -2036,7 +2051,7 @@ void so_pagedb_destroy(so_pagedb* db) { delete db; }
 // the product's slideo_matcher_use_sift: before the first page
 int so_pagedb_use_sift(so_pagedb* db, const so_sift_config* sc, float ratio) {
     if (!db->pages.empty() || db->finalized) return 4;
-    if (sc->n_octave_layers != 3 || !(ratio > 0.f) || !(ratio <= 1.f) || db->cfg.matcher != 0) return 1;
+    if (sc->n_octave_layers != 3 || !(ratio >= 0.f) || !(ratio <= 1.f) || db->cfg.matcher != 0) return 1;
     db->sift = true; db->sc = *sc; db->ratio = ratio;
     return 0;
 }

@@ -127,4 +127,33 @@ __global__ __launch_bounds__(256) void l2_ratio_keys_kernel(const unsigned long 
     for (int i = 1; i < klist / 4; ++i) out[i] = make_uint4(KNN_EMPTY, KNN_EMPTY, KNN_EMPTY, KNN_EMPTY);
 }
 
+// SIFT matcher mode with the PATH'S OWN vote (slideo_matcher_use_sift, ratio 0): the reference's tolerance rule (mo/lib.rs:268-282: a
+// neighbour counts iff d < best * tolerance, f32, strict) on the distances BFMatcher(NORM_L2) returns, sqrt(d^2) in f32.  The
+// outcome per neighbour goes into the distance field of a Hamming-format list — entry 0: 1 if the nearest row itself passes
+// (it does unless its distance is 0: 0 < 0 is false, as in the reference), else 0; entry r: 1 if it passes, else 2 — and the
+// vote kernel's tolerance branch, run with tolerance 1.5, reproduces it: limit = field0 * 1.5, a field passes iff it is below.
+// lists: [nq][kl] u64 ascending (d^2 << 32 | row); k <= kl <= klist.   grid ceil(nq / 256).
+__global__ __launch_bounds__(256) void l2_tol_keys_kernel(const unsigned long long* __restrict__ lists, int kl, int k, int nq, float tol,
+                                                          uint32_t* __restrict__ keys, int klist) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const unsigned long long* L = lists + (size_t)q * kl;
+    uint32_t* out = keys + (size_t)q * klist;
+    const unsigned long long k0 = L[0];
+    float lim = 0.f;
+    bool p0 = false;
+    if (k0 != KNL_EMPTY) { const float d0 = sqrtf((float)(uint32_t)(k0 >> 32)); lim = d0 * tol; p0 = d0 < lim; }
+    for (int r = 0; r < klist; ++r) {
+        uint32_t o = KNN_EMPTY;
+        if (r < k && r < kl) {
+            const unsigned long long kr = L[r];
+            if (kr != KNL_EMPTY) {
+                const bool pass = p0 && sqrtf((float)(uint32_t)(kr >> 32)) < lim;
+                o = ((r == 0 ? (p0 ? 1u : 0u) : (pass ? 1u : 2u)) << KNN_KEY_SHIFT) | ((uint32_t)kr & KNN_IDX_MASK);
+            }
+        }
+        out[r] = o;
+    }
+}
+
 }  // namespace slideo

@@ -1993,10 +1993,12 @@ void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int
     HIP_CHECK(hipMemcpyAsync(S.d_qofs.p, hq, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_info.p, hq + n + 1, 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(S.d_flags.p, 0, 16, st));
+    const bool lowe = m->sift_ratio > 0.f;                                   // ratio test (k = 2) or the path's tolerance vote (k = knn_k)
+    const int kq = lowe ? 2 : c.knn_k;
     S.d_keys.reserve(std::max<size_t>((size_t)qtot * KLIST * 4, 64));
-    S.d_votes.reserve(std::max<size_t>((size_t)qtot * 2 * sizeof(uint2), 16));
-    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * 2 * sizeof(float4), 16));
-    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * 2, 16));
+    S.d_votes.reserve(std::max<size_t>((size_t)qtot * kq * sizeof(uint2), 16));
+    S.d_gpts.reserve(std::max<size_t>((size_t)qtot * kq * sizeof(float4), 16));
+    S.d_gmask.reserve(std::max<size_t>((size_t)qtot * kq, 16));
     S.d_fcs.reserve((size_t)n * sizeof(FrameCands));
     S.d_verdicts.reserve((size_t)n * sizeof(slideo_verdict));
     S.d_pairs.reserve((size_t)n * MAXR * sizeof(PairDesc) + 64);
@@ -2007,15 +2009,22 @@ void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
         // the search writes this SLOT's list / pending buffers (u64 keys; d_blur is unused in this mode)
-        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, 2, st, S, false, &S.d_blur, &S.d_knn_pend);
-        l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(S.d_blur.as<unsigned long long>(), 8, (int)qtot, m->sift_ratio,
-                                                                  S.d_keys.as<uint32_t>(), KLIST);
-        check_launch("l2_ratio_keys_kernel");
+        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, kq, st, S, false, &S.d_blur, &S.d_knn_pend);
+        const int kl = kq <= 8 ? 8 : (kq <= 16 ? 16 : KLIST);                 // (the list length of the instance l2_query picked)
+        if (lowe)
+            l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(S.d_blur.as<unsigned long long>(), kl, (int)qtot, m->sift_ratio,
+                                                                      S.d_keys.as<uint32_t>(), KLIST);
+        else
+            l2_tol_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(S.d_blur.as<unsigned long long>(), kl, kq, (int)qtot, c.vote_tolerance,
+                                                                    S.d_keys.as<uint32_t>(), KLIST);
+        check_launch("l2 keys kernel");
     }
     if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));
     VerifyParams vp = make_vp(c);
     vp.rng_len = m->rng_len;
-    vp.k = 2; vp.ratio = 1.f;                                                 // (the lists carry the test's outcome: l2_ratio_keys_kernel)
+    // (the lists carry the outcome of the vote rule: l2_ratio_keys_kernel / l2_tol_keys_kernel)
+    if (lowe) { vp.k = 2; vp.ratio = 1.f; }
+    else { vp.k = kq; vp.ratio = 0.f; vp.tol = 1.5f; }
     unit_verify(m, S, vp, frames_dev, n, w, h, stride, frame_stride, qtot);
 }
 
@@ -2051,7 +2060,7 @@ int32_t slideo_matcher_use_sift(slideo_matcher* m, const slideo_sift_config* cfg
     API_TRY
     if (!m->pages.empty() || m->finalized) fail(SLIDEO_ERR_STATE, "slideo_matcher_use_sift must precede the first page");
     sift_check_cfg(cfg, 64, 64);
-    if (!(ratio > 0.f) || !(ratio <= 1.f)) fail(SLIDEO_ERR_INVALID_ARG, "ratio must be in (0, 1]");
+    if (!(ratio >= 0.f) || !(ratio <= 1.f)) fail(SLIDEO_ERR_INVALID_ARG, "ratio must be in [0, 1] (0 = the path's tolerance vote)");
     if (m->cfg.matcher != 0) fail(SLIDEO_ERR_UNSUPPORTED, "the LSH index is a Hamming index: not with SIFT features");
     m->sift_on = true; m->sift_cfg = *cfg; m->sift_ratio = ratio;
     API_CATCH(m)

@@ -148,7 +148,10 @@ def test_sift_matcher_random_decks(capi, oracle, synth, seed):
         frames, truth, _ = synth.frames_persp(pages, nframes, fw, fh, persp=0.1, seed=int(rng.integers(1, 1 << 30)))
     else:
         frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=int(rng.integers(1, 1 << 30)))
-    m, db = _build(capi, oracle, pages, sk, float(rng.choice([0.6, 0.75, 0.9])), **over)
+    ratio = float(rng.choice([0.0, 0.6, 0.75, 0.9]))                                                 # 0: the tolerance vote on L2 distances
+    if ratio == 0.0:
+        over.update(knn_k=int(rng.choice([5, 30, 32])), vote_tolerance=float(rng.choice([1.0, 1.05, 1.2])))
+    m, db = _build(capi, oracle, pages, sk, ratio, **over)
     assert m.descriptor_count == db.descriptor_count
     if m.descriptor_count > 1:
         gk, gd = m.page_features(0)

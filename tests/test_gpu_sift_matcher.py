@@ -43,7 +43,7 @@ def test_sift_matcher_end_to_end_cfg0(capi, oracle, cfg0_data):
     m.close()
 
 
-@pytest.mark.parametrize("mode", ["similarity", "homography", "all_keypoints"])
+@pytest.mark.parametrize("mode", ["similarity", "homography", "all_keypoints", "tolerance_vote"])
 def test_sift_matcher_modes(capi, oracle, synth, mode):
     pages = synth.pages(6, 800, 450, seed=11)
     over, sk, ratio = {}, dict(nfeatures=300), 0.8
@@ -54,6 +54,10 @@ def test_sift_matcher_modes(capi, oracle, synth, mode):
         frames, truth, _ = synth.frames(pages, 5, 640, 360, seed=5)
     if mode == "all_keypoints":
         sk, ratio = dict(nfeatures=0, contrast_threshold=0.06), 0.7
+    if mode == "tolerance_vote":                                   # ratio 0: the path's own vote rule on the L2 distances, knn_k rows
+        ratio = 0.0
+        pages = np.concatenate([pages, pages[:2]])                 # twin pages: Lowe's test would drop their matches
+        over = dict(knn_k=30, vote_tolerance=1.05)
     m, db = _build(capi, oracle, pages, sk, ratio, **over)
     assert m.descriptor_count == db.descriptor_count > 0
     v = m.match_frames(frames)

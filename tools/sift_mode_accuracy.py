@@ -7,7 +7,7 @@ P, B = 500, 256
 pages = synth.pages(P, 2001, 1125, threads=64)
 frames, truth, _ = synth.frames(pages, B, 1920, 1080, threads=64)
 d = torch.from_numpy(frames).cuda()
-for ratio in (0.75, 0.85):
+for ratio in (0.75, 0.85, 0.0):                # 0.0 = the path's tolerance vote on the L2 distances (knn_k = 30)
     for mr in (50.0, 25.0, 12.0):
         m = _capi.Matcher(_capi.default_config(min_rating=mr))
         m.use_sift(_capi.sift_config(nfeatures=1000), ratio)
