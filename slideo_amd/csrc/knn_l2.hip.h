@@ -88,8 +88,9 @@ template <int KL>
 __global__ __launch_bounds__(KT_THREADS, KL == 32 ? KNL_K32_WAVES : 4) void knn_l2_kernel(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
                                                                const uint32_t* __restrict__ side, const uint4* __restrict__ tile_norms,
                                                                int nt_pad, unsigned long long* __restrict__ out,
-                                                               unsigned long long* __restrict__ pend_ws) {
-    knn_tile_body<2, KtL2<KL>>(q, nq, tx, side, tile_norms, nt_pad, nt_pad / KT_ST_ROWS, out, pend_ws, 0.f, nullptr);
+                                                               unsigned long long* __restrict__ pend_ws, float prune_tol) {
+    // prune_tol: 0 = exact lists; > 0 = exact only for the neighbours that can pass sqrt(d) < sqrt(best) * tol (knl_prune_bound)
+    knn_tile_body<2, KtL2<KL>>(q, nq, tx, side, tile_norms, nt_pad, nt_pad / KT_ST_ROWS, out, pend_ws, prune_tol, nullptr);
 }
 
 // keys [nq][kl] u64 -> idx [nq][k] (-1 = none), dist [nq][k] (squared L2)

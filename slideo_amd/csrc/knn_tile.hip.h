@@ -135,6 +135,15 @@ struct KtHammingLsh : KtHamming {
     }
 };
 
+// Fused vote filter of the L2 engine (SIFT matcher mode with the tolerance vote): a neighbour can only count if
+// sqrtf(d^2) < sqrtf(best^2) * tol in f32 with the query's FINAL best, which is at most the best seen so far — so
+// d^2 <= best^2 tol^2 (1 + 1e-5) + 1 is necessary (the slack covers the f32 roundings of the two roots and the product many
+// times over; d^2 < 2^23.1, exact in f32's integer range after the ceil).  tol < 1 keeps everything up to the best itself.
+__device__ __forceinline__ int knl_prune_bound(int best_d2, float tol) {
+    const float t = fmaxf(tol, 1.f);
+    return (int)fminf(ceilf((float)best_d2 * t * t * 1.00001f) + 1.f, 1.0e9f);
+}
+
 template <int KL_>
 struct KtL2 {
     typedef knl_v16i Acc; typedef knl_v4i Bop; typedef unsigned long long Key; typedef int Thr;
@@ -299,7 +308,8 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                 h[B] = (nq_of(B) - __shfl(bnd, 32 + ql) - 1.f) * 0.5f;
             } else {
                 // thr = |q'|^2 - (k-th d^2) of the query this lane owns (tile A for the lower half-wave, B for the upper)
-                const int t = lst[KL - 1] == KNL_EMPTY ? KNL_THR_OPEN : nq_of(half ? B : A) - (int)(lst[KL - 1] >> 32);
+                int t = lst[KL - 1] == KNL_EMPTY ? KNL_THR_OPEN : nq_of(half ? B : A) - (int)(lst[KL - 1] >> 32);
+                if (prune_tol > 0.f && lst[0] != KNL_EMPTY) t = max(t, nq_of(half ? B : A) - knl_prune_bound((int)(lst[0] >> 32), prune_tol));
                 h[A] = __shfl(t, ql);
                 h[B] = __shfl(t, 32 + ql);
             }
@@ -365,7 +375,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     // qualifies, so every test is a wave-uniform "nobody" branch that falls through.  Register r of a lane is row
     // (r & 3) + 8 (r >> 2) + 4 half of the tile.
     auto candidates = [&](const Acc& acc, int thri, const uint32_t* sd, int tt, Thr& hh, int qt, Key* P) {
-        float dbest = 1024.f;
+        float dbest = M::hamming ? 1024.f : 2.0e9f;
         const Thr nq_i = nq_of(qt);
         uint32_t c = cnt_of(cntp, qt);
 #pragma unroll
@@ -405,12 +415,20 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                         if (hit) {
                             P[c * 64 + lane] = ((Key)(uint32_t)(nq_i - sc) << 32) | (Key)sd[KT_ST_ROWS + ro];
                             ++c;
+                            dbest = fminf(dbest, (float)(nq_i - sc));      // (d^2 < 2^24: exact)
                         }
                     }
                 }
             }
         }
         cntp = (cntp & ~(255u << (8 * qt))) | (c << (8 * qt));
+        if constexpr (!M::hamming) {
+            if (prune_tol > 0.f) {                                       // (the same, for the L2 engine: knl_prune_bound)
+                int bn = dbest < 1.0e9f ? knl_prune_bound((int)dbest, prune_tol) : 0x3FFFFFFF;
+                bn = min(bn, __shfl_xor(bn, 32));
+                if (bn < 0x3FFFFFFF) hh = max(hh, (Thr)(nq_i - bn));
+            }
+        }
         if constexpr (M::hamming) {
             if (prune_tol > 0.f) {
                 // Fused vote filter, applied at once instead of at the next flush: every distance seen so far bounds the

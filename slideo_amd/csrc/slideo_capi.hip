@@ -1676,7 +1676,7 @@ void l2_prepare(slideo_matcher::L2Set& L, const uint8_t* t, int nt, hipStream_t 
 // keys / pend: the list and pending-key buffers of this search — the set's own by default (results then unpacked into
 // m->d_tapidx / d_tapdist), a slot's in SIFT matcher mode (the lists are consumed as they are: no unpack)
 void l2_query(slideo_matcher* m, slideo_matcher::L2Set& L, const uint8_t* q_dev, int nq, int k, hipStream_t st, Slot& S, bool timed,
-              DevBuf* keys = nullptr, DevBuf* pend = nullptr) {
+              DevBuf* keys = nullptr, DevBuf* pend = nullptr, float prune_tol = 0.f) {
     const int qblocks = cdiv(nq, knn_qpb<2>());
     const bool own = keys == nullptr;
     if (own) { keys = &L.d_keys; pend = &L.d_pend; }
@@ -1686,13 +1686,13 @@ void l2_query(slideo_matcher* m, slideo_matcher::L2Set& L, const uint8_t* q_dev,
     const int kl = k <= 8 ? 8 : (k <= 16 ? 16 : KLIST);      // list length of the kernel instance (see knn_l2.hip.h)
     if (kl == 8)
         knn_l2_kernel<8><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                          keys->as<unsigned long long>(), pend->as<unsigned long long>());
+                                                          keys->as<unsigned long long>(), pend->as<unsigned long long>(), prune_tol);
     else if (kl == 16)
         knn_l2_kernel<16><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                           keys->as<unsigned long long>(), pend->as<unsigned long long>());
+                                                           keys->as<unsigned long long>(), pend->as<unsigned long long>(), prune_tol);
     else
         knn_l2_kernel<KLIST><<<qblocks, KT_THREADS, 0, st>>>(q_dev, nq, L.d_tx.as<uint4>(), L.d_side.as<uint32_t>(), L.d_tn.as<uint4>(), L.nt_pad,
-                                                              keys->as<unsigned long long>(), pend->as<unsigned long long>());
+                                                              keys->as<unsigned long long>(), pend->as<unsigned long long>(), prune_tol);
     check_launch("knn_l2_kernel");
     if (own) {
         knl_unpack_kernel<<<cdiv(nq * k, 256), 256, 0, st>>>(keys->as<unsigned long long>(), nq, kl, k, m->d_tapidx.as<int32_t>(), m->d_tapdist.as<uint32_t>());
@@ -2009,7 +2009,9 @@ void unit_submit_sift(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
     if (qtot > 0) {
         // the search writes this SLOT's list / pending buffers (u64 keys; d_blur is unused in this mode)
-        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, kq, st, S, false, &S.d_blur, &S.d_knn_pend);
+        // (tolerance vote: the search keeps its lists exact only for the rows that can pass it — the fused filter of the Hamming engine)
+        static const bool l2_prune = std::getenv("SLIDEO_L2_PRUNE") == nullptr || std::atoi(std::getenv("SLIDEO_L2_PRUNE")) != 0;
+        l2_query(m, m->l2, S.d_desc.as<uint8_t>(), (int)qtot, kq, st, S, false, &S.d_blur, &S.d_knn_pend, (!lowe && l2_prune) ? c.vote_tolerance : 0.f);
         const int kl = kq <= 8 ? 8 : (kq <= 16 ? 16 : KLIST);                 // (the list length of the instance l2_query picked)
         if (lowe)
             l2_ratio_keys_kernel<<<cdiv((int)qtot, 256), 256, 0, st>>>(S.d_blur.as<unsigned long long>(), kl, (int)qtot, m->sift_ratio,
