@@ -212,8 +212,9 @@ class Matcher:
         return int(lib().slideo_matcher_unique_descriptor_count(self._h))
 
     def use_sift(self, sift_cfg, ratio=0.75):
-        """SIFT features + squared-L2 2-NN + Lowe's ratio test in front of the path's own vote / RANSAC / re-projection stages
-        (north-star / configs[2] as a complete matcher).  Before the first page."""
+        """SIFT features + the squared-L2 search in front of the path's own vote / RANSAC / re-projection stages (north-star /
+        configs[2] as a complete matcher).  ratio in (0, 1]: Lowe's ratio test on the two nearest rows; ratio 0: the path's
+        tolerance vote on the knn_k nearest rows.  Before the first page."""
         self._check(lib().slideo_matcher_use_sift(self._h, C.byref(sift_cfg), C.c_float(ratio)))
         self._sift = True
 

@@ -27,7 +27,8 @@ rm -rf $out/stats $out/stats2 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmcov
   python bench.py --verify-model 1 --hdlt 0 --persp 0.1 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --matcher lsh --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload cfg4 --verify-model 0 --persp 0 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1
-  python bench.py --workload cfg4 --hdlt 0 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1; } > $out/bench_modes.jsonl
+  python bench.py --workload cfg4 --hdlt 0 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
+  python bench.py --workload cfg2 --sift-vote tolerance --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; } > $out/bench_modes.jsonl
 rocprofv3 --kernel-trace --stats -d $out/stats3 -o t -- python bench.py --workload cfg2 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_cfg2_under_rocprof.json 2>&1
 python profiles/summarize_rocpd.py $out/stats3/t_results.db | grep -v rocclr > $out/kernel_stats_cfg2.txt
 rocprofv3 --kernel-trace --stats -d $out/stats4 -o t -- python bench.py --verify-model 1 --hdlt 1 --persp 0.1 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $out/bench_homography_under_rocprof.json 2>&1
