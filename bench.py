@@ -230,9 +230,9 @@ def main():
     ap.add_argument("--verify-model", type=int, default=-1, choices=[-1, 0, 1],
                     help="geometric model of the verification: 0 = the reference's 4-DOF similarity (estimateAffinePartial2D), 1 = 8-DOF homography "
                          "(findHomography + warpPerspective; default: the workload's, 1 for cfg4, else 0)")
-    ap.add_argument("--hdlt", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--hdlt", type=int, default=0, choices=[0, 1, 2],
                     help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors, "
-                         "1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample)")
+                         "1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample), 2 = the closed form (square-to-quad maps; cheapest)")
     ap.add_argument("--matcher", default="exact", choices=["exact", "lsh"],
                     help="descriptor index: exact brute force (default; north_star) or the LSH candidate rule of the reference's FLANN index "
                          "(slideo_config.matcher 1: 6 tables, 12-bit keys, multi-probe 1 — recall < 1, and on these descriptors SLOWER than the exact "

@@ -124,7 +124,10 @@ typedef struct slideo_ocv_variants {
      *           Gaussian elimination with partial pivoting; point sets of more than 4 pairs (the refit over the
      *           inliers) still take form 0.  Agrees with form 0 to f64 round-off (same samples, same masks in every
      *           test) at 1 / 60 of its cost: a RANSAC iteration of form 0 is a 9x9 eigen-decomposition (~140
-     *           Jacobi rotations).  The fast choice when fidelity to cv::eigen's rounding is not the point. */
+     *           Jacobi rotations).  The fast choice when fidelity to cv::eigen's rounding is not the point.
+     *   2 [hip] minimal samples only: the same model in closed form — the projective maps of the unit square onto the two
+     *           normalised quadrilaterals (Heckbert), H = S_to * adj(S_from): ~90 multiplications and two divisions, no
+     *           pivoting; again equal to f64 round-off, and the cheapest of the three. */
     int32_t hdlt;
 } slideo_ocv_variants;
 

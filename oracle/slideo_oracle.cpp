@@ -48,7 +48,7 @@
  * recalled, pinned by hand-computable cases and numpy / SciPy cross-checks in tests/test_oracle_{homography,sift,lsh}.py):
  *   - verify_model 1: find_homography (calib3d fundam.cpp / ptsetreg.cpp / levmarq.cpp, core lapack.cpp JacobiImpl_: RANSAC
  *     with getSubset / checkSubset, normalised DLT, refit + LMSolver) and warp_perspective_nn_bgr8 (imgwarp.cpp
- *     WarpPerspectiveInvoker); ocv.hdlt 1 = the 8x8 elimination form of the 4-point model;
+ *     WarpPerspectiveInvoker); ocv.hdlt 1 = the 8x8 elimination form of the 4-point model, 2 = its closed form;
  *   - matcher 1: LshIdx, the candidate rule of FLANN's LshIndex as the reference configures it (mo/flann.rs:14-26);
  *   - sift_oracle.h: cv::SIFT::detectAndCompute (its own header lists what is restated and the two departures);
  *   - ratio_test, so_knn_l2_u8 (BFMatcher NORM_L2 on u8 descriptors).
@@ -483,7 +483,7 @@ static bool config_supported(const slideo_config& c) {
            c.ratio_test >= 0.f && !(c.ratio_test > 0.f && c.knn_k < 2) &&
            c.ocv.gray >= 0 && c.ocv.gray <= 1 && c.ocv.blur >= 0 && c.ocv.blur <= 3 && c.ocv.resize >= 0 && c.ocv.resize <= 1 &&
            c.ocv.atan >= 0 && c.ocv.atan <= 1 && c.ocv.warp >= 0 && c.ocv.warp <= 1 && c.ocv.area >= 0 && c.ocv.area <= 1 &&
-           c.ocv.lm >= 0 && c.ocv.lm <= 1 && c.ocv.hdlt >= 0 && c.ocv.hdlt <= 1 &&
+           c.ocv.lm >= 0 && c.ocv.lm <= 1 && c.ocv.hdlt >= 0 && c.ocv.hdlt <= 2 &&
            c.verify_model >= 0 && c.verify_model <= 1 && c.matcher >= 0 && c.matcher <= 1 &&
            (c.matcher == 0 || (c.lsh_tables >= 1 && c.lsh_tables <= 8 && c.lsh_key_bits >= 1 && c.lsh_key_bits <= 16 && c.lsh_multi_probe >= 0 &&
                                c.lsh_multi_probe <= 2 && !(c.ratio_test > 0.f)));
@@ -1125,6 +1125,58 @@ static int homography_4pt_direct(const P2f* M, const P2f* m, double H[9]) {
     return 1;
 }
 
+// ocv.hdlt 2: the same normalisation, then the 4-point model in CLOSED FORM — the projective map of the unit square onto each
+// normalised quadrilateral (Heckbert 1989), H = S_to * adj(S_from): ~90 multiplications, 2 divisions, no pivoting and no
+// iteration.  Exact for 4 pairs like the other two forms (equal to f64 round-off); every product and sum below is evaluated in
+// the order written (the HIP twin, csrc/homography.hip.h dlt4_closed, is this code).  A quadrilateral whose points 1, 2, 3 are
+// collinear has no such map: no model (checkSubset has removed those samples already).
+static bool square_to_quad(const double* x, const double* y, double* S) {
+    const double dx1 = x[1] - x[2], dx2 = x[3] - x[2], dx3 = x[0] - x[1] + x[2] - x[3];
+    const double dy1 = y[1] - y[2], dy2 = y[3] - y[2], dy3 = y[0] - y[1] + y[2] - y[3];
+    const double det = dx1 * dy2 - dx2 * dy1;
+    if (det == 0.0) return false;
+    const double g = (dx3 * dy2 - dx2 * dy3) / det, hh = (dx1 * dy3 - dx3 * dy1) / det;
+    S[0] = x[1] - x[0] + g * x[1]; S[1] = x[3] - x[0] + hh * x[3]; S[2] = x[0];
+    S[3] = y[1] - y[0] + g * y[1]; S[4] = y[3] - y[0] + hh * y[3]; S[5] = y[0];
+    S[6] = g; S[7] = hh; S[8] = 1.0;
+    return true;
+}
+static int homography_4pt_closed(const P2f* M, const P2f* m, double H[9]) {
+    const int count = 4;
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; ++i) { cmx += m[i].x; cmy += m[i].y; cMx += M[i].x; cMy += M[i].y; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; ++i) {
+        smx += std::fabs(m[i].x - cmx); smy += std::fabs(m[i].y - cmy);
+        sMx += std::fabs(M[i].x - cMx); sMy += std::fabs(M[i].y - cMy);
+    }
+    if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double fx[4], fy[4], tx[4], ty[4];
+    for (int i = 0; i < 4; ++i) {
+        tx[i] = (m[i].x - cmx) * smx; ty[i] = (m[i].y - cmy) * smy;
+        fx[i] = (M[i].x - cMx) * sMx; fy[i] = (M[i].y - cMy) * sMy;
+    }
+    double A[9], B[9];
+    if (!square_to_quad(fx, fy, A) || !square_to_quad(tx, ty, B)) return 0;
+    // adj(A)
+    const double J[9] = {A[4] * A[8] - A[5] * A[7], A[2] * A[7] - A[1] * A[8], A[1] * A[5] - A[2] * A[4],
+                         A[5] * A[6] - A[3] * A[8], A[0] * A[8] - A[2] * A[6], A[2] * A[3] - A[0] * A[5],
+                         A[3] * A[7] - A[4] * A[6], A[1] * A[6] - A[0] * A[7], A[0] * A[4] - A[1] * A[3]};
+    double h[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c2 = 0; c2 < 3; ++c2) h[3 * r + c2] = B[3 * r] * J[c2] + B[3 * r + 1] * J[3 + c2] + B[3 * r + 2] * J[6 + c2];
+    const double ix = 1. / smx, iy = 1. / smy;
+    double T[9];
+    for (int j = 0; j < 3; ++j) { T[j] = ix * h[j] + cmx * h[6 + j]; T[3 + j] = iy * h[3 + j] + cmy * h[6 + j]; T[6 + j] = h[6 + j]; }
+    const double n2 = -cMx * sMx, n5 = -cMy * sMy;
+    double R[9];
+    for (int r = 0; r < 3; ++r) { R[3 * r] = T[3 * r] * sMx; R[3 * r + 1] = T[3 * r + 1] * sMy; R[3 * r + 2] = T[3 * r] * n2 + T[3 * r + 1] * n5 + T[3 * r + 2]; }
+    const double sc = 1. / R[8];
+    for (int j = 0; j < 9; ++j) H[j] = R[j] * sc;
+    return 1;
+}
+
 // precomp.hpp haveCollinearPoints: only the LAST point of the subset is tested against the pairs before it
 static bool have_collinear_points(const P2f* p, int count) {
     const int i = count - 1;
@@ -1269,7 +1321,7 @@ static bool find_homography(const P2f* from, const P2f* to, int count, const sli
     if (count < model_points) return false;
     bool result = false;
     if (count == model_points) {                                        // `method == 0 || npoints == 4`: the kernel alone
-        result = (c.ocv.hdlt == 1 ? homography_4pt_direct(from, to, H) : homography_dlt(from, to, count, H)) > 0;
+        result = (c.ocv.hdlt == 2 ? homography_4pt_closed(from, to, H) : c.ocv.hdlt == 1 ? homography_4pt_direct(from, to, H) : homography_dlt(from, to, count, H)) > 0;
         if (result) std::fill(mask, mask + count, (uint8_t)1);
         else std::fill(H, H + 9, 0.0);
         return result;
@@ -1301,7 +1353,7 @@ static bool find_homography(const P2f* from, const P2f* to, int count, const sli
             break;
         }
         int rot = 0;
-        int nmodels = c.ocv.hdlt == 1 ? homography_4pt_direct(f, t, Hi) : homography_dlt(f, t, model_points, Hi, &rot);
+        int nmodels = c.ocv.hdlt == 2 ? homography_4pt_closed(f, t, Hi) : c.ocv.hdlt == 1 ? homography_4pt_direct(f, t, Hi) : homography_dlt(f, t, model_points, Hi, &rot);
         if (st) st->rotations += rot;
         if (nmodels <= 0) continue;
         int good = homography_find_inliers(from, to, count, Hi, thr2, cur.data());
@@ -1983,6 +2035,7 @@ int so_find_homography(const float* from_xy, const float* to_xy, int n, const sl
 }
 int so_homography_dlt(const float* from_xy, const float* to_xy, int n, double* H9, int variant) {
     if (variant == 1 && n == 4) return homography_4pt_direct((const P2f*)from_xy, (const P2f*)to_xy, H9);
+    if (variant == 2 && n == 4) return homography_4pt_closed((const P2f*)from_xy, (const P2f*)to_xy, H9);
     return homography_dlt((const P2f*)from_xy, (const P2f*)to_xy, n, H9);
 }
 int so_homography_check_subset(const float* from_xy, const float* to_xy, int n) {

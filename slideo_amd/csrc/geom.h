@@ -204,7 +204,7 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (o.area < 0 || o.area > 1) { *why = "ocv.area must be 0 or 1"; return false; }
     if (o.warp != 0) { *why = "ocv.warp: only 0 (10-bit fixed point) is implemented on the GPU; the CPU restatement has 1"; return false; }
     if (o.lm != 0) { *why = "ocv.lm: only 0 (Gaussian elimination) is implemented on the GPU; the CPU restatement has 1"; return false; }
-    if (o.hdlt < 0 || o.hdlt > 1) { *why = "ocv.hdlt must be 0 or 1"; return false; }
+    if (o.hdlt < 0 || o.hdlt > 2) { *why = "ocv.hdlt must be 0, 1 or 2"; return false; }
     if (c.verify_model < 0 || c.verify_model > 1) { *why = "verify_model must be 0 (similarity) or 1 (homography)"; return false; }
     if (c.matcher < 0 || c.matcher > 1) { *why = "matcher must be 0 (exact) or 1 (LSH-compatible)"; return false; }
     if (c.matcher == 1 && (c.lsh_tables < 1 || c.lsh_tables > 8 || c.lsh_key_bits < 1 || c.lsh_key_bits > 16 || c.lsh_multi_probe < 0 || c.lsh_multi_probe > 2)) {

@@ -333,6 +333,43 @@ __device__ __forceinline__ int dlt4_direct(const float4 (&p)[4], bool active, do
     return ok ? 1 : 0;
 }
 
+// ocv.hdlt 2 — the 4-point model in closed form (the oracle's homography_4pt_closed / square_to_quad, operation for operation):
+// the projective maps of the unit square onto the two normalised quadrilaterals, H = S_to * adj(S_from).  ~150 f64 instructions
+// and two divisions per sample against ~2.4 k for the elimination and ~140 k for the Jacobi sweep, and a few dozen registers.
+__device__ __forceinline__ bool square_to_quad(const double (&x)[4], const double (&y)[4], double (&S)[9]) {
+    const double dx1 = x[1] - x[2], dx2 = x[3] - x[2], dx3 = x[0] - x[1] + x[2] - x[3];
+    const double dy1 = y[1] - y[2], dy2 = y[3] - y[2], dy3 = y[0] - y[1] + y[2] - y[3];
+    const double det = dx1 * dy2 - dx2 * dy1;
+    const double g = (dx3 * dy2 - dx2 * dy3) / det, hh = (dx1 * dy3 - dx3 * dy1) / det;
+    S[0] = x[1] - x[0] + g * x[1]; S[1] = x[3] - x[0] + hh * x[3]; S[2] = x[0];
+    S[3] = y[1] - y[0] + g * y[1]; S[4] = y[3] - y[0] + hh * y[3]; S[5] = y[0];
+    S[6] = g; S[7] = hh; S[8] = 1.0;
+    return det != 0.0;
+}
+__device__ __forceinline__ int dlt4_closed(const float4 (&p)[4], bool active, double (&H)[9]) {
+    HNorm n{};
+    bool ok = norm4(p, n) && active;
+    double fx[4], fy[4], tx[4], ty[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tx[i] = (p[i].z - n.cmx) * n.smx; ty[i] = (p[i].w - n.cmy) * n.smy;
+        fx[i] = (p[i].x - n.cMx) * n.sMx; fy[i] = (p[i].y - n.cMy) * n.sMy;
+    }
+    double A[9], B[9];
+    ok = square_to_quad(fx, fy, A) && ok;
+    ok = square_to_quad(tx, ty, B) && ok;
+    const double J[9] = {A[4] * A[8] - A[5] * A[7], A[2] * A[7] - A[1] * A[8], A[1] * A[5] - A[2] * A[4],
+                         A[5] * A[6] - A[3] * A[8], A[0] * A[8] - A[2] * A[6], A[2] * A[3] - A[0] * A[5],
+                         A[3] * A[7] - A[4] * A[6], A[1] * A[6] - A[0] * A[7], A[0] * A[4] - A[1] * A[3]};
+    double h[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2) h[3 * r + c2] = B[3 * r] * J[c2] + B[3 * r + 1] * J[3 + c2] + B[3 * r + 2] * J[6 + c2];
+    if (ok) h_denormalise(h, n, H);
+    return ok ? 1 : 0;
+}
+
 // precomp.hpp haveCollinearPoints on 4 points (only the last point is tested against the pairs before it)
 __device__ __forceinline__ bool collinear4(float x0, float y0, float x1, float y1, float x2, float y2, float x3, float y3) {
     const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
@@ -531,7 +568,7 @@ __host__ __device__ constexpr size_t ransac_h_lds_bytes(int lds_pts, int hdlt) {
 // HDLT = slideo_ocv_variants.hdlt: how a minimal sample becomes a model.  Dynamic LDS: ransac_h_lds_bytes(LDS_PTS, HDLT).
 // Leaves per candidate: found, inliers, the RANSAC model in fc.M, the inlier mask in gmask (refine_h_kernel reads them).
 template <int LDS_PTS, int MIN_COUNT, int HDLT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1, HDLT ? 2 : 1))) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1, HDLT == 2 ? 4 : (HDLT ? 2 : 1)))) void ransac_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                       const slideo_keypoint* __restrict__ frame_kp,
                                                       const float2* __restrict__ page_xy,
                                                       const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
@@ -650,7 +687,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
             p4[2] = pts[mine ? (qs.y & 0xFFFFu) : 0]; p4[3] = pts[mine ? (qs.y >> 16) : 0];
             double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             int nmodels;
-            if constexpr (HDLT) nmodels = dlt4_direct(p4, mine, Hm);
+            if constexpr (HDLT == 2) nmodels = dlt4_closed(p4, mine, Hm);
+            else if constexpr (HDLT == 1) nmodels = dlt4_direct(p4, mine, Hm);
             else nmodels = dlt4<ST>(p4, A, V, W, mine, Hm);
             if (exact4) {
                 found = __shfl(nmodels, 0) > 0;

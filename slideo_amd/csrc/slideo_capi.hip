@@ -707,7 +707,8 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
                     m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
                 check_launch("ransac_h_kernel (large)");
             };
-            if (c.ocv.hdlt == 1) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>, 1);
+            if (c.ocv.hdlt == 2) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 2>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>, 2);
+            else if (c.ocv.hdlt == 1) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>, 1);
             else launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>, 0);
             if (c.refine_iters > 0) {
                 refine_h_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
@@ -1079,6 +1080,10 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
                                   (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 1)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 1)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 2)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 2)));
     m = mm.release();
     *out = m;
     API_CATCH(nullptr)

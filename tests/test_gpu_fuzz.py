@@ -92,7 +92,7 @@ def test_end_to_end_random_decks_extension_modes(capi, oracle, synth, seed):
     over = dict(nfeatures=int(rng.choice([300, 800, 1500])), min_rating=float(rng.choice([8.0, 20.0])))
     fseed = int(rng.integers(1, 1 << 30))
     if mode in (0, 1):
-        over.update(verify_model=1, ocv_hdlt=mode, ransac_max_iters=int(rng.choice([200, 2000])), refine_iters=int(rng.choice([0, 10])))
+        over.update(verify_model=1, ocv_hdlt=(mode if seed < 8 else 2), ransac_max_iters=int(rng.choice([200, 2000])), refine_iters=int(rng.choice([0, 10])))
         frames, truth, _ = synth.frames_persp(pages, nframes, fw, fh, persp=float(rng.choice([0.0, 0.1, 0.25])), seed=fseed)
     elif mode == 2:
         over.update(matcher=1, lsh_multi_probe=int(rng.integers(0, 3)), lsh_key_bits=int(rng.choice([8, 12, 14])), lsh_tables=int(rng.integers(1, 8)))
@@ -144,7 +144,7 @@ def test_sift_matcher_random_decks(capi, oracle, synth, seed):
     over = dict(min_rating=float(rng.choice([6.0, 12.0])))
     homog = bool(seed % 2)
     if homog:
-        over.update(verify_model=1, ocv_hdlt=int(rng.integers(0, 2)), ransac_max_iters=300)
+        over.update(verify_model=1, ocv_hdlt=int(rng.integers(0, 3)), ransac_max_iters=300)
         frames, truth, _ = synth.frames_persp(pages, nframes, fw, fh, persp=0.1, seed=int(rng.integers(1, 1 << 30)))
     else:
         frames, truth, _ = synth.frames(pages, nframes, fw, fh, seed=int(rng.integers(1, 1 << 30)))

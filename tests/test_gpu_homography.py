@@ -105,15 +105,16 @@ def test_homography_config_validation(capi):
         capi.Matcher(capi.default_config(verify_model=2))
     assert e.value.code == 5
     with pytest.raises(capi.SlideoError) as e:
-        capi.Matcher(capi.default_config(verify_model=1, ocv_hdlt=2))
+        capi.Matcher(capi.default_config(verify_model=1, ocv_hdlt=3))
     assert e.value.code == 5
 
 
-def test_direct_sample_solver_hdlt1(capi, oracle, synth, cfg0_data):
-    """ocv.hdlt 1 (8x8 elimination per minimal sample instead of the Jacobi sweep): GPU == the oracle's form 1, and the same
-    verdicts and inlier counts as the default form 0 on these inputs."""
+@pytest.mark.parametrize("hdlt", [1, 2])
+def test_direct_sample_solver_hdlt1(capi, oracle, synth, cfg0_data, hdlt):
+    """ocv.hdlt 1 / 2 (8x8 elimination / closed form per minimal sample instead of the Jacobi sweep): GPU == the oracle's same
+    form, and the same verdicts and inlier counts as the default form 0 on these inputs."""
     pages, frames, truth, _ = cfg0_data
-    kw = dict(verify_model=1, ocv_hdlt=1)
+    kw = dict(verify_model=1, ocv_hdlt=hdlt)
     m, db = _build_both(capi, oracle, small_cfg(capi, **kw), small_cfg(oracle, **kw), pages)
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v, skip_ill_conditioned=True)

@@ -37,8 +37,10 @@ def test_dlt_recovers_an_exact_homography_and_both_minimal_solvers_agree(oracle)
     assert np.abs(_project(H, src) - dst).max() < 2e-3                          # f32 input rounding only
     n0, H0 = oracle.homography_dlt(src[:4], dst[:4], 0)
     n1, H1 = oracle.homography_dlt(src[:4], dst[:4], 1)
-    assert n0 == n1 == 1
+    n2, H2 = oracle.homography_dlt(src[:4], dst[:4], 2)
+    assert n0 == n1 == n2 == 1
     assert np.allclose(H0, H1, rtol=1e-9, atol=1e-12)                            # L^T L + Jacobi vs the direct 8x8 solve
+    assert np.allclose(H0, H2, rtol=1e-9, atol=1e-12)                            # ... vs the closed form (square -> quad maps)
     assert np.abs(_project(H0, src[:4]) - dst[:4]).max() < 1e-6                  # a minimal sample is interpolated
     # no spread in one coordinate -> no model (runKernel returns 0)
     flat = src[:4].copy(); flat[:, 0] = 7.0
@@ -90,8 +92,9 @@ def test_find_homography_with_outliers(oracle):
     f4, H4, m4, _ = oracle.find_homography(src, dst, oracle.default_config(verify_model=1, ocv_lm=1))
     assert np.array_equal(m4, mask) and np.allclose(H4, H, rtol=1e-7, atol=1e-10)
     # and so do the two minimal solvers (same samples, same acceptance)
-    f5, H5, m5, st5 = oracle.find_homography(src, dst, oracle.default_config(verify_model=1, ocv_hdlt=1))
-    assert np.array_equal(m5, mask) and st5["iters"] == st["iters"] and np.allclose(H5, H, rtol=1e-7, atol=1e-10)
+    for hd in (1, 2):
+        f5, H5, m5, st5 = oracle.find_homography(src, dst, oracle.default_config(verify_model=1, ocv_hdlt=hd))
+        assert np.array_equal(m5, mask) and st5["iters"] == st["iters"] and np.allclose(H5, H, rtol=1e-7, atol=1e-10), hd
 
 
 def test_find_homography_small_counts(oracle):
