@@ -35,6 +35,8 @@ constexpr int HJ_SLICE = HJ_TRI + HJ_V + HJ_W;       // doubles per lane
 constexpr int H_WIN = 512;                  // RNG stream entries staged in LDS per sampling round
 constexpr int H_QUEUE = 128;                // valid subsets waiting for a Jacobi phase
 constexpr int H_MAX_ATTEMPTS = 10000;       // getSubset(..., maxAttempts) as RANSACPointSetRegistrator::run passes it
+constexpr int RANSAC_H_TAIL_WAVES = 8;      // waves of ransac_h_tail_kernel on one candidate's sample schedule
+constexpr int RANSAC_H_TAIL_BLOCKS = 256;   // its grid: one block per CU (111 KB of LDS), looping over the tail list
 
 __device__ __forceinline__ int tri9(int i, int j) { return ((i * (17 - i)) >> 1) + (j - i - 1); }   // i < j, upper triangle of 9x9
 __device__ __forceinline__ int tri9u(int a, int b) { return a < b ? tri9(a, b) : tri9(b, a); }
@@ -529,23 +531,36 @@ __device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], cons
 // round per attempt WITH a duplicate: fine for 2-point samples over hundreds of votes, hopeless for 4-point samples over the
 // 5..30 votes of a wrong candidate page, where most attempts have one.)  Here: the stream window is staged in LDS already
 // reduced modulo `count`; nxt[p] = where an attempt starting at window position p ends (a pure function of the window, all
-// positions in parallel); the tables J[d] = nxt^(2^d) by pointer doubling; lane j reads off start_j = nxt^j(0) from the bits
-// of j.  Six table rounds and six look-ups whatever the duplicate rate.
+// positions in parallel); the tables T[d] = nxt^(4^d) by pointer jumping, radix 4 (three gathers and a store per entry and
+// level: 16 LDS operations per entry for 512 attempts where doubling takes 24, and half the barriers); lane j reads off
+// start_j = nxt^j(0) from the base-4 digits of j.  The window holds only what the round's attempts are expected to draw
+// (h_window_len: 4.4 entries per attempt at 19 votes, 6.4 at 5 — the tables are as long as the window, and they are the work);
+// a round whose attempts do not all fit simply takes fewer of them (`na`), the sequence of attempts is the stream's either way.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int HS_END = H_WIN;                      // absorbing "beyond the window" position
 constexpr int HS_TAB = H_WIN + 8;                  // entries per table
-__host__ __device__ constexpr size_t ransac_h_samp_bytes() { return (size_t)H_WIN * 4 + 6 * (size_t)HS_TAB * 2; }
+constexpr int HS_LEVELS = 3;                       // 4^3 = 64 attempts per round
+__host__ __device__ constexpr size_t ransac_h_samp_bytes() { return (size_t)H_WIN * 4 + HS_LEVELS * (size_t)HS_TAB * 2; }
 
-// An attempt read from window position p: 4 distinct indices, `end` = the position after its last draw (HS_END if it would
-// run past the window).  win[] holds rng % count.
-__device__ __forceinline__ void read_attempt(const uint32_t* win, int p, uint32_t (&idx)[4], int& end) {
+// Window entries `attempts` attempts over `count` points are expected to consume (sum of the geometric waits for 4 distinct
+// values) + 5 % + a margin of several sigma; at most `cap`.
+__device__ __forceinline__ int h_window_len(int count, int attempts, int cap) {
+    const float c = (float)count;
+    const float mean = 1.f + c / (c - 1.f) + c / (c - 2.f) + c / (c - 3.f);
+    return min(cap, (int)((float)attempts * mean * 1.05f) + 40 + (attempts >> 4));
+}
+
+// An attempt read from window position p: 4 distinct indices, `end` = the position after its last draw (`END` if it would
+// run past the window's `lim` entries).  win[] holds rng % count.
+template <int END>
+__device__ __forceinline__ void read_attempt(const uint32_t* win, int lim, int p, uint32_t (&idx)[4], int& end) {
     int q = p;
     bool fit = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t v = 0;
         for (;;) {
-            if (q >= H_WIN) { fit = false; break; }
+            if (q >= lim) { fit = false; break; }
             v = win[q]; ++q;
             bool dup = false;
 #pragma unroll
@@ -554,7 +569,14 @@ __device__ __forceinline__ void read_attempt(const uint32_t* win, int p, uint32_
         }
         idx[i] = v;
     }
-    end = fit ? q : HS_END;
+    end = fit ? q : END;
+}
+
+// One radix-4 jump level over the window: Tn = Tp o Tp o Tp o Tp on [0, lim) and on the absorbing entry END.
+template <int END, int NT>
+__device__ __forceinline__ void h_jump4(const uint16_t* Tp, uint16_t* Tn, int lim, int tid) {
+    for (int p = tid; p <= lim; p += NT) Tn[p] = Tp[Tp[Tp[Tp[p]]]];     // (entry `lim`: where an attempt that ends with the window ends)
+    if (tid == 0) Tn[END] = (uint16_t)END;
 }
 
 // Scratch layout helper of ransac_h_kernel: jbuf (Jacobi slices; hdlt 0 only) | points | sampler tables | queue.
@@ -573,14 +595,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
                                                       const float2* __restrict__ page_xy,
                                                       const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
                                                       FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
-                                                      uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
+                                                      uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags,
+                                                      uint32_t round_cap, uint32_t* __restrict__ tail_list, uint32_t* __restrict__ tail_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
     constexpr int ST = HJ;                          // slices interleaved in jbuf (hdlt 0)
     constexpr int CH = HDLT ? 64 : HJ;              // RANSAC iterations scored per phase
     constexpr size_t REGION0 = HDLT ? ransac_h_samp_bytes() + 64 : ransac_h_jbuf_bytes(0);
     double* jbuf = reinterpret_cast<double*>(hsm);
     uint32_t* win = reinterpret_cast<uint32_t*>(hsm);                           // (aliases jbuf when HDLT == 0)
-    uint16_t* jt = reinterpret_cast<uint16_t*>(hsm + (size_t)H_WIN * 4);       // 6 tables of HS_TAB
+    uint16_t* jt = reinterpret_cast<uint16_t*>(hsm + (size_t)H_WIN * 4);       // HS_LEVELS tables of HS_TAB
     float4* lpts = reinterpret_cast<float4*>(hsm + REGION0);
     uint2* queue = reinterpret_cast<uint2*>(hsm + REGION0 + (size_t)LDS_PTS * 16);
     static_assert(ransac_h_samp_bytes() + 64 <= ransac_h_jbuf_bytes(0), "sampler tables fit in the Jacobi slices");
@@ -626,35 +649,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
         int fail_run = 0;                  // consecutive rejected attempts since the last valid subset
         bool sched_end = false;            // getSubset gave up (10000 attempts): no further iteration exists
         bool overflow = false;
+        uint32_t rounds = 0;               // sampling rounds so far (round_cap: hand the candidate to ransac_h_tail_kernel)
+        const int wlen = h_window_len(max(count, 5), 64, H_WIN);   // window entries staged per round
         if (exact4) { if (lane == 0) queue[0] = make_uint2(0u | (1u << 16), 2u | (3u << 16)); nq = 1; sched_end = true; }
         while (base < niters) {
             // ---- sampling rounds until a full phase of subsets is queued (or as many as the loop can still use) ----
             const int need = min(CH, niters - base);
             while (nq < need && !sched_end) {
                 if (pos + H_WIN + 64 > vp.rng_len) { overflow = true; break; }
-                __syncthreads();
-                for (int i = lane; i < H_WIN; i += 64) win[i] = rng_tab[pos + i] % (uint32_t)count;
-                __syncthreads();
-                uint16_t* J0 = jt;
-                for (int p = lane; p < HS_TAB; p += 64) {
-                    int end = HS_END;
-                    if (p < H_WIN) { uint32_t idx[4]; read_attempt(win, p, idx, end); }
-                    J0[p] = (uint16_t)end;
+                if (++rounds > round_cap) {
+                    // A candidate whose subsets are almost all rejected (votes that share their points) walks through 10^5 - 10^6
+                    // attempts, 64 per round: one wave for tens of milliseconds while the other 9000 candidates take 1 ms each.
+                    // It starts again in ransac_h_tail_kernel, 512 attempts per round — same stream, same result.
+                    if (lane == 0) tail_list[atomicAdd(tail_count, 1u)] = ((uint32_t)f << 6) | (uint32_t)r;
+                    return;
                 }
                 __syncthreads();
+                for (int i = lane; i < wlen; i += 64) win[i] = rng_tab[pos + i] % (uint32_t)count;
+                __syncthreads();
+                for (int p = lane; p <= wlen; p += 64) {
+                    uint32_t idx[4]; int end;
+                    read_attempt<HS_END>(win, wlen, p, idx, end);         // (p == wlen: nothing fits, HS_END)
+                    jt[p] = (uint16_t)end;
+                }
+                if (lane == 0) jt[HS_END] = (uint16_t)HS_END;
+                __syncthreads();
 #pragma unroll
-                for (int d = 1; d < 6; ++d) {
-                    const uint16_t* Jp = jt + (d - 1) * HS_TAB;
-                    uint16_t* Jn = jt + d * HS_TAB;
-                    for (int p = lane; p < HS_TAB; p += 64) Jn[p] = Jp[Jp[p]];
+                for (int d = 1; d < HS_LEVELS; ++d) {
+                    h_jump4<HS_END, 64>(jt + (d - 1) * HS_TAB, jt + d * HS_TAB, wlen, lane);
                     __syncthreads();
                 }
-                int st = 0;                                             // start of attempt `lane`
+                int st = 0;                                             // start of attempt `lane`: nxt^lane(0), by base-4 digits
 #pragma unroll
-                for (int d = 0; d < 6; ++d) if ((lane >> d) & 1) st = jt[d * HS_TAB + st];
+                for (int d = 0; d < HS_LEVELS; ++d) {
+                    const int dg = (lane >> (2 * d)) & 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) if (dg > k) st = jt[d * HS_TAB + st];
+                }
                 uint32_t idx[4] = {0, 1, 2, 3};
                 int end = HS_END;
-                if (st < H_WIN) read_attempt(win, st, idx, end);
+                if (st < wlen) read_attempt<HS_END>(win, wlen, st, idx, end);
                 const bool have = end != HS_END;                        // the attempt lies inside the window
                 const unsigned long long hb = __builtin_amdgcn_ballot_w64(have);
                 const int na = hb == ~0ull ? 64 : __builtin_ctzll(~hb); // attempts of this round (a prefix of the lanes)
@@ -755,6 +789,212 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLT ? 2 : 1
         fc.found[r] = found; fc.inliers[r] = inl;
         for (int j = 0; j < 9; ++j) fc.M[r][j] = bestH[j];
     }
+}
+
+// ransac_h_kernel for the candidates it gave up on (round_cap): the same RANSAC from the start, with the SAMPLE SCHEDULE produced
+// by NW waves — 64 NW attempts per round (radix-4 jump tables over log4(64 NW) levels) — and the model / scoring / acceptance
+// phases on wave 0 exactly as in ransac_h_kernel (64 iterations per phase).  The valid subsets are a function of the stream
+// and the points alone and are queued in stream order, so looking further ahead per round changes nothing but the time: a
+// candidate that is bound by its rejected attempts (10^5 - 10^6 of them) runs about NW times faster.
+// grid RANSAC_H_TAIL_BLOCKS (the list is taken entry by entry off flags-side counter `tail_next`), block 64 NW; HDLT 1 or 2
+// (form 0 is bound by its eigen-solver, not by the schedule).
+template <int HDLT, int NW>
+__global__ __launch_bounds__(64 * NW) void ransac_h_tail_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
+                                                                const slideo_keypoint* __restrict__ frame_kp, const float2* __restrict__ page_xy,
+                                                                const uint2* __restrict__ votes, const uint32_t* __restrict__ rng_tab,
+                                                                FrameCands* __restrict__ fcs, float4* __restrict__ gpts, uint8_t* __restrict__ gmask,
+                                                                uint32_t* __restrict__ flags, const uint32_t* __restrict__ tail_list,
+                                                                const uint32_t* __restrict__ tail_count, uint32_t* __restrict__ tail_next) {
+    static_assert(HDLT == 1 || HDLT == 2, "tail kernel: the cheap sample solvers");
+    constexpr int NT = 64 * NW, WIN = H_WIN * NW, TAB = WIN + 8, END = WIN;
+    constexpr int LV = NW == 1 ? 3 : NW <= 4 ? 4 : 5;                           // 4^LV >= NT
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "NW: a power of two up to 16");
+    constexpr int QCAP = 64 + NT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
+    uint32_t* win = reinterpret_cast<uint32_t*>(hsm);
+    uint16_t* jt = reinterpret_cast<uint16_t*>(hsm + (size_t)WIN * 4);                             // LV tables of TAB
+    float4* lpts = reinterpret_cast<float4*>(hsm + (size_t)WIN * 4 + (((size_t)LV * TAB * 2 + 15) & ~(size_t)15));
+    uint2* queue = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(lpts) + (size_t)RANSAC_LDS_PTS * 16);
+    __shared__ int s_cnt[2 * NW], s_first[NW], s_last[NW], s_end, s_ctl[4];
+    __shared__ uint32_t s_te;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ntail = *tail_count;
+    for (;;) {
+    __syncthreads();                                                            // (the previous candidate's LDS is done with)
+    if (tid == 0) s_te = atomicAdd(tail_next, 1u);
+    __syncthreads();
+    const uint32_t te = s_te;
+    if (te >= ntail) break;
+    const uint32_t tl = tail_list[te];
+    const int r = (int)(tl & 63u), f = (int)(tl >> 6);
+    FrameCands& fc = fcs[f];
+    const int count = fc.count[r];
+    const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
+    const uint2* vt = votes + vbase;
+    float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
+    uint8_t* mask = gmask + vbase;
+    const uint32_t qbase_f = qofs[f];
+    for (int i = tid; i < count; i += NT) {
+        const uint2 v = vt[i];
+        const float2 sp = page_xy[v.y];
+        const slideo_keypoint* kp = frame_kp + qbase_f + v.x;
+        pts[i] = make_float4(sp.x, sp.y, kp->x, kp->y);                         // from = slide pt, to = frame pt
+    }
+    __syncthreads();
+    const int wlen = h_window_len(max(count, 5), NT, WIN);                      // window entries staged per round
+    double bestH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                             // (wave 0)
+    int found = 0, inl = 0;
+    const float thr2 = (float)(vp.thr * vp.thr);
+    // count >= 5 here: ransac_h_kernel never hands over the exact-4 case (no sampling rounds)
+    int niters = max(vp.max_iters, 1), max_good = 0, base = 0;
+    uint32_t pos = 0;
+    int nq = 0, fail_run = 0;
+    bool sched_end = false, overflow = false;
+    while (base < niters) {
+        const int need = min(64, niters - base);
+        while (nq < need && !sched_end) {
+            if (pos + WIN + 64 > vp.rng_len) { overflow = true; break; }
+            __syncthreads();
+            for (int i = tid; i < wlen; i += NT) win[i] = rng_tab[pos + i] % (uint32_t)count;
+            __syncthreads();
+            for (int p = tid; p <= wlen; p += NT) {
+                uint32_t idx[4]; int end;
+                read_attempt<END>(win, wlen, p, idx, end);                      // (p == wlen: nothing fits, END)
+                jt[p] = (uint16_t)end;
+            }
+            if (tid == 0) jt[END] = (uint16_t)END;
+            __syncthreads();
+#pragma unroll 1
+            for (int d = 1; d < LV; ++d) {
+                h_jump4<END, NT>(jt + (d - 1) * TAB, jt + d * TAB, wlen, tid);
+                __syncthreads();
+            }
+            int st = 0;                                                         // start of attempt `tid`: nxt^tid(0), by base-4 digits
+#pragma unroll
+            for (int d = 0; d < LV; ++d) {
+                const int dg = (tid >> (2 * d)) & 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (dg > k) st = jt[d * TAB + st];
+            }
+            uint32_t idx[4] = {0, 1, 2, 3};
+            int end = END;
+            if (st < wlen) read_attempt<END>(win, wlen, st, idx, end);
+            const bool have = end != END;                                       // the attempt lies inside the window (a prefix of the threads)
+            const unsigned long long hb = __builtin_amdgcn_ballot_w64(have);
+            if (lane == 0) s_cnt[wave] = __builtin_popcountll(hb);
+            __syncthreads();
+            int na = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) na += s_cnt[w2];
+            if (na == 0) { overflow = true; break; }
+            if (tid == na - 1) s_end = end;
+            const float4 p4[4] = {pts[idx[0]], pts[idx[1]], pts[idx[2]], pts[idx[3]]};
+            const bool valid = tid < na && check_subset4(p4);
+            const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
+            if (lane == 0) {
+                s_cnt[NW + wave] = __builtin_popcountll(vb);
+                s_first[wave] = vb ? 64 * wave + __builtin_ctzll(vb) : -1;
+                s_last[wave] = vb ? 64 * wave + 63 - __builtin_clzll(vb) : -1;
+            }
+            __syncthreads();
+            pos += (uint32_t)s_end;
+            int nvalid = 0, before = 0, first = -1, last = -1;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) {
+                if (w2 < wave) before += s_cnt[NW + w2];
+                nvalid += s_cnt[NW + w2];
+                if (first < 0) first = s_first[w2];
+                if (s_last[w2] >= 0) last = s_last[w2];
+            }
+            if (nvalid == 0) {
+                fail_run += na;
+                if (fail_run >= H_MAX_ATTEMPTS) sched_end = true;
+                continue;
+            }
+            if (fail_run + first >= H_MAX_ATTEMPTS) { sched_end = true; continue; }
+            const int rank = before + __builtin_popcountll(vb & ((1ull << lane) - 1ull));
+            if (valid && nq + rank < QCAP) queue[nq + rank] = make_uint2(idx[0] | (idx[1] << 16), idx[2] | (idx[3] << 16));
+            nq = min(nq + nvalid, QCAP);                                       // (nq < 64 on entry and <= NT arrive: never clipped)
+            fail_run = na - 1 - last;                                          // rejected attempts after the round's last valid one
+        }
+        if (overflow) break;
+        __syncthreads();
+        const int nrun = min(min(nq, 64), niters - base);                      // iterations this phase scores
+        if (nrun <= 0) break;
+        if (wave == 0) {
+            // ---- model + inlier count, one iteration per lane; sequential acceptance: ransac_h_kernel's code ----
+            const bool mine = lane < nrun;
+            const uint2 qs = queue[min(lane, QCAP - 1)];
+            float4 p4[4];
+            p4[0] = pts[mine ? (qs.x & 0xFFFFu) : 0]; p4[1] = pts[mine ? (qs.x >> 16) : 0];
+            p4[2] = pts[mine ? (qs.y & 0xFFFFu) : 0]; p4[3] = pts[mine ? (qs.y >> 16) : 0];
+            double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            int nmodels;
+            if constexpr (HDLT == 2) nmodels = dlt4_closed(p4, mine, Hm);
+            else nmodels = dlt4_direct(p4, mine, Hm);
+            int good = -1;
+            if (mine && nmodels > 0) {
+                float Hf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Hf[j] = (float)Hm[j];
+                good = 0;
+                for (int i = 0; i < count; ++i) good += (h_error(Hf, pts[i]) <= thr2) ? 1 : 0;
+            }
+            int used = nrun;
+            if (__builtin_amdgcn_ballot_w64(mine && good > max(max_good, 3)) != 0ull) {
+                for (int i = 0; i < nrun; ++i) {
+                    if (base + i >= niters) { used = i; break; }
+                    const int g = __shfl(good, i);
+                    if (g > max(max_good, 3)) {
+                        max_good = g;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) bestH[j] = __shfl(Hm[j], i);
+                        niters = ransac_update_iters4(vp.conf, (double)(count - g) / count, niters);
+                    }
+                }
+            }
+            if (lane == 0) { s_ctl[0] = max_good; s_ctl[1] = niters; s_ctl[2] = used; }
+        }
+        __syncthreads();
+        max_good = s_ctl[0]; niters = s_ctl[1]; base += s_ctl[2];
+        // drop the consumed subsets
+        uint2 keep[(QCAP + NT - 1) / NT];
+#pragma unroll
+        for (int u = 0; u < (QCAP + NT - 1) / NT; ++u) keep[u] = queue[min(tid + u * NT + nrun, QCAP - 1)];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < (QCAP + NT - 1) / NT; ++u) if (tid + u * NT + nrun < nq) queue[tid + u * NT] = keep[u];
+        nq -= nrun;
+        if (sched_end && nq == 0) break;
+    }
+    if (wave != 0) continue;
+    if (overflow) { if (lane == 0) atomicOr(flags, 4u); }
+    found = max_good > 0;
+    if (found) {
+        float Hf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Hf[j] = (float)bestH[j];
+        int c = 0;
+        for (int i = lane; i < count; i += 64) {
+            const uint8_t mk = h_error(Hf, pts[i]) <= thr2;
+            mask[i] = mk; c += mk;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        inl = c;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) bestH[j] = 0;
+    }
+    if (lane == 0) {
+        fc.found[r] = found; fc.inliers[r] = inl;
+        for (int j = 0; j < 9; ++j) fc.M[r][j] = bestH[j];
+    }
+    }
+}
+__host__ __device__ constexpr size_t ransac_h_tail_lds_bytes(int nw) {
+    const int lv = nw == 1 ? 3 : nw <= 4 ? 4 : 5;
+    return (size_t)H_WIN * nw * 4 + (((size_t)lv * (H_WIN * nw + 8) * 2 + 15) & ~(size_t)15) + (size_t)RANSAC_LDS_PTS * 16 + (size_t)(64 + 64 * nw) * 8 + 64;
 }
 
 // fundam.cpp after the RANSAC: `result && npoints > 4` — runKernel over the inliers, then LMSolver (maxIters = refine_iters)

@@ -69,7 +69,7 @@ struct Slot {
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
-    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys, d_tail;
     PinBuf h_info, h_out;
     OrbOut orb;
     // unit in flight
@@ -697,19 +697,42 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
                                          S.d_fcs.as<FrameCands>(), S.d_votes.as<uint2>());
         check_launch("vote_kernel");
         if (c.verify_model == 1) {
+            // hdlt >= 1: a candidate still sampling after `round_cap` rounds goes to ransac_h_tail_kernel (8 waves on its sample
+            // schedule).  hdlt 0 is bound by its eigen-solver, not by the schedule: no cap.  flags[1] counts the tail list, flags[2] hands it out.
+            const uint32_t tail_rounds = [] {                                 // (read per unit: the tests switch it)
+                const char* e = getenv("SLIDEO_RH_TAIL_ROUNDS");
+                const long v = e ? atol(e) : 256;
+                return (uint32_t)(v < 1 ? 0xFFFFFFFFu : v);                   // 0 / negative: never hand over
+            }();
+            const uint32_t round_cap = c.ocv.hdlt ? tail_rounds : 0xFFFFFFFFu;
+            S.d_tail.reserve((size_t)c.max_candidate_pages * n * 4 + 16);
             auto launch_h = [&](auto small_tag, auto large_tag, int hdlt) {
                 small_tag<<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_SMALL_PTS, hdlt), st>>>(
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags, round_cap,
+                    S.d_tail.as<uint32_t>(), flags + 1);
                 check_launch("ransac_h_kernel (small)");
                 large_tag<<<dim3(c.max_candidate_pages, n), 64, ransac_h_lds_bytes(RANSAC_LDS_PTS, hdlt), st>>>(
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags);
+                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags, round_cap,
+                    S.d_tail.as<uint32_t>(), flags + 1);
                 check_launch("ransac_h_kernel (large)");
             };
-            if (c.ocv.hdlt == 2) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 2>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>, 2);
-            else if (c.ocv.hdlt == 1) launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>, 1);
-            else launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>, 0);
+            auto launch_tail = [&](auto tail_tag) {
+                const int blocks = std::min(RANSAC_H_TAIL_BLOCKS, c.max_candidate_pages * n);
+                tail_tag<<<blocks, 64 * RANSAC_H_TAIL_WAVES, ransac_h_tail_lds_bytes(RANSAC_H_TAIL_WAVES), st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    m->d_rng.as<uint32_t>(), S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), flags,
+                    S.d_tail.as<uint32_t>(), flags + 1, flags + 2);
+                check_launch("ransac_h_tail_kernel");
+            };
+            if (c.ocv.hdlt == 2) {
+                launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 2>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>, 2);
+                if (round_cap != 0xFFFFFFFFu) launch_tail(&ransac_h_tail_kernel<2, RANSAC_H_TAIL_WAVES>);
+            } else if (c.ocv.hdlt == 1) {
+                launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 1>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 1>, 1);
+                if (round_cap != 0xFFFFFFFFu) launch_tail(&ransac_h_tail_kernel<1, RANSAC_H_TAIL_WAVES>);
+            } else launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>, 0);
             if (c.refine_iters > 0) {
                 refine_h_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
@@ -1084,6 +1107,10 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
                                   (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 2)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 2)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_tail_kernel<1, RANSAC_H_TAIL_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_tail_lds_bytes(RANSAC_H_TAIL_WAVES)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_tail_kernel<2, RANSAC_H_TAIL_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ransac_h_tail_lds_bytes(RANSAC_H_TAIL_WAVES)));
     m = mm.release();
     *out = m;
     API_CATCH(nullptr)

@@ -130,3 +130,34 @@ def test_direct_sample_solver_hdlt1(capi, oracle, synth, cfg0_data, hdlt):
     v0 = m0.match_frames(frames)
     assert np.array_equal(v0["page_idx"], v1["page_idx"]) and np.array_equal(v0["inliers"], v1["inliers"])
     m0.close()
+
+
+@pytest.mark.parametrize("hdlt", [1, 2])
+def test_tail_kernel_equals_single_wave(capi, oracle, synth, cfg0_data, hdlt, monkeypatch):
+    """ransac_h_tail_kernel (8 waves on the sample schedule of a candidate that ransac_h_kernel gave up on after
+    SLIDEO_RH_TAIL_ROUNDS sampling rounds): with the cap at 1 every sampled candidate goes through it, with 3 a mixture —
+    verdicts and full traces equal the single-wave kernel's (cap off) and the oracle's."""
+    pages = synth.pages(48, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    kw = dict(verify_model=1, ocv_hdlt=hdlt)
+    runs = {}
+    for cap in ("0", "1", "3"):
+        monkeypatch.setenv("SLIDEO_RH_TAIL_ROUNDS", cap)
+        m, db = _build_both(capi, oracle, small_cfg(capi, **kw), small_cfg(oracle, **kw), pages)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+        runs[cap] = (v, [np.array(m.last_candidates(i)) for i in range(len(frames))])
+        m.close()
+    for cap in ("1", "3"):
+        assert np.array_equal(runs[cap][0], runs["0"][0]), cap
+        for ca, cb in zip(runs[cap][1], runs["0"][1]):
+            assert ca.tobytes() == cb.tobytes(), "candidates (inliers, models, ratings) bit-identical to the single-wave kernel's"
+    # the perspective frames (more votes per candidate: the LDS-points instance too)
+    pages = synth.pages(4)
+    frames, truth, tH = synth.frames_persp(pages, 6, 1920, 1080, persp=0.2, first=1)
+    kw = dict(nfeatures=1000, verify_model=1, ocv_hdlt=hdlt)
+    monkeypatch.setenv("SLIDEO_RH_TAIL_ROUNDS", "1")
+    m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    m.close()
