@@ -267,6 +267,52 @@ __device__ __forceinline__ double lm_eval(const float4* pts, const uint8_t* mask
     return S;
 }
 
+// The 2-point sample schedule of one chunk of 64 iterations when some iteration redraws (ptsetreg.cpp getSubset: idx = next() %
+// count, the second index redrawn while it equals the first).  Where iteration j starts in the stream depends on the redraws of
+// every iteration before it.  The window w[0, RS_WIN) = stream % count sits in LDS; nxt[p] = where an iteration starting at p
+// ends (all p in parallel); T1 = nxt^4, T2 = nxt^16 by pointer jumping; lane j reads start_j = nxt^j(0) off the base-4 digits
+// of j (homography.hip.h's schedule, two draws instead of four).  Returns false — nothing changed — if 64 iterations do not fit
+// in the window (the caller's prefix-sum fixed point then takes the chunk); `stream` = rng_tab + pos, RS_WIN entries readable.
+constexpr int RS_WIN = 256, RS_END = RS_WIN, RS_TAB = RS_WIN + 8;
+__device__ __forceinline__ bool ransac_schedule_from_window(const uint32_t* __restrict__ stream, uint32_t count, uint32_t* win, uint16_t* jt,
+                                                            int lane, uint32_t& a, uint32_t& b, uint32_t& pos) {
+    __syncthreads();                                                    // (one wave per block: orders the LDS accesses)
+#pragma unroll
+    for (int u = 0; u < RS_WIN / 64; ++u) win[lane + 64 * u] = stream[lane + 64 * u] % count;
+    __syncthreads();
+    auto attempt = [&](int p, uint32_t& i0, uint32_t& i1) -> int {      // end position, RS_END if it leaves the window
+        if (p >= RS_WIN) return RS_END;
+        i0 = win[p];
+        int q = p + 1;
+        for (;;) {
+            if (q >= RS_WIN) return RS_END;
+            i1 = win[q];
+            if (i1 != i0) return q + 1;
+            ++q;
+        }
+    };
+    uint16_t* T0 = jt; uint16_t* T1 = jt + RS_TAB; uint16_t* T2 = jt + 2 * RS_TAB;
+    for (int p = lane; p <= RS_WIN; p += 64) { uint32_t x, y; T0[p] = (uint16_t)attempt(p, x, y); }    // (p == RS_WIN == RS_END: absorbing)
+    __syncthreads();
+    for (int p = lane; p <= RS_WIN; p += 64) T1[p] = T0[T0[T0[T0[p]]]];
+    __syncthreads();
+    for (int p = lane; p <= RS_WIN; p += 64) T2[p] = T1[T1[T1[T1[p]]]];
+    __syncthreads();
+    int st = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if ((lane & 3) > k) st = T0[st];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (((lane >> 2) & 3) > k) st = T1[st];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if ((lane >> 4) > k) st = T2[st];
+    uint32_t i0 = 0, i1 = 0;
+    const int end = attempt(st, i0, i1);
+    if (__builtin_amdgcn_ballot_w64(end == RS_END) != 0ull) return false;
+    a = i0; b = i1;
+    pos += (uint32_t)__shfl(end, 63);
+    return true;
+}
+
 // Two instances share the grid: <RANSAC_SMALL_PTS> takes the candidates with few votes (most of the <= 40 per frame;
 // 4 KB of LDS, so the register file and not LDS bounds the occupancy), <RANSAC_LDS_PTS> the rest; a block whose
 // candidate belongs to the other instance exits at once.
@@ -279,6 +325,8 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
                                                     uint8_t* __restrict__ gmask, uint32_t* __restrict__ flags) {
     __shared__ float4 lpts[LDS_PTS];
     __shared__ uint8_t lmask[LDS_PTS];
+    __shared__ uint32_t rs_win[RS_WIN];
+    __shared__ uint16_t rs_jt[3][RS_TAB];
     const int r = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     FrameCands& fc = fcs[f];
     if (r >= fc.ncand) return;
@@ -321,7 +369,11 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
             uint32_t a = rng_tab[pos + 2 * lane] % (uint32_t)count;
             uint32_t b = rng_tab[pos + 2 * lane + 1] % (uint32_t)count;
             if (__builtin_amdgcn_ballot_w64(a == b) == 0ull) pos += 128;
-            else {
+            else if (ransac_schedule_from_window(rng_tab + pos, (uint32_t)count, rs_win, &rs_jt[0][0], lane, a, b, pos)) {
+                // (some iteration redraws its second index: the 64 start positions from jump tables over an LDS window of the
+                // stream — two table levels whatever the number of redraws, which is what candidates with 3 - 20 votes need:
+                // a third of their iterations redraw)
+            } else {
                 // Some iteration redraws its second index, which shifts the stream position of every later iteration:
                 // start_{j+1} = start_j + 2 + e_j, e_j = redraws of iteration j.  Instead of replaying the 64 iterations one
                 // after the other, every lane evaluates its iteration from a guessed start (pos + 2 lane + shift) and the
