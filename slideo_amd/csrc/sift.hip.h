@@ -67,27 +67,34 @@ __device__ __forceinline__ int sift_reflect101(int p, int n) {
 // (reading the BGR frame directly cost 27 byte loads per thread: bound by the texture path at 30 us per 1080p frame).
 // The interpolation is resize(INTER_LINEAR)'s: per output coordinate (i0, i1, a0, a1) from the same expression as the oracle
 // (borders clamp to weight 1 / 0), t = g0 a0 + g1 a1 per row, then t0 b0 + t1 b1: unfused multiplies and adds.
-// grid (ceil(w / 256), h, n); the gray rows must be readable 2 bytes past column w - 1 (pitch >= w + 2 or a following row).
+// grid (ceil(w / 512), ceil(h / SIFT_BASE_ROWS), n); the gray rows must be readable 2 bytes past column w - 1 (pitch >= w + 2 or a following row).
+constexpr int SIFT_BASE_ROWS = 4;          // source rows per thread (a thread per source pixel: 8.8 M waves of 30 instructions, 2.1 TB/s)
+// One thread = source columns (i, i + 1), i even, x SIFT_BASE_ROWS source rows: one unaligned dword per gray row holds columns
+// i - 1 .. i + 2, the outputs of a doubled row leave as one 16-byte store.
 __global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restrict__ gray, int64_t gray_frame, int gp, int w, int h,
                                                         float* __restrict__ out, int64_t out_frame) {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    const int i = 2 * (blockIdx.x * 256 + threadIdx.x), j0 = blockIdx.y * SIFT_BASE_ROWS;
     if (i >= w) return;
     const int W = 2 * w;
+    const bool two = i + 1 < w;                                              // (odd w: the last thread owns one column)
     const uint8_t* img = gray + (int64_t)blockIdx.z * gray_frame;
-    const int rm = max(j - 1, 0), rp = min(j + 1, h - 1);
-    float g[3][3];
+    // gray rows j0 - 1 .. j0 + SIFT_BASE_ROWS (clamped); per row the values at columns clamp(i - 1), i, clamp(i + 1), clamp(i + 2)
+    float gr[SIFT_BASE_ROWS + 2][4];
     {
-        const int rows[3] = {rm, j, rp};
-        const int xs = max(i - 1, 0);                                       // bytes xs, xs + 1, xs + 2 = columns i - 1, i, i + 1 (i = 0: 0, 1, 2)
+        const int xs = max(i - 1, 0);                                       // bytes xs .. xs + 3 = columns i - 1 .. i + 2 (i = 0: 0 .. 3)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < SIFT_BASE_ROWS + 2; ++q) {
+            const int row = min(max(j0 - 1 + q, 0), h - 1);
             uint32_t v;
-            __builtin_memcpy(&v, img + (int64_t)rows[q] * gp + xs, 4);
-            const float b0 = (float)(v & 255u), b1 = (float)((v >> 8) & 255u), b2 = (float)((v >> 16) & 255u);
-            // columns (cm, i, cp) = (max(i - 1, 0), i, min(i + 1, w - 1))
-            g[q][0] = b0;
-            g[q][1] = i >= 1 ? b1 : b0;
-            g[q][2] = i >= 1 ? (i + 1 <= w - 1 ? b2 : b1) : (w > 1 ? b1 : b0);
+            __builtin_memcpy(&v, img + (int64_t)row * gp + xs, 4);
+            const float b0 = (float)(v & 255u), b1 = (float)((v >> 8) & 255u), b2 = (float)((v >> 16) & 255u), b3 = (float)(v >> 24);
+            const float c0 = i >= 1 ? b1 : b0;                                            // column i
+            const float c1 = i >= 1 ? b2 : b1;                                            // column i + 1 (if it exists)
+            const float c2 = i >= 1 ? b3 : b2;                                            // column i + 2 (if it exists)
+            gr[q][0] = b0;                                                                // column max(i - 1, 0)
+            gr[q][1] = c0;
+            gr[q][2] = i + 1 <= w - 1 ? c1 : c0;                                          // column min(i + 1, w - 1)
+            gr[q][3] = i + 2 <= w - 1 ? c2 : (i + 1 <= w - 1 ? c1 : c0);                  // column min(i + 2, w - 1)
         }
     }
     // (index into the 3-neighbourhood of source coordinate q around centre `ctr`: 0, 1, 2 = ctr - 1, ctr, ctr + 1 after clamping)
@@ -102,35 +109,51 @@ __global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restric
         a0 = 1.f - f; a1 = f;
     };
     auto pick = [](const float (&row)[3], int k) -> float { return k == 0 ? row[0] : (k == 1 ? row[1] : row[2]); };
-    float res[2][2];
-    if (i >= 1 && i <= w - 2 && j >= 1 && j <= h - 2) {
-        // interior: the coefficient expression gives (i - 1, i; 0.25, 0.75) for output 2i and (i, i + 1; 0.75, 0.25) for 2i + 1 —
-        // exactly (1 - 0.75 = 0.25 and 1 - 0.25 = 0.75 in f32) — and the same in y: no selection needed
-        float ta[3], tb[3];
+    float* o = out + (int64_t)blockIdx.z * out_frame + (int64_t)(2 * j0) * W + 2 * i;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { ta[q] = g[q][0] * 0.25f + g[q][1] * 0.75f; tb[q] = g[q][1] * 0.75f + g[q][2] * 0.25f; }
-        res[0][0] = ta[0] * 0.25f + ta[1] * 0.75f; res[0][1] = tb[0] * 0.25f + tb[1] * 0.75f;
-        res[1][0] = ta[1] * 0.75f + ta[2] * 0.25f; res[1][1] = tb[1] * 0.75f + tb[2] * 0.25f;
-    } else
+    for (int u = 0; u < SIFT_BASE_ROWS; ++u) {
+        const int j = j0 + u;
+        if (j >= h) break;
+        float res[2][4];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-        int ky0, ky1; float b0, b1;
-        coef(2 * j + dy, h, j, ky0, ky1, b0, b1);
+        for (int c = 0; c < 2; ++c) {                                       // source column ic = i + c: gray columns (ic - 1, ic, ic + 1) = gr[.][c .. c + 2]
+            const int ic = i + c;
+            float g[3][3];
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            int kx0, kx1; float a0, a1;
-            coef(2 * i + dx, w, i, kx0, kx1, a0, a1);
-            const float r0[3] = {g[0][0], g[1][0], g[2][0]}, r1[3] = {g[0][1], g[1][1], g[2][1]}, r2[3] = {g[0][2], g[1][2], g[2][2]};
-            // gray value at (row index ky, column index kx)
-            auto at = [&](int ky, int kx) -> float { return kx == 0 ? pick(r0, ky) : (kx == 1 ? pick(r1, ky) : pick(r2, ky)); };
-            const float t0 = at(ky0, kx0) * a0 + at(ky0, kx1) * a1;
-            const float t1 = at(ky1, kx0) * a0 + at(ky1, kx1) * a1;
-            res[dy][dx] = t0 * b0 + t1 * b1;
+            for (int q = 0; q < 3; ++q) { g[q][0] = gr[u + q][c]; g[q][1] = gr[u + q][c + 1]; g[q][2] = gr[u + q][c + 2]; }
+            if (ic >= 1 && ic <= w - 2 && j >= 1 && j <= h - 2) {
+                // interior: the coefficient expression gives (ic - 1, ic; 0.25, 0.75) for output 2 ic and (ic, ic + 1; 0.75, 0.25) for
+                // 2 ic + 1 — exactly (1 - 0.75 = 0.25 and 1 - 0.25 = 0.75 in f32) — and the same in y: no selection needed
+                float ta[3], tb[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { ta[q] = g[q][0] * 0.25f + g[q][1] * 0.75f; tb[q] = g[q][1] * 0.75f + g[q][2] * 0.25f; }
+                res[0][2 * c] = ta[0] * 0.25f + ta[1] * 0.75f; res[0][2 * c + 1] = tb[0] * 0.25f + tb[1] * 0.75f;
+                res[1][2 * c] = ta[1] * 0.75f + ta[2] * 0.25f; res[1][2 * c + 1] = tb[1] * 0.75f + tb[2] * 0.25f;
+            } else
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                int ky0, ky1; float b0, b1;
+                coef(2 * j + dy, h, j, ky0, ky1, b0, b1);
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    int kx0, kx1; float a0, a1;
+                    coef(2 * ic + dx, w, min(ic, w - 1), kx0, kx1, a0, a1);
+                    const float r0[3] = {g[0][0], g[1][0], g[2][0]}, r1[3] = {g[0][1], g[1][1], g[2][1]}, r2[3] = {g[0][2], g[1][2], g[2][2]};
+                    // gray value at (row index ky, column index kx)
+                    auto at = [&](int ky, int kx) -> float { return kx == 0 ? pick(r0, ky) : (kx == 1 ? pick(r1, ky) : pick(r2, ky)); };
+                    const float t0 = at(ky0, kx0) * a0 + at(ky0, kx1) * a1;
+                    const float t1 = at(ky1, kx0) * a0 + at(ky1, kx1) * a1;
+                    res[dy][2 * c + dx] = t0 * b0 + t1 * b1;
+                }
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float* d = o + (int64_t)(2 * u + dy) * W;
+            if (two) *reinterpret_cast<float4*>(d) = make_float4(res[dy][0], res[dy][1], res[dy][2], res[dy][3]);
+            else *reinterpret_cast<float2*>(d) = make_float2(res[dy][0], res[dy][1]);
         }
     }
-    float* o = out + (int64_t)blockIdx.z * out_frame + (int64_t)(2 * j) * W + 2 * i;
-    *reinterpret_cast<float2*>(o) = make_float2(res[0][0], res[0][1]);
-    *reinterpret_cast<float2*>(o + W) = make_float2(res[1][0], res[1][1]);
 }
 
 // grid (tiles_x * tiles_y, n), block 256.  src / dst: layer pointers of frame 0, per-frame strides in floats.
@@ -446,7 +469,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
     }
 }
 
-// dst(x, y) = src(2x, 2y).  grid (ceil(dw / 256), dh, n)
+// dst(x, y) = src(2x, 2y).  grid (ceil(dw / 256), dh, n).  (Four outputs x four rows per thread through 16-byte accesses: measured
+// 15 % slower — r03.)
 __global__ __launch_bounds__(256) void sift_half_kernel(const float* __restrict__ src, int64_t src_frame, int sw, float* __restrict__ dst,
                                                         int64_t dst_frame, int dw, int dh) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;

@@ -1887,7 +1887,7 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
         const int aligned4 = ((uintptr_t)frames_dev % 4 == 0) && (stride % 4 == 0) && (fs % 4 == 0);
         gray_kernel<<<dim3(cdiv(cdiv(w, 4), 256), h, nb), 256, 0, st>>>(frames_dev, fs, stride, W.gray.as<uint8_t>(), gframe, w, h, gp, aligned4, gc);
         check_launch("gray_kernel");
-        sift_base_kernel<<<dim3(cdiv(w, 256), h, nb), 256, 0, st>>>(W.gray.as<uint8_t>(), gframe, gp, w, h, W.base.as<float>(), base_frame);
+        sift_base_kernel<<<dim3(cdiv(w, 512), cdiv(h, SIFT_BASE_ROWS), nb), 256, 0, st>>>(W.gray.as<uint8_t>(), gframe, gp, w, h, W.base.as<float>(), base_frame);
         check_launch("sift_base_kernel");
     }
     const float sigma = (float)sc.sigma;
