@@ -999,12 +999,20 @@ __host__ __device__ constexpr size_t ransac_h_tail_lds_bytes(int nw) {
 
 // fundam.cpp after the RANSAC: `result && npoints > 4` — runKernel over the inliers, then LMSolver (maxIters = refine_iters)
 // on H[0..7]; the mask stays RANSAC's.  One wave per (candidate, frame); every sum in point order (lm8_eval); the one
-// eigenproblem and the 8x8 solves run on lane 0's slice.  grid (max_cand, B), block 64, LDS static.
+// 8x8 solves run on lane 0's slice.  grid (max_cand, B), block 64, LDS static.
+// Three launches (r03): the 9x9 eigenproblem of runKernel is ONE lane's work for ~0.5 ms — 58 % of the 8.9 s of candidate time
+// a headline unit's 9000 candidates spent in the single kernel, with 63 lanes waiting.  PHASE 0 (this kernel) normalises,
+// accumulates L^T L in point order and leaves both in a scratch record; refine_h_eigen_kernel solves 32 candidates' problems per
+// wave, a lane and an LDS slice each (ransac_h_kernel's Jacobi, unchanged); PHASE 1 (this kernel) runs the LM from the record's
+// matrix.  The arithmetic of a candidate is what the single kernel did, operation for operation.
+struct RefineRec { double H[9]; double LtL[45]; HNorm n; double ok; };      // 63 doubles per (frame, candidate)
+template <int PHASE>
 __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                       const slideo_keypoint* __restrict__ frame_kp,
                                                       const float2* __restrict__ page_xy, const uint2* __restrict__ votes,
                                                       FrameCands* __restrict__ fcs, float4* __restrict__ gpts,
-                                                      const uint8_t* __restrict__ gmask) {
+                                                      const uint8_t* __restrict__ gmask, RefineRec* __restrict__ recs,
+                                                      uint32_t* __restrict__ eig_list, uint32_t* __restrict__ eig_count) {
     __shared__ float4 lpts[RANSAC_LDS_PTS];
     __shared__ uint8_t lmask[RANSAC_LDS_PTS];
     __shared__ double jslice[HJ_SLICE];
@@ -1013,6 +1021,7 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
     if (r >= fc.ncand) return;
     const int count = fc.count[r], inl = fc.inliers[r];
     if (count <= 4 || !fc.found[r] || inl <= 0 || vp.refine_iters <= 0) return;
+    RefineRec& rec = recs[(size_t)f * gridDim.x + r];
     const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
     const uint2* vt = votes + vbase;
     float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
@@ -1027,10 +1036,12 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
     }
     __syncthreads();
     constexpr int ST = 1;
-    double* A = jslice; double* V = A + HJ_TRI; double* W = V + HJ_V;
+    [[maybe_unused]] double* A = jslice;                    // (the 8x8 solves' scratch)
     double bestH[9];
+    if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) bestH[j] = fc.M[r][j];
+        for (int j = 0; j < 9; ++j) bestH[j] = rec.ok != 0.0 ? rec.H[j] : fc.M[r][j];       // (runKernel returning 0 leaves H as RANSAC found it)
+    } else {
     // runKernel over the inliers.  All sums in point order (see lm8_eval): lanes 0..3 own the four centroid / deviation sums,
     // lanes 0..44 the 45 entries of L^T L.
     HNorm n{};
@@ -1053,7 +1064,8 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
         n.smx = __shfl(acc, 0); n.smy = __shfl(acc, 1); n.sMx = __shfl(acc, 2); n.sMy = __shfl(acc, 3);
     }
     const bool ok = !(fabs(n.smx) < DBL_EPSILON || fabs(n.smy) < DBL_EPSILON || fabs(n.sMx) < DBL_EPSILON || fabs(n.sMy) < DBL_EPSILON);
-    if (ok) {                                               // (runKernel returning 0 leaves H as RANSAC found it)
+    if (lane == 0) rec.ok = ok ? 1.0 : 0.0;
+    if (ok) {
         n.smx = cnt / n.smx; n.smy = cnt / n.smy; n.sMx = cnt / n.sMx; n.sMy = cnt / n.sMy;
         int rj = 0, rk = 0;
         { int e = min(lane, 44); while (e >= 9 - rj) { e -= 9 - rj; ++rj; } rk = rj + e; }
@@ -1067,14 +1079,10 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
             const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
             acc += sel9(Lx, rj) * sel9(Lx, rk) + sel9(Ly, rj) * sel9(Ly, rk);
         }
-        double LtL[45];
-#pragma unroll
-        for (int e = 0; e < 45; ++e) LtL[e] = __shfl(acc, e);
-        double h[9];
-        jacobi9_smallest<ST>(A, V, W, LtL, lane == 0, h);   // one problem: lane 0, the vector is exchanged
-#pragma unroll
-        for (int j = 0; j < 9; ++j) h[j] = __shfl(h[j], 0);
-        h_denormalise(h, n, bestH);
+        if (lane < 45) rec.LtL[lane] = acc;
+        if (lane == 0) { rec.n = n; eig_list[atomicAdd(eig_count, 1u)] = (uint32_t)f * gridDim.x + (uint32_t)r; }
+    }
+    return;
     }
     // LMSolverImpl::run, 8 parameters
     const double eps = (double)FLT_EPSILON;
@@ -1159,6 +1167,34 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
     if (lane == 0) {
         for (int i = 0; i < 8; ++i) fc.M[r][i] = x[i];
         fc.M[r][8] = bestH[8];
+    }
+}
+
+// The eigenproblems of refine_h_kernel<0>'s records: lane l < HJ of block b solves entry b HJ + l of the list on its LDS slice
+// (jacobi9_smallest<HJ>, the sweep ransac_h_kernel runs per sample) and leaves the denormalised matrix in the record.
+// grid ceil(candidates / HJ), block 64, dynamic LDS ransac_h_jbuf_bytes(0).
+__global__ __launch_bounds__(64) void refine_h_eigen_kernel(RefineRec* __restrict__ recs, const uint32_t* __restrict__ eig_list,
+                                                            const uint32_t* __restrict__ eig_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
+    const uint32_t total = *eig_count;
+    if (blockIdx.x * HJ >= total) return;
+    const int lane = threadIdx.x;
+    const uint32_t e = blockIdx.x * HJ + (uint32_t)lane;
+    const bool mine = lane < HJ && e < total;
+    double* A = reinterpret_cast<double*>(hsm) + (lane & (HJ - 1));
+    double* V = A + HJ_TRI * HJ;
+    double* W = V + HJ_V * HJ;
+    RefineRec& rec = recs[mine ? eig_list[e] : eig_list[blockIdx.x * HJ]];
+    double LtL[45];
+#pragma unroll
+    for (int j = 0; j < 45; ++j) LtL[j] = rec.LtL[j];
+    const HNorm n = rec.n;
+    double h[9], H[9];
+    jacobi9_smallest<HJ>(A, V, W, LtL, mine, h);
+    if (mine) {
+        h_denormalise(h, n, H);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) rec.H[j] = H[j];
     }
 }
 

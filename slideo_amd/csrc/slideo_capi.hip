@@ -69,7 +69,7 @@ struct Slot {
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
-    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys, d_tail;
+    DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys, d_tail, d_refine;
     PinBuf h_info, h_out;
     OrbOut orb;
     // unit in flight
@@ -698,7 +698,7 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
         check_launch("vote_kernel");
         if (c.verify_model == 1) {
             // hdlt >= 1: a candidate still sampling after `round_cap` rounds goes to ransac_h_tail_kernel (8 waves on its sample
-            // schedule).  hdlt 0 is bound by its eigen-solver, not by the schedule: no cap.  flags[1] counts the tail list, flags[2] hands it out.
+            // schedule).  hdlt 0 is bound by its eigen-solver, not by the schedule: no cap.  flags[1] counts the tail list, flags[2] hands it out (flags[3]: refine_h's eigenproblem list).
             const uint32_t tail_rounds = [] {                                 // (read per unit: the tests switch it)
                 const char* e = getenv("SLIDEO_RH_TAIL_ROUNDS");
                 const long v = e ? atol(e) : 256;
@@ -734,10 +734,21 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
                 if (round_cap != 0xFFFFFFFFu) launch_tail(&ransac_h_tail_kernel<1, RANSAC_H_TAIL_WAVES>);
             } else launch_h(&ransac_h_kernel<RANSAC_SMALL_PTS, 0, 0>, &ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 0>, 0);
             if (c.refine_iters > 0) {
-                refine_h_kernel<<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
+                // runKernel over the inliers: normalise + L^T L (wave per candidate), the eigenproblems 32 per wave, then the LM
+                const size_t ncand = (size_t)c.max_candidate_pages * n;
+                S.d_refine.reserve(ncand * sizeof(RefineRec) + ncand * 4 + 16);
+                RefineRec* recs = S.d_refine.as<RefineRec>();
+                uint32_t* eig_list = reinterpret_cast<uint32_t*>(S.d_refine.as<uint8_t>() + ncand * sizeof(RefineRec));
+                refine_h_kernel<0><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
-                    S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>());
-                check_launch("refine_h_kernel");
+                    S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), recs, eig_list, flags + 3);
+                check_launch("refine_h_kernel<0>");
+                refine_h_eigen_kernel<<<cdiv((int)ncand, HJ), 64, ransac_h_jbuf_bytes(0), st>>>(recs, eig_list, flags + 3);
+                check_launch("refine_h_eigen_kernel");
+                refine_h_kernel<1><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), recs, eig_list, flags + 3);
+                check_launch("refine_h_kernel<1>");
             }
         } else {
         ransac_kernel<RANSAC_SMALL_PTS, 0><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
