@@ -997,6 +997,122 @@ __host__ __device__ constexpr size_t ransac_h_tail_lds_bytes(int nw) {
     return (size_t)H_WIN * nw * 4 + (((size_t)lv * (H_WIN * nw + 8) * 2 + 15) & ~(size_t)15) + (size_t)RANSAC_LDS_PTS * 16 + (size_t)(64 + 64 * nw) * 8 + 64;
 }
 
+// lm8_eval with ONE LANE per candidate: the lane walks its candidate's points in order and owns all 44 accumulators — the sums
+// and their order are lm8_eval's (entry (a, b): acc += J0[a] J0[b] + J1[a] J1[b]; J^T r: acc += J0[a] ex + J1[a] ey).
+// pts / mask: the lane's column of an LDS tile, element i at [i * HJ].
+__device__ __forceinline__ double lm8_eval_lane(const float4* pts, const uint8_t* mask, int n, const double (&h)[8], bool want_j,
+                                                double (&AU)[36], double (&v)[8], double* rinf) {
+    double S = 0, ri = 0;
+    if (want_j) {
+#pragma unroll
+        for (int e = 0; e < 36; ++e) AU[e] = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!mask[i * HJ]) continue;
+        const float4 p = pts[i * HJ];
+        const double Mx = p.x, My = p.y;
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        const double ex = xi - (double)p.z, ey = yi - (double)p.w;
+        S += ex * ex; S += ey * ey;
+        ri = fmax(ri, fmax(fabs(ex), fabs(ey)));
+        if (want_j) {
+            const double J0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            const double J1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = a; b < 8; ++b) { AU[e] += J0[a] * J0[b] + J1[a] * J1[b]; ++e; }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[a] += J0[a] * ex + J1[a] * ey;
+        }
+    }
+    if (rinf) *rinf = ri;
+    return S;
+}
+
+// LMSolverImpl::run on 8 parameters, one lane per candidate: refine_h_kernel<1>'s loop with the lane's own solves (its LDS slice,
+// stride HJ) and evaluations.  x: in = the start, out = the result.
+__device__ __forceinline__ void lm8_run_lane(double* sc, const float4* pts, const uint8_t* mask, int n, int max_iters, double (&x)[8]) {
+    const double eps = (double)FLT_EPSILON;
+    double xd[8], AU[36], v[8], D[8], d[8], dl[8], rinf = 0;
+    double S = lm8_eval_lane(pts, mask, n, x, true, AU, v, &rinf);
+    {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { D[i] = AU[e]; e += 8 - i; }
+    }
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dl[i] = lambda * D[i];
+        if (!solve8_lds<HJ>(sc, AU, dl, v, d)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xd[i] = x[i] - d[i];
+        double dummyA[36], dummyv[8];
+        const double Sd = lm8_eval_lane(pts, mask, n, xd, false, dummyA, dummyv, nullptr);
+        double dS = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double t = 2 * v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int a = i < j ? i : j, b = i < j ? j : i;
+                t -= AU[a * 8 - (a * (a - 1)) / 2 + (b - a)] * d[j];
+            }
+            dS += d[i] * t;
+        }
+        const double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+        else if (R < Rlo) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += d[i] * v[i];
+            double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = fmin(fmax(nu, 2.), 10.);
+            if (lambda == 0) {
+                double maxval = DBL_EPSILON;
+                const double zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 8; ++i) {
+                    double e8[8], col[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e8[j] = j == i ? 1.0 : 0.0;
+                    if (solve8_lds<HJ>(sc, AU, zero8, e8, col)) {
+                        double ci = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ci = j == i ? col[j] : ci;
+                        maxval = fmax(maxval, fabs(ci));
+                    }
+                }
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = xd[i];
+            lm8_eval_lane(pts, mask, n, x, true, AU, v, &rinf);
+        }
+        iter++;
+        double dinf = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dinf = fmax(dinf, fabs(d[i]));
+        if (!(iter < max_iters && dinf >= eps && rinf >= eps)) break;
+    }
+}
+
 // fundam.cpp after the RANSAC: `result && npoints > 4` — runKernel over the inliers, then LMSolver (maxIters = refine_iters)
 // on H[0..7]; the mask stays RANSAC's.  One wave per (candidate, frame); every sum in point order (lm8_eval); the one
 // 8x8 solves run on lane 0's slice.  grid (max_cand, B), block 64, LDS static.
@@ -1005,7 +1121,7 @@ __host__ __device__ constexpr size_t ransac_h_tail_lds_bytes(int nw) {
 // accumulates L^T L in point order and leaves both in a scratch record; refine_h_eigen_kernel solves 32 candidates' problems per
 // wave, a lane and an LDS slice each (ransac_h_kernel's Jacobi, unchanged); PHASE 1 (this kernel) runs the LM from the record's
 // matrix.  The arithmetic of a candidate is what the single kernel did, operation for operation.
-struct RefineRec { double H[9]; double LtL[45]; HNorm n; double ok; };      // 63 doubles per (frame, candidate)
+struct RefineRec { double H[9]; double LtL[45]; HNorm n; double ok; double lm_done; };      // 64 doubles per (frame, candidate)
 template <int PHASE>
 __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs,
                                                       const slideo_keypoint* __restrict__ frame_kp,
@@ -1022,6 +1138,7 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
     const int count = fc.count[r], inl = fc.inliers[r];
     if (count <= 4 || !fc.found[r] || inl <= 0 || vp.refine_iters <= 0) return;
     RefineRec& rec = recs[(size_t)f * gridDim.x + r];
+    if (PHASE == 1 && rec.lm_done != 0.0) return;                                // refine_h_eigen_kernel ran this candidate's LM too
     const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
     const uint2* vt = votes + vbase;
     float4* pts = count <= RANSAC_LDS_PTS ? lpts : gpts + vbase;
@@ -1064,7 +1181,7 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
         n.smx = __shfl(acc, 0); n.smy = __shfl(acc, 1); n.sMx = __shfl(acc, 2); n.sMy = __shfl(acc, 3);
     }
     const bool ok = !(fabs(n.smx) < DBL_EPSILON || fabs(n.smy) < DBL_EPSILON || fabs(n.sMx) < DBL_EPSILON || fabs(n.sMy) < DBL_EPSILON);
-    if (lane == 0) rec.ok = ok ? 1.0 : 0.0;
+    if (lane == 0) { rec.ok = ok ? 1.0 : 0.0; rec.lm_done = 0.0; }
     if (ok) {
         n.smx = cnt / n.smx; n.smy = cnt / n.smy; n.sMx = cnt / n.sMx; n.sMy = cnt / n.sMy;
         int rj = 0, rk = 0;
@@ -1171,10 +1288,17 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
 }
 
 // The eigenproblems of refine_h_kernel<0>'s records: lane l < HJ of block b solves entry b HJ + l of the list on its LDS slice
-// (jacobi9_smallest<HJ>, the sweep ransac_h_kernel runs per sample) and leaves the denormalised matrix in the record.
-// grid ceil(candidates / HJ), block 64, dynamic LDS ransac_h_jbuf_bytes(0).
-__global__ __launch_bounds__(64) void refine_h_eigen_kernel(RefineRec* __restrict__ recs, const uint32_t* __restrict__ eig_list,
-                                                            const uint32_t* __restrict__ eig_count) {
+// (jacobi9_smallest<HJ>, the sweep ransac_h_kernel runs per sample) and leaves the denormalised matrix in the record.  A
+// candidate with at most REFINE_LANE_PTS votes — two thirds of all candidates have 5 - 7 inliers — gets its LM in the same lane
+// (lm8_run_lane: the points in a lane-major LDS tile, the 8x8 solves on the slice), and refine_h_kernel<1> skips it (lm_done).
+// grid ceil(candidates / HJ), block 64, dynamic LDS refine_h_eigen_lds_bytes().
+constexpr int REFINE_LANE_PTS = 48;
+__host__ __device__ constexpr size_t refine_h_eigen_lds_bytes() { return ransac_h_jbuf_bytes(0) + (size_t)REFINE_LANE_PTS * HJ * 16 + (size_t)REFINE_LANE_PTS * HJ; }
+__global__ __launch_bounds__(64) void refine_h_eigen_kernel(VerifyParams vp, const uint32_t* __restrict__ qofs, const slideo_keypoint* __restrict__ frame_kp,
+                                                            const float2* __restrict__ page_xy, const uint2* __restrict__ votes,
+                                                            FrameCands* __restrict__ fcs, const uint8_t* __restrict__ gmask, int max_cand,
+                                                            RefineRec* __restrict__ recs, const uint32_t* __restrict__ eig_list,
+                                                            const uint32_t* __restrict__ eig_count, int lane_lm) {
     extern __shared__ __attribute__((aligned(16))) uint8_t hsm[];
     const uint32_t total = *eig_count;
     if (blockIdx.x * HJ >= total) return;
@@ -1184,17 +1308,47 @@ __global__ __launch_bounds__(64) void refine_h_eigen_kernel(RefineRec* __restric
     double* A = reinterpret_cast<double*>(hsm) + (lane & (HJ - 1));
     double* V = A + HJ_TRI * HJ;
     double* W = V + HJ_V * HJ;
-    RefineRec& rec = recs[mine ? eig_list[e] : eig_list[blockIdx.x * HJ]];
-    double LtL[45];
+    float4* tile = reinterpret_cast<float4*>(hsm + ransac_h_jbuf_bytes(0)) + (lane & (HJ - 1));
+    uint8_t* mtile = hsm + ransac_h_jbuf_bytes(0) + (size_t)REFINE_LANE_PTS * HJ * 16 + (lane & (HJ - 1));
+    const uint32_t ci = mine ? eig_list[e] : eig_list[blockIdx.x * HJ];
+    RefineRec& rec = recs[ci];
+    double H[9];
+    {
+        double LtL[45];
 #pragma unroll
-    for (int j = 0; j < 45; ++j) LtL[j] = rec.LtL[j];
-    const HNorm n = rec.n;
-    double h[9], H[9];
-    jacobi9_smallest<HJ>(A, V, W, LtL, mine, h);
-    if (mine) {
-        h_denormalise(h, n, H);
+        for (int j = 0; j < 45; ++j) LtL[j] = rec.LtL[j];
+        const HNorm n = rec.n;
+        double h[9];
+        jacobi9_smallest<HJ>(A, V, W, LtL, mine, h);
+        if (mine) {
+            h_denormalise(h, n, H);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) rec.H[j] = H[j];
+            for (int j = 0; j < 9; ++j) rec.H[j] = H[j];
+        }
+    }
+    if (!lane_lm) return;
+    const int f = (int)(ci / (uint32_t)max_cand), r = (int)(ci - (uint32_t)f * (uint32_t)max_cand);
+    FrameCands& fc = fcs[f];
+    const int count = fc.count[r];
+    const bool small = mine && count <= REFINE_LANE_PTS;
+    if (small) {
+        const size_t vbase = (size_t)qofs[f] * vp.k + fc.ofs[r];
+        const uint32_t qbase_f = qofs[f];
+        for (int i = 0; i < count; ++i) {
+            const uint2 v = votes[vbase + i];
+            const float2 sp = page_xy[v.y];
+            const slideo_keypoint* kp = frame_kp + qbase_f + v.x;
+            tile[i * HJ] = make_float4(sp.x, sp.y, kp->x, kp->y);
+            mtile[i * HJ] = gmask[vbase + i];
+        }
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = H[j];
+        lm8_run_lane(A, tile, mtile, count, vp.refine_iters, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fc.M[r][j] = x[j];
+        fc.M[r][8] = H[8];
+        rec.lm_done = 1.0;
     }
 }
 

@@ -743,7 +743,13 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
                     S.d_fcs.as<FrameCands>(), S.d_gpts.as<float4>(), S.d_gmask.as<uint8_t>(), recs, eig_list, flags + 3);
                 check_launch("refine_h_kernel<0>");
-                refine_h_eigen_kernel<<<cdiv((int)ncand, HJ), 64, ransac_h_jbuf_bytes(0), st>>>(recs, eig_list, flags + 3);
+                // the small candidates' LM in the eigen kernel's lanes: less wave time (3.7 -> 2.1 s per headline unit) but a longer
+                // critical path (one lane's ten iterations, ~2 ms) — it pays when the candidates outnumber the resident waves
+                const char* lane_env = getenv("SLIDEO_REFINE_LANE_LM");                 // (read per unit: the tests switch it)
+                const int lane_lm = lane_env ? atoi(lane_env) : (ncand >= 4096 ? 1 : 0);
+                refine_h_eigen_kernel<<<cdiv((int)ncand, HJ), 64, refine_h_eigen_lds_bytes(), st>>>(
+                    vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
+                    S.d_fcs.as<FrameCands>(), S.d_gmask.as<uint8_t>(), c.max_candidate_pages, recs, eig_list, flags + 3, lane_lm);
                 check_launch("refine_h_eigen_kernel");
                 refine_h_kernel<1><<<dim3(c.max_candidate_pages, n), 64, 0, st>>>(
                     vp, S.d_qofs.as<uint32_t>(), S.d_kp.as<slideo_keypoint>(), m->d_page_xy.as<float2>(), S.d_votes.as<uint2>(),
@@ -1118,6 +1124,8 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
                                   (int)ransac_h_lds_bytes(RANSAC_SMALL_PTS, 2)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_kernel<RANSAC_LDS_PTS, RANSAC_SMALL_PTS + 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ransac_h_lds_bytes(RANSAC_LDS_PTS, 2)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_h_eigen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)refine_h_eigen_lds_bytes()));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_tail_kernel<1, RANSAC_H_TAIL_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ransac_h_tail_lds_bytes(RANSAC_H_TAIL_WAVES)));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_h_tail_kernel<2, RANSAC_H_TAIL_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -161,3 +161,22 @@ def test_tail_kernel_equals_single_wave(capi, oracle, synth, cfg0_data, hdlt, mo
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
     m.close()
+
+
+def test_lane_lm_equals_wave_lm(capi, oracle, synth, monkeypatch):
+    """refine_h_eigen_kernel's lane-per-candidate LM (candidates with <= 48 votes; SLIDEO_REFINE_LANE_LM=1) against the
+    wave-per-candidate LM of refine_h_kernel<1> (=0): verdicts and candidate records bit-identical, both equal to the oracle."""
+    pages = synth.pages(48, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    kw = dict(verify_model=1, ocv_hdlt=1)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SLIDEO_REFINE_LANE_LM", mode)
+        m, db = _build_both(capi, oracle, small_cfg(capi, **kw), small_cfg(oracle, **kw), pages)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+        runs[mode] = (v, [np.array(m.last_candidates(i)) for i in range(len(frames))])
+        m.close()
+    assert np.array_equal(runs["0"][0], runs["1"][0])
+    for ca, cb in zip(runs["0"][1], runs["1"][1]):
+        assert ca.tobytes() == cb.tobytes()
