@@ -191,6 +191,8 @@ VerifyParams make_vp(const slideo_config& c) {
     v.thr = c.ransac_threshold; v.conf = c.ransac_confidence; v.min_rating = c.min_rating;
     v.min_rating_ratio = c.min_rating_ratio; v.max_iters = c.ransac_max_iters; v.refine_iters = c.refine_iters;
     v.model = c.verify_model;
+    const char* e = getenv("SLIDEO_RANSAC_WINDOW");      // (read per unit: the tests switch it)
+    v.sched_window = e ? (atoi(e) != 0) : 1;
     return v;
 }
 

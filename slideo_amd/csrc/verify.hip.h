@@ -65,6 +65,7 @@ struct VerifyParams {
     int32_t max_iters, refine_iters;
     uint32_t rng_len;                       // entries of the pre-drawn cv::RNG stream (grown on demand by the host)
     int32_t model;                          // slideo_config.verify_model: 0 similarity (2x3), 1 homography (3x3)
+    int32_t sched_window;                   // ransac_kernel: redraw schedule from the LDS-window jump tables (1) / by the fixed point only (0: A/B, tests)
 };
 
 // ---------------------------------------------------------------------------
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64) void ransac_kernel(VerifyParams vp, const uint3
             uint32_t a = rng_tab[pos + 2 * lane] % (uint32_t)count;
             uint32_t b = rng_tab[pos + 2 * lane + 1] % (uint32_t)count;
             if (__builtin_amdgcn_ballot_w64(a == b) == 0ull) pos += 128;
-            else if (ransac_schedule_from_window(rng_tab + pos, (uint32_t)count, rs_win, &rs_jt[0][0], lane, a, b, pos)) {
+            else if (vp.sched_window && ransac_schedule_from_window(rng_tab + pos, (uint32_t)count, rs_win, &rs_jt[0][0], lane, a, b, pos)) {
                 // (some iteration redraws its second index: the 64 start positions from jump tables over an LDS window of the
                 // stream — two table levels whatever the number of redraws, which is what candidates with 3 - 20 votes need:
                 // a third of their iterations redraw)

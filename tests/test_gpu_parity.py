@@ -709,6 +709,28 @@ def test_ransac_rng_stream_grows_on_demand(capi, oracle, cfg0_data, monkeypatch)
     m.close()
 
 
+@pytest.mark.parametrize("ratio", [0.0, 0.8])
+def test_ransac_redraw_schedule_window_equals_fixed_point(capi, oracle, cfg0_data, synth, monkeypatch, ratio):
+    """ransac_kernel's redraw schedule of a 64-iteration chunk: from the jump tables over an LDS window of the stream (default)
+    and by the prefix-sum fixed point (SLIDEO_RANSAC_WINDOW=0, the fall-back for a chunk the window does not hold): the same
+    candidate records bit for bit, both equal to the oracle's.  The ratio-test mode makes the few-vote candidates in which a
+    third of the iterations redraw."""
+    pages = synth.pages(48, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    kw = dict(ratio_test=ratio) if ratio else {}
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SLIDEO_RANSAC_WINDOW", mode)
+        m, db = _build_both(capi, oracle, small_cfg(capi, **kw), small_cfg(oracle, **kw), pages)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)
+        runs[mode] = (v, [np.array(m.last_candidates(i)) for i in range(len(frames))])
+        m.close()
+    assert np.array_equal(runs["0"][0], runs["1"][0])
+    for ca, cb in zip(runs["0"][1], runs["1"][1]):
+        assert ca.tobytes() == cb.tobytes()
+
+
 def test_fused_pyramid_chain_equals_per_level_kernels(capi, oracle, synth, monkeypatch):
     """SLIDEO_PYR_CHAIN=1 builds the pyramid with pyr_chain_kernel (gray + two levels, then three levels per launch, LDS to LDS)
     instead of one kernel per level; off by default because it measured slower, kept honest here: same pyramid, same features."""
