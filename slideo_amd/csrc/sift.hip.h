@@ -302,7 +302,8 @@ __device__ __forceinline__ uint32_t sift_lds_addr(const void* p) { return (uint3
 // kernel's: bit-identical.   grid (ceil(strips * chunks / 4), n), block 256.
 template <int N, bool FMA>
 __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
-                                                               float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h) {
+                                                               float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h,
+                                                               float* __restrict__ half, int64_t half_frame, int hw, int hh) {
     constexpr int R = N / 2, LAG = (2 * R + 7) / 8, WIN = 8 * (LAG + 1), IW = 64 + 2 * R, IP = 96, NV4 = (N + 7 + 3) / 4, SP = 68;
     // input buffers: three (rows requested two steps ahead) for the wide kernels, which are bound by their arithmetic and by
     // registers (3 waves per SIMD); two for the narrow ones — 33 instead of 45 KB of LDS per block: 4 instead of 3 waves per SIMD
@@ -319,6 +320,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
     const float* S = src + (int64_t)blockIdx.y * src_frame;
     float* D = dst + (int64_t)blockIdx.y * dst_frame;
     float* G = dog ? dog + (int64_t)blockIdx.y * dog_frame : nullptr;
+    // `half` (the launch that completes layer nOctaveLayers): the next octave's first layer = every second pixel of this output,
+    // written from the registers instead of being read back by sift_half_kernel (chunks start at even rows: chunk_h is a multiple of 8)
+    float* HF = half ? half + (int64_t)blockIdx.y * half_frame : nullptr;
     float* const IN = s_in[wave][0];
     const uint32_t in_addr = sift_lds_addr(IN), st_addr = sift_lds_addr(s_st[wave]);
     // (the taps are symmetric bit for bit — exp(-x^2 / 2 sigma^2) of +-x — so R + 1 registers hold them)
@@ -445,6 +449,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
 #pragma unroll
                 for (int o = 0; o < 8; ++o) __builtin_nontemporal_store(res[o], o0 + (int64_t)o * w);
             }
+            if (HF && !(gx & 1) && (gx >> 1) < hw) {
+#pragma unroll
+                for (int o = 0; o < 8; o += 2) if (((Y + o) >> 1) < hh) HF[(int64_t)((Y + o) >> 1) * hw + (gx >> 1)] = res[o];
+            }
             s1 = 8;
         } else if (m >= LAG) {
             const int Y = y0 + 8 * (m - LAG);
@@ -462,6 +470,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
                 if (gx < w && gy < y1) {
                     D[(int64_t)gy * w + gx] = sacc;
                     if (G) G[(int64_t)gy * w + gx] = sacc - sv[o];
+                    if (HF && !((gx | gy) & 1) && (gx >> 1) < hw && (gy >> 1) < hh) HF[(int64_t)(gy >> 1) * hw + (gx >> 1)] = sacc;
                 }
             }
         }

@@ -1851,13 +1851,14 @@ void sift_check_cfg(const slideo_sift_config* sc, int w, int h) {
 }
 
 template <int N>
-void sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n, const SiftTaps& tp, hipStream_t st) {
+bool sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n, const SiftTaps& tp, hipStream_t st,
+                    float* half, int64_t hf, int hw, int hh) {      // returns: the half-size copy was written too
     static const bool tiles = std::getenv("SLIDEO_SIFT_BLUR_TILES") != nullptr;                   // A/B: the 64 x 64 tile kernel
     if (tiles) {
         const dim3 grid(cdiv(w, 64) * cdiv(h, 64), n);
         if (fma) sift_blur_fast_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
         else sift_blur_fast_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
-        return;
+        return false;
     }
     // streams: one wave per (64-column strip, chunk of rows); chunks sized so that a launch has ~16 k waves (several rounds of the chip: a short tail)
     const int strips = cdiv(w, 64);
@@ -1865,18 +1866,21 @@ void sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t 
     const int chunks = std::min(std::max(cdiv(target_waves, strips * std::max(n, 1)), 1), cdiv(h, 64));
     const int chunk_h = (cdiv(h, chunks) + 7) & ~7;
     const dim3 grid(cdiv(strips * cdiv(h, chunk_h), 4), n);
-    if (fma) sift_blur_stream_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h);
-    else sift_blur_stream_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h);
+    if (fma) sift_blur_stream_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
+    else sift_blur_stream_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
+    return half != nullptr;
 }
 
-void sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n,
-                      const SiftTaps& tp, hipStream_t st) {
+// half != null: also leave dst's every-second-pixel copy (hw x hh) there if the kernel taken can (returns whether it did)
+bool sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* dst, int64_t df, float* dog, int64_t dgf, int w, int h, int n,
+                      const SiftTaps& tp, hipStream_t st, float* half = nullptr, int64_t hf = 0, int hw = 0, int hh = 0) {
+    bool half_done = false;
     const bool fma = m->cfg.ocv.blur != 1;
     static const bool generic_only = std::getenv("SLIDEO_SIFT_BLUR_GENERIC") != nullptr;        // A/B and the equality test
     bool fast = !generic_only && w >= 32 && h >= 32;
     if (fast) {
         switch (tp.n) {
-#define SLIDEO_SIFT_CASE(N) case N: sift_blur_fast<N>(fma, src, sf, dst, df, dog, dgf, w, h, n, tp, st); break;
+#define SLIDEO_SIFT_CASE(N) case N: half_done = sift_blur_fast<N>(fma, src, sf, dst, df, dog, dgf, w, h, n, tp, st, half, hf, hw, hh); break;
             SLIDEO_SIFT_CASE(7) SLIDEO_SIFT_CASE(9) SLIDEO_SIFT_CASE(11) SLIDEO_SIFT_CASE(13) SLIDEO_SIFT_CASE(15) SLIDEO_SIFT_CASE(17)
             SLIDEO_SIFT_CASE(19) SLIDEO_SIFT_CASE(21) SLIDEO_SIFT_CASE(23) SLIDEO_SIFT_CASE(25) SLIDEO_SIFT_CASE(27)
 #undef SLIDEO_SIFT_CASE
@@ -1889,6 +1893,7 @@ void sift_blur_launch(slideo_matcher* m, const float* src, int64_t sf, float* ds
         else sift_blur_kernel<false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp);
     }
     check_launch("sift_blur_kernel");
+    return half_done;
 }
 
 // Gaussian + DoG pyramids of nb frames (device) into m->sift.gauss / dog
@@ -1919,17 +1924,24 @@ void sift_pyramids(slideo_matcher* m, const uint8_t* frames_dev, int nb, int w, 
     sig[0] = sc.sigma;
     const double k = std::pow(2., 1. / SIFT_NL);
     for (int i = 1; i < SIFT_NL + 3; ++i) { const double sp = std::pow(k, (double)(i - 1)) * sc.sigma, stt = sp * k; sig[i] = std::sqrt(stt * stt - sp * sp); }
+    static const bool fuse_half = std::getenv("SLIDEO_SIFT_FUSE_HALF") == nullptr || atoi(std::getenv("SLIDEO_SIFT_FUSE_HALF")) != 0;   // A/B
+    bool half_done = false;                       // the octave's first layer was written by the previous octave's layer-3 blur
     for (int o = 0; o < g.n_oct; ++o) {
         const int ow = g.ow[o], oh = g.oh[o];
         const int64_t lsz = (int64_t)ow * oh;
-        if (o > 0) {
+        if (o > 0 && !half_done) {
             sift_half_kernel<<<dim3(cdiv(ow, 256), oh, nb), 256, 0, st>>>(G + g.g_ofs[o - 1] + (int64_t)g.ow[o - 1] * g.oh[o - 1] * SIFT_NL, g.g_frame, g.ow[o - 1],
                                                                           G + g.g_ofs[o], g.g_frame, ow, oh);
             check_launch("sift_half_kernel");
         }
-        for (int i = 1; i < SIFT_NL + 3; ++i)
-            sift_blur_launch(m, G + g.g_ofs[o] + lsz * (i - 1), g.g_frame, G + g.g_ofs[o] + lsz * i, g.g_frame, nullptr, 0,      // (the DoG layers are not stored: SiftDog)
-                             ow, oh, nb, sift_taps(sig[i]), st);
+        half_done = false;
+        for (int i = 1; i < SIFT_NL + 3; ++i) {
+            const bool want_half = fuse_half && i == SIFT_NL && o + 1 < g.n_oct;
+            const bool did = sift_blur_launch(m, G + g.g_ofs[o] + lsz * (i - 1), g.g_frame, G + g.g_ofs[o] + lsz * i, g.g_frame, nullptr, 0,      // (the DoG layers are not stored: SiftDog)
+                                              ow, oh, nb, sift_taps(sig[i]), st,
+                                              want_half ? G + g.g_ofs[o + 1] : nullptr, g.g_frame, want_half ? g.ow[o + 1] : 0, want_half ? g.oh[o + 1] : 0);
+            if (want_half) half_done = did;
+        }
     }
 }
 
