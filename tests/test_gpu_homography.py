@@ -163,6 +163,27 @@ def test_tail_kernel_equals_single_wave(capi, oracle, synth, cfg0_data, hdlt, mo
     m.close()
 
 
+def test_tail_kernel_candidates_beyond_the_lds_points(capi, oracle, synth, monkeypatch):
+    """ORB-4000 on 1080p frames: the true page collects more votes than RANSAC_LDS_PTS (1024), so its point pairs live in
+    global memory (gpts) — in ransac_h_kernel's large instance and, with the hand-over cap at 1, in ransac_h_tail_kernel.
+    Traces equal the oracle's and the cap-off run's bit for bit."""
+    pages = synth.pages(4)
+    frames, truth, _ = synth.frames(pages, 3, 1920, 1080, first=1)
+    kw = dict(nfeatures=4000, verify_model=1, ocv_hdlt=1)
+    runs = {}
+    for cap in ("0", "1"):
+        monkeypatch.setenv("SLIDEO_RH_TAIL_ROUNDS", cap)
+        m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+        runs[cap] = (v, [np.array(m.last_candidates(i)) for i in range(len(frames))])
+        m.close()
+    assert max(int(c["n_votes"].max()) for c in runs["1"][1] if len(c)) > 1024, "the case this test is for"
+    assert np.array_equal(runs["0"][0], runs["1"][0])
+    for ca, cb in zip(runs["0"][1], runs["1"][1]):
+        assert ca.tobytes() == cb.tobytes()
+
+
 def test_lane_lm_equals_wave_lm(capi, oracle, synth, monkeypatch):
     """refine_h_eigen_kernel's lane-per-candidate LM (candidates with <= 48 votes; SLIDEO_REFINE_LANE_LM=1) against the
     wave-per-candidate LM of refine_h_kernel<1> (=0): verdicts and candidate records bit-identical, both equal to the oracle."""
