@@ -167,6 +167,47 @@ def test_configs4_shape_4k_orb2000_end_to_end(capi, oracle, synth):
     m.close()
 
 
+def test_headline_shape_homography_traces_vs_oracle(capi, oracle, synth, deck500):
+    """The headline shape with the homography verifier (verify_model 1, ocv.hdlt 1) on perspective frames, 256 frames as ONE unit:
+    10 240 candidate slots, so everything size-dependent is on as in bench.py — ransac_h_tail_kernel takes over after the default
+    256 rounds, refine_h's small candidates get the lane LM (>= 4096 candidates per unit).  Traces of ALL 256 frames against the
+    oracle (skipping the matrices of ill-conditioned non-survivors, as test_gpu_homography does), and the whole unit twice."""
+    import torch
+    pages = deck500
+    B, fw, fh = 256, 1920, 1080
+    frames, truth, _ = synth.frames_persp(pages, B, fw, fh, persp=0.1, threads=min(64, NCPU))
+    kw = dict(nfeatures=1000, verify_model=1, ocv_hdlt=1)
+    db = oracle.PageDB(oracle.default_config(**kw))
+    db.add_pages(pages, threads=NCPU)
+    assert db.finalize() == 0
+    m = capi.Matcher(capi.default_config(**kw))
+    for i in range(0, 500, 50):
+        m.add_pages(list(pages[i:i + 50]))
+    m.finalize()
+    idx = list(range(B))
+    otr = _oracle_traces(db, frames, idx)
+    d_frames = torch.from_numpy(frames).cuda()
+    v, cands = _one_unit(m, d_frames, B, fw, fh)
+    for i in idx:
+        ov, oc = otr[i]
+        gc = cands[i]
+        tag = "frame %d" % i
+        assert v[i]["n_keypoints"] == ov["n_keypoints"] and list(gc["page_idx"]) == list(oc["page_idx"]), tag
+        assert list(gc["n_votes"]) == list(oc["n_votes"]) and list(gc["inliers"]) == list(oc["inliers"]), tag
+        assert list(gc["survived"]) == list(oc["survived"]), tag
+        for a, b in zip(gc, oc):
+            if b["survived"]:
+                assert np.allclose(a["transform"], b["transform"], rtol=1e-5, atol=1e-9), tag
+            assert abs(a["similarity"] - b["similarity"]) <= 1e-4, tag
+        assert v[i]["page_idx"] == ov["page_idx"] and v[i]["inliers"] == ov["inliers"], tag
+    v2, cands2 = _one_unit(m, d_frames, B, fw, fh)
+    assert np.array_equal(v, v2)
+    for a, b in zip(cands, cands2):
+        assert np.array(a).tobytes() == np.array(b).tobytes()
+    assert (v["page_idx"] == truth).mean() >= 0.8          # (the sibling-page effect of the 8-DOF model: DESIGN section 5)
+    m.close()
+
+
 def test_configs4_shape_homography_verification(capi, oracle, synth):
     """configs[4] as BASELINE words it ("RANSAC homography verify"): 4K frames generated under a projective map, ORB-2000,
     verify_model 1 in both sample-solver forms; every frame's trace against the oracle (csrc/homography.hip.h)."""
