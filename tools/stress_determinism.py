@@ -1,7 +1,7 @@
 """Repeats the headline batch many times through the streaming entry points (two units in flight) and checks that every
 repetition returns bit-identical verdict records and candidate traces — a race in the kNN ring protocol, the pending
 buffers or the slot pipeline would show up as a difference.  usage (GPU box): python tools/stress_determinism.py [reps] [mode]
-mode "homography": verify_model 1, ocv.hdlt 1 on perspective frames — ransac_h_tail_kernel's hand-over list, refine_h's
+mode "sift": the SIFT matcher mode; mode "homography": verify_model 1, ocv.hdlt 1 on perspective frames — ransac_h_tail_kernel's hand-over list, refine_h's
 eigenproblem list and the lane LM are filled through atomics in whatever order the blocks arrive; the results must not care.
 The candidate traces of EVERY repetition's last unit are compared in that mode (the lists differ from run to run)."""
 import sys, time
@@ -14,7 +14,13 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 mode = sys.argv[2] if len(sys.argv) > 2 else "default"
 P, B = 500, 256
 pages = synth.pages(P, 2001, 1125, threads=64)
-if mode == "homography":
+if mode == "sift":
+    # the SIFT matcher mode (BASELINE configs[2]): SIFT extraction (LDS-DMA stream blurs), L2 2-NN on the int8 matrix cores, Lowe's
+    # ratio test, then the shared verify stages
+    frames, truth, _ = synth.frames(pages, B, 1920, 1080, threads=64)
+    m = _capi.Matcher(_capi.default_config(nfeatures=1000))
+    m.use_sift(_capi.sift_config(nfeatures=1000), 0.8)
+elif mode == "homography":
     frames, truth, _ = synth.frames_persp(pages, B, 1920, 1080, persp=0.1, threads=64)
     m = _capi.Matcher(_capi.default_config(nfeatures=1000, verify_model=1, ocv_hdlt=1))
 else:
