@@ -442,7 +442,7 @@ __device__ __forceinline__ double sel9(const double (&a)[9], int i) {
 // nearly degenerate set: 1e-4 relative).  Parallelism is across the 44 accumulators instead of across the points: lane e
 // owns entry e (0..35: J^T J, 36..43: J^T r), every lane evaluates the (wave-uniform) residual and Jacobian rows of the
 // point and picks its two factors; the totals are exchanged at the end.  Every lane returns the same values.
-__device__ __noinline__ double lm8_eval(const float4* pts, const uint8_t* mask, int n, int lane, const double (&h)[8], bool want_j,
+__device__ __forceinline__ double lm8_eval(const float4* pts, const uint8_t* mask, int n, int lane, const double (&h)[8], bool want_j,
                                         double (&AU)[36], double (&v)[8], double* rinf) {
     double S = 0, ri = 0, acc = 0;
     int ra = 0, rb = 0;                                   // this lane's entry: (ra, rb) of J^T J, or ra of J^T r
