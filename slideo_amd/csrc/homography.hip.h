@@ -482,7 +482,7 @@ __device__ __forceinline__ double lm8_eval(const float4* pts, const uint8_t* mas
 // no broadcast, no divergence); sc: >= 72 doubles at stride HJ.  AU: upper triangle of the symmetric matrix, dl: added to
 // the diagonal (lambda * D).
 template <int HJ>
-__device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], const double (&dl)[8], const double (&b)[8], double (&x)[8]) {
+__device__ __forceinline__ bool solve8_lds(double* sc, const double (&AU)[36], const double (&dl)[8], const double (&b)[8], double (&x)[8]) {
     {
         int e = 0;
 #pragma unroll
@@ -523,6 +523,13 @@ __device__ __noinline__ bool solve8_lds(double* sc, const double (&AU)[36], cons
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = xs[i];
     return true;
+}
+
+// (refine_h_kernel<1> calls the solver out of line — inlined three times it costs the kernel half its occupancy —, the lane LM of
+// refine_h_eigen_kernel inlines it: no scratch there, -17 %)
+template <int HJ>
+__device__ __noinline__ bool solve8_lds_call(double* sc, const double (&AU)[36], const double (&dl)[8], const double (&b)[8], double (&x)[8]) {
+    return solve8_lds<HJ>(sc, AU, dl, b, x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1220,7 +1227,7 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
         for (int i = 0; i < 8; ++i) dl[i] = lambda * D[i];
         {
             int okd = 0;
-            if (lane == 0) okd = solve8_lds<ST>(A, AU, dl, v, d) ? 1 : 0;
+            if (lane == 0) okd = solve8_lds_call<ST>(A, AU, dl, v, d) ? 1 : 0;
             okd = __shfl(okd, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) d[i] = okd ? __shfl(d[i], 0) : 0.0;
@@ -1258,7 +1265,7 @@ __global__ __launch_bounds__(64) void refine_h_kernel(VerifyParams vp, const uin
                     int okc = 0;
                     double ci = 0;
                     if (lane == 0) {
-                        okc = solve8_lds<ST>(A, AU, zero8, e8, col) ? 1 : 0;
+                        okc = solve8_lds_call<ST>(A, AU, zero8, e8, col) ? 1 : 0;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ci = j == i ? col[j] : ci;
                     }
