@@ -300,7 +300,7 @@ __device__ __forceinline__ uint32_t sift_lds_addr(const void* p) { return (uint3
 // A row-pass row is computed once per chunk (+ 2R warm-up rows), LDS is 11.4 KB per wave whatever N, no block barrier exists: the
 // four waves of a block are independent strips.  Per output value the operation order is the tile kernel's and the generic
 // kernel's: bit-identical.   grid (ceil(strips * chunks / 4), n), block 256.
-template <int N, bool FMA>
+template <int N, bool FMA, bool HALF = false>      // HALF: also write the every-second-pixel copy (instantiated for the layer-3 tap count only: the other instances keep their registers)
 __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void sift_blur_stream_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
                                                                float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp, int chunk_h,
                                                                float* __restrict__ half, int64_t half_frame, int hw, int hh) {
@@ -322,7 +322,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(256) void s
     float* G = dog ? dog + (int64_t)blockIdx.y * dog_frame : nullptr;
     // `half` (the launch that completes layer nOctaveLayers): the next octave's first layer = every second pixel of this output,
     // written from the registers instead of being read back by sift_half_kernel (chunks start at even rows: chunk_h is a multiple of 8)
-    float* HF = half ? half + (int64_t)blockIdx.y * half_frame : nullptr;
+    float* HF = HALF && half ? half + (int64_t)blockIdx.y * half_frame : nullptr;
     float* const IN = s_in[wave][0];
     const uint32_t in_addr = sift_lds_addr(IN), st_addr = sift_lds_addr(s_st[wave]);
     // (the taps are symmetric bit for bit — exp(-x^2 / 2 sigma^2) of +-x — so R + 1 registers hold them)

@@ -1866,9 +1866,16 @@ bool sift_blur_fast(bool fma, const float* src, int64_t sf, float* dst, int64_t 
     const int chunks = std::min(std::max(cdiv(target_waves, strips * std::max(n, 1)), 1), cdiv(h, 64));
     const int chunk_h = (cdiv(h, chunks) + 7) & ~7;
     const dim3 grid(cdiv(strips * cdiv(h, chunk_h), 4), n);
-    if (fma) sift_blur_stream_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
-    else sift_blur_stream_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
-    return half != nullptr;
+    if constexpr (N == 17) {            // (the tap count of layer nOctaveLayers at the default sigma: the instance that can write the half-size copy)
+        if (half) {
+            if (fma) sift_blur_stream_kernel<N, true, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
+            else sift_blur_stream_kernel<N, false, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, half, hf, hw, hh);
+            return true;
+        }
+    }
+    if (fma) sift_blur_stream_kernel<N, true><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, nullptr, 0, 0, 0);
+    else sift_blur_stream_kernel<N, false><<<grid, 256, 0, st>>>(src, sf, dst, df, dog, dgf, w, h, tp, chunk_h, nullptr, 0, 0, 0);
+    return false;
 }
 
 // half != null: also leave dst's every-second-pixel copy (hw x hh) there if the kernel taken can (returns whether it did)
