@@ -1,10 +1,10 @@
-//! Hand-written declarations of include/slideo_amd.h (ABI 4) — what bindgen would emit for the entry points this crate
+//! Hand-written declarations of include/slideo_amd.h (ABI 5) — what bindgen would emit for the entry points this crate
 //! uses.  Field order and types mirror the C structs exactly; tests/test_capi_load.py pins the C side's layout
 //! (sizeof(slideo_config) == 160) and `assert_abi()` below pins the version at run time.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_char;
 
-pub const SLIDEO_ABI_VERSION: u32 = 4;
+pub const SLIDEO_ABI_VERSION: u32 = 5;
 
 /// slideo_ocv_variants: which restatement of each OpenCV primitive runs.  slideo_config_default fills it; the
 /// application never touches it.
@@ -78,32 +78,36 @@ pub struct slideo_sift_config {
     pub sigma: f64,
 }
 
+/// The N-device group (include/slideo_amd.h, "N-device group"): one matcher per GPU behind one handle.  This crate binds the
+/// group form of every call; a group over one device is the single matcher.
 #[repr(C)]
-pub struct slideo_matcher {
+pub struct slideo_group {
     _private: [u8; 0],
 }
 
 extern "C" {
     pub fn slideo_abi_version() -> u32;
     pub fn slideo_config_default(cfg: *mut slideo_config);
-    pub fn slideo_matcher_create(
+    pub fn slideo_device_count() -> i32;
+    pub fn slideo_group_create(
         cfg: *const slideo_config,
-        device: i32,
-        out: *mut *mut slideo_matcher,
+        n_devices: i32,
+        devices: *const i32,
+        out: *mut *mut slideo_group,
     ) -> i32;
-    pub fn slideo_matcher_destroy(m: *mut slideo_matcher);
-    pub fn slideo_last_error(m: *const slideo_matcher) -> *const c_char;
-    pub fn slideo_matcher_add_pages_bgr8(
-        m: *mut slideo_matcher,
+    pub fn slideo_group_destroy(g: *mut slideo_group);
+    pub fn slideo_group_last_error(g: *const slideo_group) -> *const c_char;
+    pub fn slideo_group_add_pages_bgr8(
+        g: *mut slideo_group,
         n_pages: i32,
         data: *const *const u8,
         width: *const i32,
         height: *const i32,
         stride_bytes: *const i32,
     ) -> i32;
-    pub fn slideo_matcher_finalize_pages(m: *mut slideo_matcher) -> i32;
-    pub fn slideo_match_frames_bgr8(
-        m: *mut slideo_matcher,
+    pub fn slideo_group_finalize_pages(g: *mut slideo_group) -> i32;
+    pub fn slideo_group_match_frames_bgr8(
+        g: *mut slideo_group,
         n_frames: i32,
         frames: *const u8,
         width: i32,
@@ -113,16 +117,16 @@ extern "C" {
         verdicts_out: *mut slideo_verdict,
     ) -> i32;
     pub fn slideo_sift_config_default(cfg: *mut slideo_sift_config);
-    /// optional: SIFT + L2 + ratio test in front of the verify stages (before the first page)
-    pub fn slideo_matcher_use_sift(m: *mut slideo_matcher, cfg: *const slideo_sift_config, ratio: f32) -> i32;
-    pub fn slideo_match_kept_frames(
-        m: *mut slideo_matcher,
+    /// optional: SIFT + L2 search in front of the verify stages (before the first page); ratio 0 = the path's tolerance vote
+    pub fn slideo_group_use_sift(g: *mut slideo_group, cfg: *const slideo_sift_config, ratio: f32) -> i32;
+    pub fn slideo_group_match_kept_frames(
+        g: *mut slideo_group,
         n_sel: i32,
         sel: *const i32,
         verdicts_out: *mut slideo_verdict,
     ) -> i32;
-    pub fn slideo_changed_mask_bgr8(
-        m: *mut slideo_matcher,
+    pub fn slideo_group_changed_mask_bgr8(
+        g: *mut slideo_group,
         n_frames: i32,
         frames: *const u8,
         width: i32,

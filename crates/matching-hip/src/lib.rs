@@ -3,11 +3,13 @@
 //! panics-instead-of-Results, same post-processing of the per-frame results.
 //!
 //!   OpenCVImageVideoMatcher::default()          -> HipImageVideoMatcher::default()
-//!   create_video_matcher    (mo/lib.rs:37-64)   -> slideo_matcher_create + add_pages_bgr8 + finalize_pages
+//!   create_video_matcher    (mo/lib.rs:37-64)   -> slideo_group_create (one matcher per GPU of the node) + add_pages_bgr8 +
+//!                                                  finalize_pages: pages analysed across the devices, DB replicated
 //!   match_images_with_video (mo/lib.rs:140-158) -> opens the video to size the progress bar, as the reference does
-//!   process                 (mo/lib.rs:168-246) -> sampled frames in batches: slideo_changed_mask_bgr8
-//!                                                  (MarkSimilarIter, mo/video_capture.rs:86-98), then
-//!                                                  slideo_match_kept_frames on the changed ones (the mask's upload)
+//!   process                 (mo/lib.rs:168-246) -> sampled frames in batches, each batch sharded over the devices:
+//!                                                  slideo_group_changed_mask_bgr8 (MarkSimilarIter,
+//!                                                  mo/video_capture.rs:86-98), then slideo_group_match_kept_frames on
+//!                                                  the changed ones (the mask's upload, on the device that holds it)
 //!                                                  (match_images_with_frame, mo/lib.rs:249-413); sentinel, sort,
 //!                                                  consecutive-duplicate removal as mo/lib.rs:185-189,229-244
 //! (mo/ = crates/matching-opencv/src/)
@@ -26,11 +28,12 @@ use std::{
     time::Duration,
 };
 
-/// Sampled frames handed to the library per call.  The changed-frame mask needs consecutive samples in one call (or the
-/// previous small image carried over, which is what happens at batch seams); 64 x 1080p = 400 MB of host memory.
-const FRAMES_PER_CALL: usize = 64;
+/// Sampled frames handed to the library per call AND DEVICE.  The changed-frame mask needs consecutive samples in one call
+/// (or the previous small image carried over, which is what happens at batch seams); 64 x 1080p = 400 MB of host memory
+/// per device of the group.
+const FRAMES_PER_CALL_PER_DEVICE: usize = 64;
 
-struct RawHandle(*mut ffi::slideo_matcher);
+struct RawHandle(*mut ffi::slideo_group);
 // The pointer itself may move between threads; USE is serialised by the Mutex below — include/slideo_amd.h: "a matcher
 // is NOT re-entrant: calls on one handle must come from one thread at a time".
 unsafe impl Send for RawHandle {}
@@ -42,14 +45,14 @@ struct Handle {
 impl Drop for Handle {
     fn drop(&mut self) {
         let g = self.raw.lock().unwrap_or_else(|e| e.into_inner());
-        unsafe { ffi::slideo_matcher_destroy(g.0) }
+        unsafe { ffi::slideo_group_destroy(g.0) }
     }
 }
 
 /// The reference has no `Result` anywhere on this surface: it panics (mo/lib.rs:95-104, unwrap() throughout).
-fn check(h: *mut ffi::slideo_matcher, rc: i32) {
+fn check(h: *mut ffi::slideo_group, rc: i32) {
     if rc != 0 {
-        let msg = unsafe { CStr::from_ptr(ffi::slideo_last_error(h)) }
+        let msg = unsafe { CStr::from_ptr(ffi::slideo_group_last_error(h)) }
             .to_string_lossy()
             .into_owned();
         panic!("slideo_amd error {}: {}", rc, msg);
@@ -57,16 +60,18 @@ fn check(h: *mut ffi::slideo_matcher, rc: i32) {
 }
 
 pub struct HipImageVideoMatcher {
-    /// HIP device ordinal (one process per GPU: the multi-GPU launcher gives each rank its own)
-    pub device: i32,
-    /// Some(ratio): the north-star's SIFT + L2 + Lowe's ratio test front end (slideo_matcher_use_sift) instead of the
-    /// reference's ORB + Hamming + tolerance vote; None (default) = the reference's
+    /// HIP device ordinals, one matcher each (slideo_group_create).  Empty (default) = every gfx950 device of the node:
+    /// the reference fans out over the whole machine too (the global rayon pool, mo/lib.rs:45,174).
+    pub devices: Vec<i32>,
+    /// Some(ratio): the north-star's SIFT + L2 front end (slideo_group_use_sift) instead of the reference's ORB + Hamming;
+    /// Some(0.0) keeps the path's own 5 % tolerance vote on the L2 distances (the robust choice on decks whose pages
+    /// share a template), Some(r > 0) is Lowe's ratio test.  None (default) = the reference's extractor and matcher.
     pub sift_ratio: Option<f32>,
 }
 
 impl Default for HipImageVideoMatcher {
     fn default() -> Self {
-        HipImageVideoMatcher { device: 0, sift_ratio: None }
+        HipImageVideoMatcher { devices: Vec::new(), sift_ratio: None }
     }
 }
 
@@ -79,25 +84,30 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
         ffi::assert_abi();
         let len = images.len() as u64;
         let mut cfg = std::mem::MaybeUninit::<ffi::slideo_config>::uninit();
-        let mut h: *mut ffi::slideo_matcher = std::ptr::null_mut();
+        let mut h: *mut ffi::slideo_group = std::ptr::null_mut();
+        let devices: Vec<i32> = if self.devices.is_empty() {
+            (0..unsafe { ffi::slideo_device_count() }.max(1)).collect() // (no device at all: create reports it)
+        } else {
+            self.devices.clone()
+        };
         unsafe {
             ffi::slideo_config_default(cfg.as_mut_ptr()); // the reference's literals (mo/feature_extractor.rs:13-23 etc.)
             check(
                 std::ptr::null_mut(),
-                ffi::slideo_matcher_create(cfg.as_ptr(), self.device, &mut h),
+                ffi::slideo_group_create(cfg.as_ptr(), devices.len() as i32, devices.as_ptr(), &mut h),
             );
             if let Some(ratio) = self.sift_ratio {
                 let mut sc = std::mem::MaybeUninit::<ffi::slideo_sift_config>::uninit();
                 ffi::slideo_sift_config_default(sc.as_mut_ptr());
-                check(h, ffi::slideo_matcher_use_sift(h, sc.as_ptr(), ratio));
+                check(h, ffi::slideo_group_use_sift(h, sc.as_ptr(), ratio));
             }
         }
         // Page analysis (mo/lib.rs:43-58).  Pages are decoded on the host and handed over in groups, so that a 1000-page
         // deck does not sit decoded in memory at once; the progress protocol is the reference's and is driven from here
-        // (slideo_matcher_set_progress — a C callback for callers without a reporter of their own — is not needed).
+        // (slideo_group_set_progress — a C callback for callers without a reporter of their own — is not needed).
         progress_reporter.report(0, len, "Analyzing PDF pages...");
         let mut done = 0u64;
-        for group in images.chunks(32) {
+        for group in images.chunks(32 * devices.len()) {
             let decoded: Vec<decode::BgrImage> =
                 group.iter().map(|i| decode::decode_page_bgr(i.get_path())).collect();
             let ptrs: Vec<*const u8> = decoded.iter().map(|d| d.data.as_ptr()).collect();
@@ -107,7 +117,7 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
             unsafe {
                 check(
                     h,
-                    ffi::slideo_matcher_add_pages_bgr8(
+                    ffi::slideo_group_add_pages_bgr8(
                         h,
                         ptrs.len() as i32,
                         ptrs.as_ptr(),
@@ -123,11 +133,12 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
                 progress_reporter.report(done, len, "Analyzing PDF pages...");
             }
         }
-        unsafe { check(h, ffi::slideo_matcher_finalize_pages(h)) }; // FlannMatcher::new, mo/flann.rs:65-71
+        unsafe { check(h, ffi::slideo_group_finalize_pages(h)) }; // FlannMatcher::new, mo/flann.rs:65-71
         progress_reporter.report(len, len, "PDF page analysis successful."); // mo/lib.rs:58
         Box::new(HipVideoMatcher {
             handle: Arc::new(Handle { raw: Mutex::new(RawHandle(h)) }),
             images: Arc::new(images),
+            n_devices: devices.len(),
         })
     }
 }
@@ -135,6 +146,7 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
 struct HipVideoMatcher<I> {
     handle: Arc<Handle>,
     images: Arc<Vec<I>>,
+    n_devices: usize,
 }
 
 impl<'i, I: MatchableImage + Send + Sync + Copy + Eq + 'i> VideoMatcher<'i, I> for HipVideoMatcher<I> {
@@ -151,6 +163,7 @@ impl<'i, I: MatchableImage + Send + Sync + Copy + Eq + 'i> VideoMatcher<'i, I> f
         Box::new(HipVideoMatcherTask {
             handle: self.handle.clone(),
             images: self.images.clone(),
+            n_devices: self.n_devices,
             video_path: video_path.to_owned(),
             progress_reporter,
         })
@@ -160,6 +173,7 @@ impl<'i, I: MatchableImage + Send + Sync + Copy + Eq + 'i> VideoMatcher<'i, I> f
 struct HipVideoMatcherTask<I> {
     handle: Arc<Handle>,
     images: Arc<Vec<I>>,
+    n_devices: usize,
     video_path: PathBuf,
     progress_reporter: ProgressReporter,
 }
@@ -187,7 +201,8 @@ impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVid
         let h = guard.0;
         let mut progress = 0u64;
         let mut prev_small: Option<Vec<u8>> = None;
-        for batch in decode::batches(vid, FRAMES_PER_CALL) {
+        // one call = one shard of FRAMES_PER_CALL_PER_DEVICE sampled frames per device (mo/lib.rs:213: one task per frame over the pool)
+        for batch in decode::batches(vid, FRAMES_PER_CALL_PER_DEVICE * self.n_devices) {
             let n = batch.meta.len();
             let fb = batch.frame_bytes();
             // MarkSimilarIter (mo/video_capture.rs:86-98): changed <=> similarity to the previous SAMPLED frame < 0.98; the
@@ -198,7 +213,7 @@ impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVid
             unsafe {
                 check(
                     h,
-                    ffi::slideo_changed_mask_bgr8(
+                    ffi::slideo_group_changed_mask_bgr8(
                         h,
                         n as i32,
                         batch.frames.as_ptr(),
@@ -217,15 +232,15 @@ impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVid
             // make compute_similarity panic in the reference
             prev_small = Some(last_small);
 
-            // the changed frames through match_images_with_frame (mo/lib.rs:213-214): the mask call left its upload on the
-            // device, slideo_match_kept_frames matches a subset of it by index — no second copy over PCIe
+            // the changed frames through match_images_with_frame (mo/lib.rs:213-214): the mask call left every device's block
+            // of the upload on that device, slideo_group_match_kept_frames matches a subset by index — no second copy over PCIe
             let sel: Vec<i32> = (0..n as i32).filter(|&i| changed[i as usize] != 0).collect();
             let mut verdicts = vec![ffi::slideo_verdict::default(); sel.len()];
             if !sel.is_empty() {
                 unsafe {
                     check(
                         h,
-                        ffi::slideo_match_kept_frames(h, sel.len() as i32, sel.as_ptr(), verdicts.as_mut_ptr()),
+                        ffi::slideo_group_match_kept_frames(h, sel.len() as i32, sel.as_ptr(), verdicts.as_mut_ptr()),
                     );
                 }
             }

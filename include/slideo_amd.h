@@ -39,6 +39,23 @@
  *   NOT limits: keypoints per frame (beyond 8192 the canonical sort moves from LDS to global memory; a frame beyond the
  *   capacity the asynchronous path provides for is re-run through the exact-size path), the RANSAC sample schedule (the
  *   pre-drawn cv::RNG stream is extended on demand), frames per call (cut into units that fit the workspace budget).
+ *
+ * Environment (read by slideo_matcher_create unless marked "per unit"; NONE changes a result — they select between code paths
+ * that the tests hold bit-identical, or size workspaces; everything else that used to be switchable this way was removed):
+ *   SLIDEO_KNN_ENGINE 0..3        initial value of slideo_matcher_set_knn_engine
+ *   SLIDEO_KNN_DEDUP=0            search all M train rows instead of the distinct ones (slideo_matcher_unique_descriptor_count)
+ *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
+ *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)
+ *   SLIDEO_ORB_CHAIN=0            ORB stages of consecutive units free-running instead of taking turns
+ *   SLIDEO_HOST_UNIT n            frames per unit of a host-memory batch (32; 0 = the device-path rule)
+ *   SLIDEO_WS_GB x                workspace budget of all slots together (48)
+ *   SLIDEO_SIFT_WS_MB n           SIFT pyramid budget per pass (24576)                                          [per call]
+ *   SLIDEO_SIFT_LIST_CAP n        start capacity of SIFT's per-frame extrema list (65536; the tests force its growth path) [per call]
+ *   SLIDEO_RNG_STREAM_LEN n       start length of the pre-drawn cv::RNG stream (the tests force its growth path)
+ *   SLIDEO_RANSAC_WINDOW=0        ransac_kernel's redraw schedule by the fixed point only                       [per unit]
+ *   SLIDEO_RH_TAIL_ROUNDS n       verify_model 1: rounds before a candidate moves to ransac_h_tail_kernel (256; 0 = never) [per unit]
+ *   SLIDEO_REFINE_LANE_LM 0|1     verify_model 1: the small candidates' LM in refine_h_kernel<1> / in the eigen kernel's lanes [per unit]
+ *   build time only: SLIDEO_HIP_EXTRA_FLAGS (slideo_amd/build.py), SLIDEO_LIB_PATH / SLIDEO_REBUILD (slideo_amd/_capi.py)
  */
 #ifndef SLIDEO_AMD_H
 #define SLIDEO_AMD_H
@@ -50,7 +67,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 4
+#define SLIDEO_ABI_VERSION 5
 
 enum {
     SLIDEO_OK = 0,
@@ -333,6 +350,7 @@ int32_t     slideo_host_unregister(void* ptr);
 /* Optional progress sink for add_pages / match_frames. */
 int32_t     slideo_matcher_set_progress(slideo_matcher* m, slideo_progress_fn fn, void* user);
 
+
 /* ---- measurement ---------------------------------------------------------- */
 
 /* Stage timing with HIP events recorded on the stream the kernels are launched
@@ -471,6 +489,51 @@ typedef struct slideo_candidate {
 
 int32_t     slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_in_batch,
                                          slideo_candidate* out, int32_t capacity, int32_t* n_out);
+
+/* ---- N-device group ----------------------------------------------------------------------------------------------
+ * One matcher per device behind ONE handle: what the reference's fan-out over every core of the machine becomes on a node
+ * with several GPUs (rayon: one task per changed frame, mo/lib.rs:174,213; pages par_iter, mo/lib.rs:45-47).  The page
+ * database is replicated on every member device, a call's frames are cut into contiguous shards — member r
+ * takes frames [r n / N, (r + 1) n / N), block sizes differing by at most one — each shard runs through its device's matcher
+ * on a host thread of its own, and every shard's verdicts land in the caller's array at the shard's offset: the gather of the
+ * in-process form is the device-to-host copy each member makes anyway.  Page analysis is sharded the same way and every
+ * member appends the whole call in page order.  Results are those of a single matcher, bit for bit, whatever N is.
+ * `devices`: HIP ordinals, one member each (an ordinal may repeat: two members then share a device).  A group is not
+ * re-entrant (like a matcher); progress callbacks fire from the member threads.  (One PROCESS per GPU — where every rank needs
+ * the whole timeline — is the other multi-GPU form: slideo_match_frames_collect_dev leaves a rank's records in device memory
+ * for ONE RCCL all-gather, bench.py / slideo_amd/distributed.py.) */
+typedef struct slideo_group slideo_group;
+/* gfx950 devices visible to this process (0 when there is none: nothing here runs without one). */
+int32_t     slideo_device_count(void);
+int32_t     slideo_group_create(const slideo_config* cfg, int32_t n_devices, const int32_t* devices, slideo_group** out);
+void        slideo_group_destroy(slideo_group* g);
+/* Message of the last failure on `g` (of the last failed create when g is NULL); names the member and its device. */
+const char* slideo_group_last_error(const slideo_group* g);
+int32_t     slideo_group_device_count(const slideo_group* g);
+/* Member i's matcher (owned by the group): for the introspection calls, the taps and the measurement hooks above. */
+slideo_matcher* slideo_group_member(slideo_group* g, int32_t i);
+int32_t     slideo_group_set_progress(slideo_group* g, slideo_progress_fn fn, void* user);
+/* slideo_matcher_use_sift on every member (before the first page). */
+int32_t     slideo_group_use_sift(slideo_group* g, const slideo_sift_config* cfg, float ratio);
+/* slideo_matcher_add_pages_bgr8 with the call's pages analysed across the members (mo/lib.rs:45-56). */
+int32_t     slideo_group_add_pages_bgr8(slideo_group* g, int32_t n_pages, const uint8_t* const* data,
+                                        const int32_t* width, const int32_t* height, const int32_t* stride_bytes);
+int32_t     slideo_group_finalize_pages(slideo_group* g);
+int32_t     slideo_group_page_count(const slideo_group* g);
+int64_t     slideo_group_descriptor_count(const slideo_group* g);
+/* slideo_match_frames_bgr8 with the frames sharded over the members (mo/lib.rs:213-214: one independent task per frame). */
+int32_t     slideo_group_match_frames_bgr8(slideo_group* g, int32_t n_frames, const uint8_t* frames, int32_t width, int32_t height,
+                                           int32_t stride_bytes, int64_t frame_stride_bytes, slideo_verdict* verdicts_out);
+/* Trace of frame `frame_in_batch` of the LAST slideo_group_match_frames_bgr8 call (from the member that matched it). */
+int32_t     slideo_group_last_frame_candidates(const slideo_group* g, int32_t frame_in_batch, slideo_candidate* out, int32_t capacity,
+                                               int32_t* n_out);
+/* slideo_changed_mask_bgr8 over the members: a shard reads the one frame before its block (the previous sampled frame
+ * MarkSimilarIter compares with, mo/video_capture.rs:86-98) — flags equal the single matcher's.  Every member keeps its
+ * block's frames for slideo_group_match_kept_frames, which matches each selected frame on the member that holds it. */
+int32_t     slideo_group_changed_mask_bgr8(slideo_group* g, int32_t n_frames, const uint8_t* frames, int32_t width, int32_t height,
+                                           int32_t stride_bytes, int64_t frame_stride_bytes, const uint8_t* prev_small,
+                                           uint8_t* last_small_out, uint8_t* changed_out, float* similarity_out);
+int32_t     slideo_group_match_kept_frames(slideo_group* g, int32_t n_sel, const int32_t* sel, slideo_verdict* verdicts_out);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,10 @@ EXPORTS = [
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
     "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
     "slideo_sift_config_default", "slideo_sift_bgr8", "slideo_sift_frames_dev", "slideo_sift_layer_bgr8", "slideo_knn_lsh",
+    "slideo_device_count", "slideo_group_create", "slideo_group_destroy", "slideo_group_last_error", "slideo_group_device_count",
+    "slideo_group_member", "slideo_group_set_progress", "slideo_group_use_sift", "slideo_group_add_pages_bgr8",
+    "slideo_group_finalize_pages", "slideo_group_page_count", "slideo_group_descriptor_count", "slideo_group_match_frames_bgr8",
+    "slideo_group_last_frame_candidates", "slideo_group_changed_mask_bgr8", "slideo_group_match_kept_frames",
 ]
 
 _lib = None
@@ -106,6 +110,16 @@ def lib():
         L.slideo_matcher_max_in_flight.argtypes = [C.c_void_p]
         L.slideo_matcher_destroy.argtypes = [C.c_void_p]
         L.slideo_matcher_destroy.restype = None
+        L.slideo_group_last_error.restype = C.c_char_p
+        L.slideo_group_last_error.argtypes = [C.c_void_p]
+        L.slideo_group_destroy.argtypes = [C.c_void_p]
+        L.slideo_group_destroy.restype = None
+        L.slideo_group_member.restype = C.c_void_p
+        L.slideo_group_member.argtypes = [C.c_void_p, C.c_int32]
+        L.slideo_group_device_count.argtypes = [C.c_void_p]
+        L.slideo_group_page_count.argtypes = [C.c_void_p]
+        L.slideo_group_descriptor_count.argtypes = [C.c_void_p]
+        L.slideo_group_descriptor_count.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -211,7 +225,7 @@ class Matcher:
         """Distinct rows among the train descriptors: what the k-NN stage actually searches (results are those of all rows)."""
         return int(lib().slideo_matcher_unique_descriptor_count(self._h))
 
-    def use_sift(self, sift_cfg, ratio=0.75):
+    def use_sift(self, sift_cfg, ratio=0.0):
         """SIFT features + the squared-L2 search in front of the path's own vote / RANSAC / re-projection stages (north-star /
         configs[2] as a complete matcher).  ratio in (0, 1]: Lowe's ratio test on the two nearest rows; ratio 0: the path's
         tolerance vote on the knn_k nearest rows.  Before the first page."""
@@ -417,6 +431,119 @@ class Matcher:
         self._check(lib().slideo_small_image_bgr8(self._h, _p(bgr), w, h, w * 3, _p(out), C.c_int64(out.size),
                                                   C.byref(a), C.byref(b)))
         return out
+
+
+class Group:
+    """slideo_group (include/slideo_amd.h, "N-device group"): one matcher per device behind one handle — page DB replicated,
+    a call's pages and frames sharded contiguously over the devices, verdicts gathered into one host array.  Results equal
+    a single Matcher's bit for bit.  `devices`: HIP ordinals (may repeat); None = every gfx950 device of the node."""
+
+    def __init__(self, cfg=None, devices=None):
+        self.cfg = cfg if cfg is not None else default_config()
+        if devices is None:
+            devices = list(range(max(1, int(lib().slideo_device_count()))))
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        self._cb = None
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        rc = lib().slideo_group_create(C.byref(self.cfg), len(self.devices), arr, C.byref(self._h))
+        if rc != OK:
+            raise SlideoError(rc, lib().slideo_group_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SlideoError(rc, lib().slideo_group_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().slideo_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def member(self, i):
+        """Member i as a (non-owning) Matcher: introspection, taps, profiling."""
+        m = Matcher.__new__(Matcher)
+        m.cfg, m._cb = self.cfg, None
+        m._h = C.c_void_p(lib().slideo_group_member(self._h, int(i)))
+        m.close = lambda: None                       # the group owns the handle
+        if getattr(self, "_sift", False):
+            m._sift = True
+        return m
+
+    def set_progress(self, fn):
+        if fn is None:
+            self._cb = None
+            self._check(lib().slideo_group_set_progress(self._h, None, None))
+            return
+        self._cb = PROGRESS_FN(lambda user, d, t, msg: fn(int(d), int(t), (msg or b"").decode()))
+        self._check(lib().slideo_group_set_progress(self._h, self._cb, None))
+
+    def use_sift(self, sift_cfg, ratio=0.0):
+        self._check(lib().slideo_group_use_sift(self._h, C.byref(sift_cfg), C.c_float(ratio)))
+        self._sift = True
+
+    def add_pages(self, pages):
+        pages = [_img3(p) for p in pages]
+        n = len(pages)
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+        w = (C.c_int32 * n)(*[p.shape[1] for p in pages])
+        h = (C.c_int32 * n)(*[p.shape[0] for p in pages])
+        s = (C.c_int32 * n)(*[p.shape[1] * 3 for p in pages])
+        self._check(lib().slideo_group_add_pages_bgr8(self._h, n, ptrs, w, h, s))
+
+    def finalize(self):
+        self._check(lib().slideo_group_finalize_pages(self._h))
+
+    @property
+    def page_count(self):
+        return int(lib().slideo_group_page_count(self._h))
+
+    @property
+    def descriptor_count(self):
+        return int(lib().slideo_group_descriptor_count(self._h))
+
+    def match_frames(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, c = frames.shape
+        assert c == 3
+        out = np.zeros(n, VERDICT_DTYPE)
+        self._check(lib().slideo_group_match_frames_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3), _p(out)))
+        return out
+
+    def last_candidates(self, frame_in_batch):
+        cands = np.zeros(64, CANDIDATE_DTYPE)
+        n = C.c_int32()
+        self._check(lib().slideo_group_last_frame_candidates(self._h, frame_in_batch, _p(cands), 64, C.byref(n)))
+        return cands[: n.value].copy()
+
+    def changed_mask(self, frames, prev_small=None):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, _ = frames.shape
+        changed = np.zeros(n, np.uint8)
+        sims = np.zeros(n, np.float32)
+        sw, sh = small_size(w, h, self.cfg.small_area)
+        last = np.zeros((sh, sw, 3), np.uint8)
+        if prev_small is not None:
+            prev_small = np.ascontiguousarray(prev_small, np.uint8)
+        self._check(lib().slideo_group_changed_mask_bgr8(self._h, n, _p(frames), w, h, w * 3, C.c_int64(w * h * 3),
+                                                         _p(prev_small), _p(last), _p(changed), _p(sims)))
+        return changed.astype(bool), sims, last
+
+    def match_kept_frames(self, sel):
+        sel = np.ascontiguousarray(sel, np.int32)
+        out = np.zeros(len(sel), VERDICT_DTYPE)
+        self._check(lib().slideo_group_match_kept_frames(self._h, len(sel), _p(sel), _p(out)))
+        return out
+
+
+def device_count():
+    """gfx950 devices visible to this process."""
+    return int(lib().slideo_device_count())
 
 
 def small_size(w, h, small_area=120000):

@@ -19,8 +19,15 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(LIBDIR, "libslideo_amd.so")
 SYNTH_LIB = os.path.join(LIBDIR, "libslideo_synth.so")
 
-HIP_SOURCES = ["slideo_capi.hip"]
-HIP_DEPS_GLOB = (".hip", ".h", ".hpp")
+# one translation unit per stage; every kernel header (csrc/*.hip.h) is compiled by exactly one of them (csrc/runtime.hpp)
+HIP_SOURCES = ["capi_runtime.hip", "capi_group.hip", "capi_taps.hip", "stage_orb.hip", "stage_knn.hip", "stage_verify.hip", "stage_sift.hip"]
+# the kernel headers each unit includes (beyond runtime.hpp and the plain headers, which every unit depends on)
+HIP_UNIT_HEADERS = {"stage_orb.hip": ["orb.hip.h", "cv_math.hip.h"],
+                    "stage_knn.hip": ["knn.hip.h", "knn_tile.hip.h", "knn_l2.hip.h", "knn_lsh.hip.h"],
+                    "stage_verify.hip": ["verify.hip.h", "homography.hip.h"],
+                    "stage_sift.hip": ["sift.hip.h", "cv_math.hip.h"]}
+HIP_COMMON_HEADERS = ["runtime.hpp", "common.h", "geom.h", "types.h"]
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def _newer(target, deps):
@@ -38,19 +45,37 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(HIP_DEPS_GLOB)]
-    deps.append(os.path.join(INCLUDE, "slideo_amd.h"))
-    if not (force or _newer(HIP_LIB, deps)):
+    """Compiles the changed units (in parallel) and links libslideo_amd.so."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    common = [os.path.join(CSRC, h) for h in HIP_COMMON_HEADERS] + [os.path.join(INCLUDE, "slideo_amd.h")]
+    extra = os.environ.get("SLIDEO_HIP_EXTRA_FLAGS", "").split()           # (experiments: -D switches of the kernels)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc",
+             "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC] + extra
+    stamp = os.path.join(OBJDIR, "flags.txt")                              # another flag set = another build of every unit
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs, objs = [], []
+    for src in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        deps = [os.path.join(CSRC, src)] + common + [os.path.join(CSRC, h) for h in HIP_UNIT_HEADERS.get(src, [])]
+        if force or _newer(obj, deps):
+            jobs.append([_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
+    if not jobs and not _newer(HIP_LIB, objs):
         return HIP_LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC, "-o", HIP_LIB]
-    cmd += os.environ.get("SLIDEO_HIP_EXTRA_FLAGS", "").split()           # (experiments: -D switches of the kernels)
-    cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    open(stamp, "w").write(" ".join(flags))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", HIP_LIB] + objs + ["-pthread"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return HIP_LIB
 
 

@@ -290,89 +290,6 @@ inline void build_pyr_geom(int w, int h, const slideo_config& c, PyrGeom& g, std
     g.frame_bytes = ofs; g.fast_tiles = ftile; g.blur_tiles = btile; g.cand_per_frame = cand;
 }
 
-// ---- fused pyramid chains (pyr_chain_kernel, orb.hip.h) --------------------------------------------------------------
-// The pyramid is built by a few launches instead of 1 + (nlevels - 1): a block takes a PYR_TW x PYR_TH tile of a chain's BASE
-// level into LDS (for the first chain: converts it from the BGR frame — that is level 0) and produces the next <= PYR_MAX_PROD
-// levels from it, LDS to LDS, writing each level's OWNED part to the pyramid.  Per axis and level: a tile OWNS the destination
-// indices whose first source index lies in the range it owns one level up (a partition of every level: the table is
-// monotone), and NEEDS, beyond those, whatever the next level's needed indices tap (both taps: source and source + 1), which
-// grows the range to the right / bottom only, by about 2, 4.4, 7.3 pixels after one, two, three levels — hence chains of three.
-constexpr int PYR_TW = 256, PYR_TH = 32, PYR_MAX_PROD = 3;
-struct PyrSpan { int16_t own0, own1, need1, org; };     // owns [own0, own1), needs [own0, need1); LDS origin org <= own0 (x: multiple of 4)
-struct PyrChain {
-    int32_t base, nprod, from_bgr;    // levels base + 1 .. base + nprod are produced (from_bgr: base = 0 is produced too)
-    int32_t tiles_x, tiles_y;
-    int32_t xspan_ofs, yspan_ofs;     // PyrSpan entries: [tile][nprod + 1]
-    int32_t buf_bytes[2];             // LDS ping-pong buffers (chain levels of even / odd position)
-    int32_t xt_entries, yt_entries;   // LDS copies of the x / y coefficient tables of the level being produced
-};
-__host__ __device__ inline int pyr_lds_pitch(const PyrSpan& s) { return ((((int)s.need1 - (int)s.org) + 3) & ~3) + 8; }
-
-inline void pyr_chain_spans(const PyrGeom& g, const std::vector<uint32_t>& tab, bool is_x, int base, int nprod, int tile, PyrSpan* out) {
-    auto size_of = [&](int l) { return is_x ? g.lv[l].w : g.lv[l].h; };
-    auto src_of = [&](int l, int d) { return (int)(tab[(size_t)(is_x ? g.lv[l].xtab_ofs : g.lv[l].ytab_ofs) + d] & 0xffffu); };
-    const int tsize = is_x ? PYR_TW : PYR_TH;
-    int own0[PYR_MAX_PROD + 1], own1[PYR_MAX_PROD + 1], need1[PYR_MAX_PROD + 1];
-    own0[0] = std::min(tile * tsize, size_of(base)); own1[0] = std::min(own0[0] + tsize, size_of(base));
-    for (int i = 1; i <= nprod; ++i) {
-        const int l = base + i, n = size_of(l);
-        auto lower = [&](int v) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) / 2; if (src_of(l, mid) >= v) hi = mid; else lo = mid + 1; } return lo; };
-        own0[i] = lower(own0[i - 1]); own1[i] = lower(own1[i - 1]);
-    }
-    need1[nprod] = own1[nprod];
-    for (int i = nprod - 1; i >= 0; --i) {
-        need1[i] = own1[i];
-        if (need1[i + 1] > own0[i + 1]) need1[i] = std::max(need1[i], std::min(src_of(base + i + 1, need1[i + 1] - 1) + 2, size_of(base + i)));
-    }
-    for (int i = 0; i <= nprod; ++i) {
-        int org = is_x ? (own0[i] & ~3) : own0[i];
-        // x: the next level is produced in groups of 4 starting at ITS origin, and a group's source dwords start at the aligned
-        // source index of its first pixel — which may lie left of what this level owns (never read for a needed pixel, but
-        // it must be addressable)
-        if (is_x && i < nprod && need1[i + 1] > own0[i + 1]) org = std::min(org, src_of(base + i + 1, own0[i + 1] & ~3) & ~3);
-        out[i] = PyrSpan{(int16_t)own0[i], (int16_t)own1[i], (int16_t)need1[i], (int16_t)org};
-    }
-}
-
-inline void build_pyr_chains(const PyrGeom& g, const std::vector<uint32_t>& lin_tab, std::vector<PyrChain>& chains, std::vector<PyrSpan>& spans) {
-    chains.clear(); spans.clear();
-    int nvalid = 0;
-    while (nvalid < g.nlevels && g.lv[nvalid].w > 0 && g.lv[nvalid].h > 0) ++nvalid;
-    if (nvalid == 0) return;
-    int base = 0;
-    bool first = true;
-    while (first || base < nvalid - 1) {
-        PyrChain c{};
-        c.base = base; c.from_bgr = first ? 1 : 0;
-        c.nprod = std::min(first ? PYR_MAX_PROD - 1 : PYR_MAX_PROD, nvalid - 1 - base);
-        c.tiles_x = (g.lv[base].w + PYR_TW - 1) / PYR_TW; c.tiles_y = (g.lv[base].h + PYR_TH - 1) / PYR_TH;
-        const int NL = c.nprod + 1;
-        int maxpitch[PYR_MAX_PROD + 1] = {0}, maxrows[PYR_MAX_PROD + 1] = {0};
-        c.xspan_ofs = (int32_t)spans.size();
-        for (int tx = 0; tx < c.tiles_x; ++tx) {
-            PyrSpan sp[PYR_MAX_PROD + 1];
-            pyr_chain_spans(g, lin_tab, true, base, c.nprod, tx, sp);
-            for (int i = 0; i < NL; ++i) { spans.push_back(sp[i]); maxpitch[i] = std::max(maxpitch[i], pyr_lds_pitch(sp[i])); }
-        }
-        c.yspan_ofs = (int32_t)spans.size();
-        for (int ty = 0; ty < c.tiles_y; ++ty) {
-            PyrSpan sp[PYR_MAX_PROD + 1];
-            pyr_chain_spans(g, lin_tab, false, base, c.nprod, ty, sp);
-            for (int i = 0; i < NL; ++i) { spans.push_back(sp[i]); maxrows[i] = std::max(maxrows[i], (int)sp[i].need1 - (int)sp[i].own0); }
-        }
-        c.buf_bytes[0] = c.buf_bytes[1] = 16;
-        c.xt_entries = 4; c.yt_entries = 1;
-        for (int i = 0; i < NL; ++i) {
-            c.buf_bytes[i & 1] = std::max(c.buf_bytes[i & 1], (maxpitch[i] * std::max(maxrows[i], 1) + 15) & ~15);
-            if (i >= 1) { c.xt_entries = std::max(c.xt_entries, maxpitch[i]); c.yt_entries = std::max(c.yt_entries, maxrows[i]); }
-        }
-        chains.push_back(c);
-        base += c.nprod;
-        first = false;
-        if (c.nprod == 0) break;
-    }
-}
-
 // ---- INTER_AREA tap tables ([OCV A.11] computeResizeAreaTab) -----------------
 struct AreaTap { int32_t si; float alpha; };
 

@@ -24,12 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "types.h"
+
 namespace slideo {
 
-constexpr int KNN_KEY_SHIFT = 23;
-constexpr uint32_t KNN_IDX_MASK = (1u << KNN_KEY_SHIFT) - 1;
-constexpr uint32_t KNN_EMPTY = 0xFFFFFFFFu;
-constexpr int KNN_BLOCK = 256;
 
 // Insert `key` into the ascending list: new[i] = median(old[i-1], old[i], key),
 // new[0] = min(old[0], key).  Swept from the top slot down it is in place and

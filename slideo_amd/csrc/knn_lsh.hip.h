@@ -24,14 +24,6 @@ namespace slideo {
 constexpr int LSH_TIE_CAP = 1024;       // rows at the k-th distance kept in LDS; beyond it the lowest rows are found by repeated minimum passes
 constexpr int LSH_MAX_PROBES = 1 + 16 + 120;
 
-struct LshDev {
-    LshParams p;
-    int32_t nbuckets;                   // 2^kb
-    const int32_t* ofs;                 // [ntab][nbuckets + 1]
-    const int32_t* rows;                // [ntab][M]
-    const uint16_t* keys;               // [M][ntab]
-    int32_t M;
-};
 
 // grid ceil(nq_grid / 4), block 256 = 4 waves; q: [nq][8] u32, t: [M][8] u32; out: [nq][KLIST] keys ascending (KNN_EMPTY padding).
 // nq_dev != null: the query count lives on the device.

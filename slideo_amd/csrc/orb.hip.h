@@ -28,17 +28,11 @@
 #include <stdint.h>
 
 #include "geom.h"
+#include "types.h"
+#include "cv_math.hip.h"
 
 namespace slideo {
 
-struct OrbTables {             // device-resident constants (per matcher)
-    int32_t umax[68];
-    int32_t gk[8];             // 7-tap Q8 kernel of slideo_ocv_variants.blur 2 (sum 257) / 3 (sum 256); geom.h
-    float gkf[8];              // 7-tap f32 kernel of blur 0 / 1
-    int8_t pattern[1024];      // 512 (x,y)
-};
-
-struct GrayCoef { uint32_t cb, cg, cr, shift; };      // slideo_ocv_variants.gray: Q15 3735/19235/9798 or Q14 1868/9617/4899
 
 // ---------------------------------------------------------------------------
 // [OCV A.1] gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
@@ -153,124 +147,6 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
         uint8_t* d = base + dst.ofs + __umul24(y, dst.pitch) + x0;
         if (nx == 4) *reinterpret_cast<uint32_t*>(d) = outv;
         else for (int i = 0; i < nx; ++i) d[i] = (uint8_t)(outv >> (8 * i));
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Fused pyramid chain (geom.h: PyrChain): gray (first chain) + up to three INTER_LINEAR_EXACT steps per launch, LDS to LDS.
-// The arithmetic of a step is resize_kernel's (same tables, same perm / dot2 form); what changes is where the source
-// comes from — the tile of the previous level this block has just made — so a level is written once and not read back,
-// the dependent chain table -> address -> data runs against LDS, and the pyramid takes 3 launches instead of 8.
-// grid (tiles_x * tiles_y, B), block 256, dynamic LDS buf_bytes[0] + buf_bytes[1] + 8 xt_entries + 4 yt_entries.
-// ---------------------------------------------------------------------------
-template <bool FROM_BGR>
-__global__ __launch_bounds__(256) void pyr_chain_kernel(PyrGeom g, PyrChain ch, const PyrSpan* __restrict__ spans,
-                                                        const uint32_t* __restrict__ lin_tab, const uint8_t* __restrict__ frames,
-                                                        int64_t frame_stride, int stride, int aligned4, GrayCoef gc,
-                                                        uint8_t* __restrict__ pyr) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_smem[];
-    const int tid = threadIdx.x;
-    const int ty = blockIdx.x / ch.tiles_x, tx = blockIdx.x - ty * ch.tiles_x, f = blockIdx.y;
-    const int NL = ch.nprod + 1;
-    const PyrSpan* xs = spans + ch.xspan_ofs + tx * NL;
-    const PyrSpan* ys = spans + ch.yspan_ofs + ty * NL;
-    uint8_t* fp = pyr + (int64_t)f * g.frame_bytes;
-    uint8_t* buf[2] = {pyr_smem, pyr_smem + ch.buf_bytes[0]};
-    uint2* xt = reinterpret_cast<uint2*>(pyr_smem + ch.buf_bytes[0] + ch.buf_bytes[1]);
-    uint32_t* yt = reinterpret_cast<uint32_t*>(xt + ch.xt_entries);
-    auto magic_of = [](int n) -> uint32_t { return n > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)n - 1) / (uint64_t)n) : 0u; };
-    // ---- the base level's needed rectangle into buf[0]
-    {
-        const LevelGeom& L = g.lv[ch.base];
-        const PyrSpan X = xs[0], Y = ys[0];
-        const int pitch = pyr_lds_pitch(X), ng = pitch >> 2, nrows = (int)Y.need1 - (int)Y.own0;
-        const uint32_t mg = magic_of(ng);
-        const uint32_t half = 1u << (gc.shift - 1);
-        auto gray_of = [&](uint32_t b, uint32_t gg, uint32_t r) { return (b * gc.cb + gg * gc.cg + r * gc.cr + half) >> gc.shift; };
-        for (int t = tid; t < ng * nrows; t += 256) {
-            const int r = mg ? (int)__umulhi((uint32_t)t, mg) : t, gq = t - r * ng;
-            const int y = (int)Y.own0 + r, x = (int)X.org + 4 * gq;
-            uint32_t v = 0;
-            if (FROM_BGR) {
-                if (x < L.w) {
-                    const uint8_t* src = frames + (int64_t)f * frame_stride + (int64_t)y * stride + (int64_t)x * 3;
-                    if (aligned4 && x + 3 < L.w) {
-                        const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-                        const uint32_t a = s[0], b = s[1], c = s[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-                        v = gray_of(a & 255, (a >> 8) & 255, (a >> 16) & 255) | (gray_of(a >> 24, b & 255, (b >> 8) & 255) << 8) |
-                            (gray_of((b >> 16) & 255, b >> 24, c & 255) << 16) | (gray_of((c >> 8) & 255, (c >> 16) & 255, c >> 24) << 24);
-                    } else {
-                        for (int i = 0; i < 4 && x + i < L.w; ++i) v |= gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]) << (8 * i);
-                    }
-                    if (y < (int)Y.own1 && x >= (int)X.own0 && x < (int)X.own1) {      // level 0 is this chain's to write
-                        uint8_t* d = fp + L.ofs + (int64_t)y * L.pitch + x;
-                        if (x + 3 < L.w) *reinterpret_cast<uint32_t*>(d) = v;
-                        else for (int i = 0; i < 4 && x + i < L.w; ++i) d[i] = (uint8_t)(v >> (8 * i));
-                    }
-                }
-            } else {
-                const uint32_t* row = reinterpret_cast<const uint32_t*>(fp + L.ofs + (int64_t)y * L.pitch);
-                v = row[min(x >> 2, (L.pitch >> 2) - 1)];
-            }
-            reinterpret_cast<uint32_t*>(buf[0] + r * pitch)[gq] = v;
-        }
-    }
-    // ---- the produced levels
-    for (int i = 1; i <= ch.nprod; ++i) {
-        const LevelGeom& Ld = g.lv[ch.base + i];
-        const LevelGeom& Ls = g.lv[ch.base + i - 1];
-        const PyrSpan X = xs[i], Y = ys[i], PX = xs[i - 1], PY = ys[i - 1];
-        const int pitch = pyr_lds_pitch(X), nrows = (int)Y.need1 - (int)Y.own0;
-        const int nx4 = ((int)X.need1 - (int)X.org + 3) >> 2;                 // groups of 4 that hold a needed pixel
-        const int ppitch = pyr_lds_pitch(PX), maxd = (ppitch >> 2) - 1;
-        const uint8_t* src = buf[(i - 1) & 1];
-        uint8_t* dst = buf[i & 1];
-        __syncthreads();                                                      // the previous level is complete; xt / yt are free
-        const bool any = nrows > 0 && (int)X.need1 > (int)X.own0;
-        if (any) {
-            for (int t = tid; t < nx4 * 4; t += 256) {
-                const int x = min((int)X.org + t, Ld.w - 1);
-                xt[t] = make_uint2(lin_tab[Ld.xtab_ofs + x], lin_tab[Ld.xctab_ofs + x]);
-            }
-            for (int t = tid; t < nrows; t += 256) yt[t] = lin_tab[Ld.ytab_ofs + (int)Y.own0 + t];
-        }
-        __syncthreads();
-        if (!any) continue;
-        const uint32_t mg = magic_of(nx4);
-        for (int t = tid; t < nx4 * nrows; t += 256) {
-            const int r = mg ? (int)__umulhi((uint32_t)t, mg) : t, gq = t - r * nx4;
-            const int y = (int)Y.own0 + r, x = (int)X.org + 4 * gq;
-            const uint32_t ye = yt[r];
-            const int yo = ye & 0xffff, cy1 = ye >> 16, cy0 = 256 - cy1;
-            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + (yo - (int)PY.own0) * ppitch);
-            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(src + (min(yo + 1, Ls.h - 1) - (int)PY.own0) * ppitch);
-            const uint4 e01 = reinterpret_cast<const uint4*>(xt)[2 * gq], e23 = reinterpret_cast<const uint4*>(xt)[2 * gq + 1];
-            const uint32_t xe[4] = {e01.x, e01.z, e23.x, e23.z};
-            const uint32_t cp[4] = {e01.y, e01.w, e23.y, e23.w};
-            const int xa = (int)(xe[0] & 0xffff) & ~3;
-            const int d0 = max((xa - (int)PX.org) >> 2, 0), i1 = min(d0 + 1, maxd), i2 = min(d0 + 2, maxd);
-            const uint32_t a0 = p0[d0], a1 = p0[i1], a2 = p0[i2], b0 = p1[d0], b1 = p1[i1], b2 = p1[i2];
-            uint32_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // tap 2 is byte p + 1 even at the right edge: there c1 == 0, so its value is irrelevant
-                const int p = (int)(xe[k] & 0xffff) - xa;                     // 0..10 (shrink factors <= 2)
-                const bool up = p >= 4;
-                const uint32_t sel = (uint32_t)(up ? p - 4 : p) * 0x00010001u + 0x0c010c00u;   // bytes (q, 0, q+1, 0)
-                const uint32_t ta = __builtin_amdgcn_perm(up ? a2 : a1, up ? a1 : a0, sel);
-                const uint32_t tb = __builtin_amdgcn_perm(up ? b2 : b1, up ? b1 : b0, sel);
-                v[k] = __umul24(cy0, dot2_u16(ta, cp[k])) + (__umul24(cy1, dot2_u16(tb, cp[k])) + (1u << 15));
-            }
-            const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
-                                                        __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
-            reinterpret_cast<uint32_t*>(dst + r * pitch)[gq] = outv;
-            if (y < (int)Y.own1) {
-                const int w0 = max(x, (int)X.own0), w1 = min(x + 4, (int)X.own1);
-                uint8_t* d = fp + Ld.ofs + (int64_t)y * Ld.pitch + x;
-                if (w0 == x && w1 == x + 4) *reinterpret_cast<uint32_t*>(d) = outv;
-                else for (int q = w0; q < w1; ++q) d[q - x] = (uint8_t)(outv >> (8 * (q - x)));
-            }
-        }
     }
 }
 
@@ -1054,32 +930,9 @@ __global__ __launch_bounds__(1024) void sort_global_kernel(const uint32_t* __res
 }
 
 // ---------------------------------------------------------------------------
-// [OCV A.5] fastAtan2 (f32) ; [OCV A.5] ICAngles ; [OCV A.7] rotated BRIEF-256
+// [OCV A.5] ICAngles (fastAtan2: cv_math.hip.h) ; [OCV A.7] rotated BRIEF-256
 // One wave per keypoint, 4 keypoints per block.  grid ceil(Qtot/4).
 // ---------------------------------------------------------------------------
-// fma = slideo_ocv_variants.atan 1: the Horner steps (and the final 90 - P c) contracted, as a compiler does when the
-// scalar code is built for a baseline with FMA3
-__device__ __forceinline__ float fast_atan2f_cv(float y, float x, bool fma) {
-    const float s = (float)(180.0 / 3.14159265358979323846);
-    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
-                p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
-    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = fma ? __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1) * c
-                : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = fma ? __builtin_fmaf(-__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1), c, 90.f)
-                : 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
-
 // Window geometry of describe_kernel (host side: describe_window()).  The rotated pattern reaches
 // ceil(half_patch * sqrt 2) pixels from the centre and the 7x7 blur 3 more: R = that + 3.  A wave stages the
 // (2R+1) rows x wpd dwords around its keypoint (x aligned down to 4) in LDS, padded to whole wave-instructions.

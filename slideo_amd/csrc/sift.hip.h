@@ -26,7 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "orb.hip.h"
+#include "geom.h"
+#include "types.h"
+#include "cv_math.hip.h"
 
 namespace slideo {
 
@@ -196,84 +198,6 @@ __global__ __launch_bounds__(256) void sift_blur_kernel(const float* __restrict_
         for (int j = 1; j <= r; ++j) s = mad(tp.k[r + j], p[j * TW] + p[-j * TW], s);
         D[(int64_t)gy * w + gx] = s;
         if (dog) dog[(int64_t)blockIdx.y * dog_frame + (int64_t)gy * w + gx] = s - s_in[(yy + r) * iw + xx + r];
-    }
-}
-
-// The same filter for a tap count known at compile time (N = 7 .. 27, what cvRound(8 sigma + 1) | 1 gives for the pyramid's sigmas):
-// register-blocked sliding windows.  Row pass: a thread computes 8 horizontally adjacent outputs of one row from the N + 7 inputs
-// it reads once (8 N fused multiply-adds per N + 7 LDS reads instead of N per output); column pass: 8 vertically adjacent
-// outputs of one column from 8 + 2 R row-pass values held in registers.  Per output the accumulation order is the generic
-// kernel's (tap 0 .. N - 1; centre, then pairs outward): bit-identical results.  Tile 64 x 64; LDS pitches are 1 (mod 32) so
-// that the 8 x 8 (segment, row) lanes of a wave spread over all banks; the taps live in VGPRs (a scalar operand halves the
-// FMA issue rate on this chip).
-template <int N, bool FMA>
-__global__ __launch_bounds__(256) void sift_blur_fast_kernel(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst, int64_t dst_frame,
-                                                             float* __restrict__ dog, int64_t dog_frame, int w, int h, SiftTaps tp) {
-    constexpr int R = N / 2, TW = 64, TH = 64, IW = TW + 2 * R, IH = TH + 2 * R;
-    constexpr int PIN = ((IW + 30) / 32) * 32 + 1, PROW = TW + 1;
-    constexpr int IN_DW = ((IH * PIN + 63) / 64) * 64;              // whole wave-instructions of the LDS-DMA fill
-    __shared__ float s_in[IN_DW];
-    __shared__ float s_row[IH * PROW];
-    const int tiles_x = (w + TW - 1) / TW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const float* S = src + (int64_t)blockIdx.y * src_frame;
-    // The input tile goes global -> LDS by LDS-DMA (global_load_lds: no staging registers, every wave's ~35 requests in flight at
-    // once; a loop of load -> store pairs waited for each round trip and a tile took 24 us).  One instruction fills 64
-    // consecutive LDS dwords from 64 per-lane addresses: lane l of chunk `base` owns LDS dword base + l = (row, column) of the
-    // padded tile; pad columns and the tail re-read a valid pixel.
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int base = wave * 64; base < IN_DW; base += 256) {
-            const int L = base + lane;
-            const int yy = min(L / PIN, IH - 1), xx = min(L - (L / PIN) * PIN, IW - 1);
-            const float* ga = S + (int64_t)sift_reflect101(y0 - R + yy, h) * w + sift_reflect101(x0 - R + xx, w);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga, (__attribute__((address_space(3))) void*)&s_in[base], 4, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    float k[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) { k[j] = tp.k[j]; asm volatile("" : "+v"(k[j])); }
-    __syncthreads();
-    auto mad = [](float a, float b, float c) -> float { return FMA ? __builtin_fmaf(a, b, c) : a * b + c; };
-    for (int task = threadIdx.x; task < IH * (TW / 8); task += 256) {
-        const int row = task >> 3, xg = task & 7;
-        const float* p = s_in + row * PIN + xg * 8;
-        float acc[8];
-#pragma unroll
-        for (int t = 0; t < N + 7; ++t) {
-            const float v = p[t];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const int j = t - o;
-                if (j == 0) acc[o] = k[0] * v;
-                else if (j > 0 && j < N) acc[o] = mad(k[j], v, acc[o]);
-            }
-        }
-        float* q = s_row + row * PROW + xg * 8;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) q[o] = acc[o];
-    }
-    __syncthreads();
-    float* D = dst + (int64_t)blockIdx.y * dst_frame;
-    for (int task = threadIdx.x; task < TW * (TH / 8); task += 256) {
-        const int x = task & (TW - 1), yg = task / TW;
-        const int gx = x0 + x;
-        float c[8 + 2 * R];
-#pragma unroll
-        for (int t = 0; t < 8 + 2 * R; ++t) c[t] = s_row[(yg * 8 + t) * PROW + x];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            float sacc = k[R] * c[o + R];
-#pragma unroll
-            for (int j = 1; j <= R; ++j) sacc = mad(k[R + j], c[o + R + j] + c[o + R - j], sacc);
-            const int gy = y0 + yg * 8 + o;
-            if (gx < w && gy < h) {
-                D[(int64_t)gy * w + gx] = sacc;
-                if (dog) dog[(int64_t)blockIdx.y * dog_frame + (int64_t)gy * w + gx] = sacc - s_in[(yg * 8 + o + R) * PIN + x + R];
-            }
-        }
     }
 }
 

@@ -1,5 +1,5 @@
 // host_demo — drives the C++ trait-surface mirror the way crates/app/src/main.rs:69-93 drives the reference:
-//   host_demo <pages.txt | page dir> <video.slvf> [nfeatures] [min_rating] [video_hash]
+//   host_demo <pages.txt | page dir> <video.slvf> [nfeatures] [min_rating] [video_hash]      (SLIDEO_DEMO_DEVICES=0,0: the group's devices)
 //   host_demo --dump-image <file.png|.ppm>
 // pages.txt: one PPM/PNG path per line (page order); a directory is scanned like a pdftocairo target dir (p-<nr>.png).  Prints "time_ms page_nr" per timeline entry (page_nr 0 = None).
 #include <cstdio>
@@ -32,7 +32,12 @@ int main(int argc, char** argv) {
         if (argc > 4) cfg.min_rating = std::atof(argv[4]);
         uint64_t last = 0;
         slideo_host::ProgressReporter rep([&](uint64_t d, uint64_t t, const std::string& msg) { last = d; (void)t; (void)msg; });
-        slideo_host::HipImageVideoMatcher matcher(0, &cfg);
+        slideo_host::HipImageVideoMatcher matcher(-1, &cfg);             // every gfx950 device of the node, as the app would
+        if (const char* e = std::getenv("SLIDEO_DEMO_DEVICES")) {          // e.g. "0,0": two members on one device (tests)
+            std::vector<int32_t> devs;
+            for (const char* p = e; *p;) { devs.push_back((int32_t)std::strtol(p, const_cast<char**>(&p), 10)); if (*p == ',') ++p; }
+            matcher.with_devices(devs);
+        }
         auto vm = matcher.create_video_matcher(pages, rep);
         auto task = vm->match_images_with_video(argv[2], rep);
         auto out = task->process();

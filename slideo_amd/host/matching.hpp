@@ -161,11 +161,14 @@ private:
 };
 
 namespace detail {
+// one slideo_group = one matcher per GPU of the node behind one handle (include/slideo_amd.h, "N-device group"): the N-device
+// counterpart of the reference's fan-out over the global rayon pool (mo/lib.rs:45,174,213)
 struct Handle {
-    slideo_matcher* m = nullptr;
-    ~Handle() { if (m) slideo_matcher_destroy(m); }
+    slideo_group* g = nullptr;
+    int n_devices = 1;
+    ~Handle() { if (g) slideo_group_destroy(g); }
     void check(int32_t rc) const {
-        if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_last_error(m));
+        if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_group_last_error(g));
     }
 };
 inline void tramp(void* user, uint64_t d, uint64_t t, const char* msg) {
@@ -205,7 +208,7 @@ public:
         uint64_t progress = 0;
         const double step = std::floor(video.fps * interval);
         const size_t fb = (size_t)video.width * video.height * 3;
-        const int batch = 64;
+        const int batch = 64 * h_->n_devices;             // one shard of 64 sampled frames per device and call
         std::vector<uint8_t> frames, prev_small, last_small;
         std::vector<std::pair<double, size_t>> meta;
         int sw = 0, sh = 0;
@@ -216,18 +219,18 @@ public:
             if (last_small.empty()) {       // size of the small image: ask once
                 std::vector<uint8_t> tmp(fb);
                 int32_t a, b;
-                h_->check(slideo_small_image_bgr8(h_->m, frames.data(), video.width, video.height, video.width * 3, tmp.data(), (int64_t)tmp.size(), &a, &b));
+                h_->check(slideo_small_image_bgr8(slideo_group_member(h_->g, 0), frames.data(), video.width, video.height, video.width * 3, tmp.data(), (int64_t)tmp.size(), &a, &b));
                 sw = a; sh = b; last_small.resize((size_t)sw * sh * 3);
             }
-            h_->check(slideo_changed_mask_bgr8(h_->m, n, frames.data(), video.width, video.height, video.width * 3, (int64_t)fb,
+            h_->check(slideo_group_changed_mask_bgr8(h_->g, n, frames.data(), video.width, video.height, video.width * 3, (int64_t)fb,
                                                prev_small.empty() ? nullptr : prev_small.data(), last_small.data(), changed.data(), nullptr));   // video_capture.rs:86-98
             prev_small = last_small;
             std::vector<int32_t> idx;
             for (int i = 0; i < n; ++i) if (changed[i]) idx.push_back(i);
             if (!idx.empty()) {
                 std::vector<slideo_verdict> v(idx.size());
-                // mo/lib.rs:213-214 on the copy of the frames the mask call left on the device (no second upload)
-                h_->check(slideo_match_kept_frames(h_->m, (int32_t)idx.size(), idx.data(), v.data()));
+                // mo/lib.rs:213-214 on the copy of the frames the mask call left on the devices (no second upload)
+                h_->check(slideo_group_match_kept_frames(h_->g, (int32_t)idx.size(), idx.data(), v.data()));
                 for (size_t k = 0; k < idx.size(); ++k) {
                     std::optional<I> img;
                     if (v[k].page_idx >= 0) img = (*images_)[(size_t)v[k].page_idx];
@@ -280,39 +283,47 @@ private:
 // I must provide `std::string get_path() const` (matching::MatchableImage, lib.rs:31-33) and operator==.
 class HipImageVideoMatcher {
 public:
-    explicit HipImageVideoMatcher(int device = 0, const slideo_config* cfg = nullptr, ImageLoader loader = load_image_bgr)
-        : device_(device), loader_(std::move(loader)) {
+    // device >= 0: that one device; -1 (default): every gfx950 device of the node (with_devices names them explicitly)
+    explicit HipImageVideoMatcher(int device = -1, const slideo_config* cfg = nullptr, ImageLoader loader = load_image_bgr)
+        : loader_(std::move(loader)) {
+        if (device >= 0) devices_.push_back(device);
         slideo_config_default(&cfg_);
         if (cfg) cfg_ = *cfg;
     }
-    // ratio > 0: SIFT features + squared-L2 2-NN + Lowe's ratio test instead of the reference's ORB + Hamming + tolerance vote
-    // (slideo_matcher_use_sift); 0 (default) = the reference's
-    HipImageVideoMatcher& with_sift(float ratio) { sift_ratio_ = ratio; return *this; }
+    HipImageVideoMatcher& with_devices(std::vector<int32_t> devices) { devices_ = std::move(devices); return *this; }
+    // SIFT features + squared-L2 search instead of the reference's ORB + Hamming (slideo_group_use_sift).  ratio 0 (default): the
+    // path's own 5 % tolerance vote on the L2 distances — the robust choice on decks whose pages share a template; ratio in
+    // (0, 1]: Lowe's ratio test on the two nearest rows (the north_star's wording)
+    HipImageVideoMatcher& with_sift(float ratio = 0.f) { sift_on_ = true; sift_ratio_ = ratio; return *this; }
     template <class I>
     std::unique_ptr<VideoMatcher<I>> create_video_matcher(std::vector<I> images, ProgressReporter reporter) const {
         auto h = std::make_shared<detail::Handle>();
-        int32_t rc = slideo_matcher_create(&cfg_, device_, &h->m);
-        if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_last_error(nullptr));
-        if (sift_ratio_ > 0.f) {                                                                    // the north-star's SIFT + L2 + ratio-test front end
+        std::vector<int32_t> devs = devices_;
+        if (devs.empty()) for (int d = 0; d < std::max(slideo_device_count(), 1); ++d) devs.push_back(d);   // (no device at all: create reports it)
+        int32_t rc = slideo_group_create(&cfg_, (int32_t)devs.size(), devs.data(), &h->g);
+        if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_group_last_error(nullptr));
+        h->n_devices = (int)devs.size();
+        if (sift_on_) {                                                                             // the north-star's SIFT + L2 front end
             slideo_sift_config sc;
             slideo_sift_config_default(&sc);
-            h->check(slideo_matcher_use_sift(h->m, &sc, sift_ratio_));
+            h->check(slideo_group_use_sift(h->g, &sc, sift_ratio_));
         }
-        h->check(slideo_matcher_set_progress(h->m, detail::tramp, &reporter));                       // "Analyzing PDF pages..." protocol, mo/lib.rs:43-58
-        const size_t CH = 32;
+        h->check(slideo_group_set_progress(h->g, detail::tramp, &reporter));                         // "Analyzing PDF pages..." protocol, mo/lib.rs:43-58
+        const size_t CH = 32 * devs.size();
         for (size_t i = 0; i < images.size(); i += CH) {
             std::vector<Image8> dec;
             for (size_t j = i; j < std::min(images.size(), i + CH); ++j) dec.push_back(loader_(images[j].get_path()));
             std::vector<const uint8_t*> ptrs; std::vector<int32_t> w, hh, st;
             for (auto& d : dec) { ptrs.push_back(d.bgr.data()); w.push_back(d.w); hh.push_back(d.h); st.push_back(d.w * 3); }
-            h->check(slideo_matcher_add_pages_bgr8(h->m, (int32_t)dec.size(), ptrs.data(), w.data(), hh.data(), st.data()));
+            h->check(slideo_group_add_pages_bgr8(h->g, (int32_t)dec.size(), ptrs.data(), w.data(), hh.data(), st.data()));
         }
-        h->check(slideo_matcher_set_progress(h->m, nullptr, nullptr));
-        h->check(slideo_matcher_finalize_pages(h->m));                                              // FlannMatcher::new, mo/flann.rs:65-71
+        h->check(slideo_group_set_progress(h->g, nullptr, nullptr));
+        h->check(slideo_group_finalize_pages(h->g));                                              // FlannMatcher::new, mo/flann.rs:65-71
         return std::make_unique<HipVideoMatcher<I>>(h, std::make_shared<std::vector<I>>(std::move(images)));
     }
 private:
-    int device_;
+    std::vector<int32_t> devices_;
+    bool sift_on_ = false;
     float sift_ratio_ = 0.f;
     slideo_config cfg_;
     ImageLoader loader_;

@@ -102,8 +102,9 @@ def sampled_frames(video, interval_s=5.0):
 class HipVideoMatcherTask:
     """OpenCVVideoMatcherTask (lib.rs:161-246)."""
 
-    def __init__(self, matcher, images, video, progress_reporter, batch=64):
-        self._m, self._images, self._video, self._rep, self._batch = matcher, images, video, progress_reporter, batch
+    def __init__(self, matcher, images, video, progress_reporter, batch=None):
+        self._m, self._images, self._video, self._rep = matcher, images, video, progress_reporter
+        self._batch = batch or 64 * len(getattr(matcher, "devices", [0]))       # one shard of 64 sampled frames per device and call
 
     def process(self) -> List[Matching]:
         video, m = self._video, self._m
@@ -181,19 +182,22 @@ class HipVideoMatcher:
 class HipImageVideoMatcher:
     """Drop-in for OpenCVImageVideoMatcher (lib.rs:34-73) behind matching::ImageVideoMatcher."""
 
-    def __init__(self, cfg=None, device=0, sift=None):
-        """sift = (slideo_sift_config, ratio): the north-star's SIFT + L2 + ratio-test front end instead of the reference's ORB +
-        Hamming + tolerance vote (slideo_matcher_use_sift); None = the reference's."""
-        self._cfg, self._device, self._sift = cfg, device, sift
+    def __init__(self, cfg=None, device=None, sift=None, devices=None):
+        """devices: HIP ordinals, one matcher each behind one slideo_group (the reference fans out over the whole machine, the
+        global rayon pool of lib.rs:45,174); None = every gfx950 device of the node; `device` = d is short for devices = [d].
+        sift = (slideo_sift_config, ratio): the north-star's SIFT + L2 front end instead of the reference's ORB + Hamming
+        (slideo_group_use_sift; ratio 0 = the path's own tolerance vote, > 0 = Lowe's ratio test); None = the reference's."""
+        self._cfg, self._sift = cfg, sift
+        self._devices = [device] if device is not None else devices
 
     def create_video_matcher(self, images, progress_reporter: ProgressReporter) -> HipVideoMatcher:
         """images: objects with get_path() (matching::MatchableImage, lib.rs:31-33)."""
         images = list(images)
-        m = _capi.Matcher(self._cfg, self._device)
+        m = _capi.Group(self._cfg, self._devices)
         if self._sift is not None:
             m.use_sift(*self._sift)
         m.set_progress(progress_reporter.report)        # "Analyzing PDF pages..." protocol, lib.rs:43-58
-        CH = 32
+        CH = 32 * len(m.devices)
         for i in range(0, len(images), CH):
             m.add_pages([_load_bgr(str(im.get_path())) for im in images[i:i + CH]])
         if not images:

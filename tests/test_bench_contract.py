@@ -31,7 +31,8 @@ def test_single_gpu_line():
     rf = j["roofline"]
     for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
         assert k in rf, k
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] <= 1        # the EXECUTED rate (K x Mu pairs)
+    assert rf["algorithmic"]["frac"] >= rf["frac"]                                            # SURVEY 8(d)'s K x M count, reported beside it
     assert rf["traffic"] is None or isinstance(rf["traffic"], (int, float))      # HBM bytes per launch; measured for the headline only
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["verdict_agreement_with_gpu"] == 1.0
@@ -48,6 +49,20 @@ def test_two_ranks_control_flow_over_gloo():
         assert k in j, k
     assert j["n_gpus"] == 2 and j["steps"] == 2 and "cpu_baseline" not in j       # the CPU leg runs at N=1 only
     assert j["config"]["frames_per_step_per_gpu"] == 16 and j["value"] > 0
+    assert j["config"]["collective"] == {"backend": "gloo", "all_gather_of_verdicts_checked": True}
+
+
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` — no launcher, the form of the driver's recorded single-GPU command — starts the two ranks itself
+    (torch.distributed.run on 127.0.0.1) and prints the one line of rank 0 (it used to exit with a hint)."""
+    env = dict(os.environ, SLIDEO_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
     assert j["config"]["collective"] == {"backend": "gloo", "all_gather_of_verdicts_checked": True}
 
 
@@ -86,7 +101,7 @@ def test_cfg2_sift_l2_line():
     assert j["roofline"]["bound"] == "mfma" and j["roofline"]["kernel"] == "knn_l2_kernel" and j["sift_stage"]["bound"] == "hbm"
     ck = j["config"]["checked"]
     assert ck["knn_vs_numpy_64_queries"] is True and ck["sift_frame0_bit_exact_vs_cpu_restatement"] is True
-    assert j["config"]["accuracy_vs_synthetic_truth"] >= 0.75 and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["config"]["sift_vote"] == "tolerance" and j["config"]["accuracy_vs_synthetic_truth"] >= 0.85 and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
     assert set(j["stage_ms_per_batch"]) == {"sift", "l2_knn", "verify"}
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
 
@@ -100,4 +115,4 @@ def test_cfg2_full_size():
     c = j["config"]
     assert c["frames_per_step_per_gpu"] == 256 and c["pages"] == 500 and c["train_descriptors_M"] > 400000 and c["query_descriptors_per_step"] > 200000
     assert c["checked"]["knn_vs_numpy_64_queries"] is True and c["checked"]["sift_frame0_bit_exact_vs_cpu_restatement"] is True
-    assert c["accuracy_vs_synthetic_truth"] >= 0.65 and j["roofline"]["frac"] > 0.2      # (0.71: see DESIGN.md — the ratio test drops matches between template-sharing pages)
+    assert c["sift_vote"] == "tolerance" and c["accuracy_vs_synthetic_truth"] >= 0.97 and j["roofline"]["frac"] > 0.15     # (the path's own vote: 256 of 256; Lowe's test — --sift-vote ratio — reaches 0.71)

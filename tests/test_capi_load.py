@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.EXPORTS) == names
-    assert L.slideo_abi_version() == 4
+    assert L.slideo_abi_version() == 5        # ABI 5: + the N-device group (slideo_group_*, slideo_device_count); struct layouts as in 4
 
 
 def test_config_struct_matches_oracle_layout(capi, oracle):

@@ -1,0 +1,147 @@
+"""slideo_group_* — the N-device form of the matcher (include/slideo_amd.h "N-device group"): page DB replicated, pages and frames
+sharded contiguously over the member devices, verdicts gathered into the caller's array.  The reference fans the same work out
+over the global rayon pool (crates/matching-opencv/src/lib.rs:45-47,174,213).  A single-GPU box runs the groups with a repeated
+ordinal (two or three members sharing device 0): every control-flow path of an N-GPU node except the second physical device.
+Bar: bit for bit the single matcher's verdicts, traces, page features, changed flags."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(capi, pages, **over):
+    m = capi.Matcher(small_cfg(capi, **over))
+    m.add_pages(list(pages))
+    m.finalize()
+    return m
+
+
+@pytest.mark.parametrize("members", [1, 2, 3])
+def test_group_equals_single_matcher(capi, cfg0_data, members):
+    pages, frames, truth, _ = cfg0_data
+    m = _single(capi, pages)
+    g = capi.Group(small_cfg(capi), devices=[0] * members)
+    assert len(g.devices) == members
+    log = []
+    g.set_progress(lambda d, t, msg: log.append((d, t, msg)))
+    g.add_pages(list(pages[:3]))                   # two calls: shards of 3 pages, then of 1 (members with an empty share)
+    assert log[0] == (0, 3, "Analyzing PDF pages...") and log[-1] == (3, 3, "PDF page analysis successful.")
+    assert sorted(d for d, _, msg in log[1:-1]) == [1, 2, 3]
+    g.add_pages(list(pages[3:]))
+    g.set_progress(None)
+    g.finalize()
+    assert g.page_count == m.page_count == len(pages) and g.descriptor_count == m.descriptor_count
+    for r in range(members):                       # every member holds the whole deck, in page order
+        mem = g.member(r)
+        for p in range(len(pages)):
+            ka, da = m.page_features(p); kb, db = mem.page_features(p)
+            assert np.array_equal(da, db) and ka.tobytes() == kb.tobytes()
+            assert np.array_equal(m.page_small(p), mem.page_small(p))
+    v1 = m.match_frames(frames)
+    t1 = [m.last_candidates(i) for i in range(len(frames))]
+    vg = g.match_frames(frames)
+    assert vg.tobytes() == v1.tobytes()
+    for i in range(len(frames)):
+        assert g.last_candidates(i).tobytes() == t1[i].tobytes()
+    assert list(vg["page_idx"]) == list(truth)
+    # fewer frames than members: empty shards
+    v2 = g.match_frames(frames[:2])
+    assert v2.tobytes() == v1[:2].tobytes()
+    assert len(g.match_frames(frames[:0])) == 0
+    m.close(); g.close()
+
+
+def test_group_changed_mask_and_kept_frames(capi, cfg0_data):
+    """The changed-frame mask over shards (each reads the one frame before its block, video_capture.rs:86-98) and the kept
+    frames matched on the member that holds them."""
+    pages, frames, _, _ = cfg0_data
+    seq = np.stack([frames[0], frames[0], frames[1], frames[1], frames[2], frames[3], frames[3], frames[4], frames[5]])
+    m = _single(capi, pages)
+    for members in (2, 3, 4):
+        g = capi.Group(small_cfg(capi), devices=[0] * members)
+        g.add_pages(list(pages)); g.finalize()
+        with pytest.raises(capi.SlideoError) as e:
+            g.match_kept_frames([0])
+        assert e.value.code == 4
+        c1, s1, l1 = m.changed_mask(seq)
+        cg, sg, lg = g.changed_mask(seq)
+        assert list(cg) == list(c1) and np.array_equal(sg, s1) and np.array_equal(lg, l1)
+        sel = np.array([7, 0, 2, 8, 4, 5], np.int32)
+        assert g.match_kept_frames(sel).tobytes() == m.match_kept_frames(sel).tobytes()
+        # the seam of two calls: the previous call's last small image carried over
+        c2, s2, _ = m.changed_mask(seq[3:], prev_small=m.small_image(seq[2]))
+        g2, t2, _ = g.changed_mask(seq[3:], prev_small=m.small_image(seq[2]))
+        assert list(g2) == list(c2) and np.array_equal(t2, s2)
+        assert g.match_kept_frames(np.nonzero(g2)[0]).tobytes() == m.match_frames(seq[3:][c2]).tobytes()
+        g.match_frames(seq[:2])
+        with pytest.raises(capi.SlideoError):
+            g.match_kept_frames([0])                # another call uploaded frames since the mask
+        g.close()
+    m.close()
+
+
+def test_group_sift_mode_and_errors(capi, synth):
+    pages = synth.pages(5, 800, 450, seed=11)
+    frames, truth, _ = synth.frames(pages, 5, 640, 360, seed=5)
+    sc = capi.sift_config(nfeatures=300)
+    m = capi.Matcher(small_cfg(capi)); m.use_sift(sc, 0.0); m.add_pages(list(pages)); m.finalize()
+    g = capi.Group(small_cfg(capi), devices=[0, 0]); g.use_sift(sc, 0.0); g.add_pages(list(pages))
+    with pytest.raises(capi.SlideoError) as e:
+        g.match_frames(frames)                       # before finalize: every member says so
+    assert e.value.code == 4 and "member 0" in str(e.value)
+    g.finalize()
+    assert g.descriptor_count == m.descriptor_count
+    assert g.match_frames(frames).tobytes() == m.match_frames(frames).tobytes()
+    with pytest.raises(capi.SlideoError) as e:
+        capi.Group(small_cfg(capi), devices=[0, 99])
+    assert e.value.code == 1 and "member 1" in str(e.value)
+    with pytest.raises(capi.SlideoError):
+        capi.Group(small_cfg(capi), devices=[])
+    assert capi.device_count() >= 1
+    m.close(); g.close()
+
+
+def test_trait_surface_on_a_two_member_group(tmp_path, capi, synth):
+    """The host mirrors (Python and C++) drive the group API: the same timeline from one member and from two."""
+    from PIL import Image
+    from slideo_amd import build, matching as mt
+
+    class Page:
+        def __init__(self, path, nr): self.path, self.page_nr = path, nr
+        def get_path(self): return self.path
+        def __eq__(self, o): return isinstance(o, Page) and o.page_nr == self.page_nr
+
+    pages = synth.pages(4, 800, 450)
+    d = os.path.join(tmp_path, "pages"); os.makedirs(d)
+    objs = []
+    for i, p in enumerate(pages):
+        path = os.path.join(d, "p-%d.png" % (i + 1))
+        Image.fromarray(np.ascontiguousarray(p[:, :, ::-1])).save(path)
+        objs.append(Page(path, i + 1))
+    frames, truth, _ = synth.frames(pages, 6, 640, 360)
+    vid = os.path.join(tmp_path, "v.slvf")
+    mt.RawVideo.write(vid, np.repeat(frames, 10, axis=0), fps=1.0)
+    cfg = capi.default_config(nfeatures=500, min_rating=12.0)
+    outs = []
+    for devs in ([0], [0, 0]):
+        log = []
+        rep = mt.ProgressReporter(lambda a, b, c: log.append((a, b, c)))
+        vm = mt.HipImageVideoMatcher(cfg, devices=devs).create_video_matcher(objs, rep)
+        assert log[0] == (0, 4, "Analyzing PDF pages...") and log[-1] == (4, 4, "PDF page analysis successful.")
+        out = vm.match_images_with_video(vid, rep).process()
+        assert log[-1] == (12, 12, "Finished!")
+        outs.append([(mm.video_time, mm.video_frame_idx, None if mm.image is None else mm.image.page_nr) for mm in out])
+    assert outs[0] == outs[1] and len(outs[0]) >= 4
+    exe = build.build_host_demo()
+    runs = []
+    for devs in ("0", "0,0"):
+        r = subprocess.run([exe, d, vid, "500", "12"], capture_output=True, text=True, timeout=300, env=dict(os.environ, SLIDEO_DEMO_DEVICES=devs))
+        assert r.returncode == 0, r.stderr
+        runs.append(r.stdout)
+    assert runs[0] == runs[1]
+    assert [tuple(int(x) for x in ln.split()) for ln in runs[0].strip().splitlines()] == [(int(round(t * 1000)), nr or 0) for t, _, nr in outs[0]]

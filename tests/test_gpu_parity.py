@@ -731,24 +731,6 @@ def test_ransac_redraw_schedule_window_equals_fixed_point(capi, oracle, cfg0_dat
         assert ca.tobytes() == cb.tobytes()
 
 
-def test_fused_pyramid_chain_equals_per_level_kernels(capi, oracle, synth, monkeypatch):
-    """SLIDEO_PYR_CHAIN=1 builds the pyramid with pyr_chain_kernel (gray + two levels, then three levels per launch, LDS to LDS)
-    instead of one kernel per level; off by default because it measured slower, kept honest here: same pyramid, same features."""
-    pages = synth.pages(2, 1000, 700)
-    monkeypatch.setenv("SLIDEO_PYR_CHAIN", "1")
-    mc = capi.Matcher(capi.default_config(nfeatures=700))
-    monkeypatch.delenv("SLIDEO_PYR_CHAIN")
-    mp = capi.Matcher(capi.default_config(nfeatures=700))
-    for img in (pages[0], pages[1][3:, 5:].copy(), np.random.default_rng(3).integers(0, 256, (131, 257, 3), dtype=np.uint8)):
-        for lvl in range(8):
-            a, b = mc.pyramid_level(img, lvl, False), mp.pyramid_level(img, lvl, False)
-            assert a.shape == b.shape and np.array_equal(a, b), lvl
-        ka, da = mc.orb(img); kb, db = mp.orb(img)
-        assert np.array_equal(da, db) and np.array_equal(ka["x"], kb["x"]) and np.array_equal(ka["angle"], kb["angle"])
-    _cmp_orb(capi, oracle, mc, oracle.default_config(nfeatures=700), pages[0])
-    mc.close(); mp.close()
-
-
 def test_train_set_dedup_is_exact(capi, oracle, synth, monkeypatch):
     """Equal descriptors across pages (a deck that repeats pages / templates): the matcher searches the DISTINCT rows and
     restores the full-set k-NN exactly (knn.hip.h knn_expand_dups_kernel) — every copy of a row votes, in row order, as
@@ -807,6 +789,14 @@ def test_match_kept_frames_equals_a_second_upload(capi, cfg0_data):
         assert np.array_equal(ck[i], m.last_candidates(i))
     with pytest.raises(capi.SlideoError):
         m.match_kept_frames([0])                                        # the host-frame call above overwrote the staging buffer
+    # every entry point that uploads into the staging buffer invalidates the kept frames (the taps did not)
+    for tap in (lambda: m.small_image(frames[0]), lambda: m.orb(frames[0]), lambda: m.pyramid_level(frames[0], 1, False),
+                lambda: m.sift(frames[0])):
+        m.changed_mask(frames[:3])
+        tap()
+        with pytest.raises(capi.SlideoError) as e:
+            m.match_kept_frames([0])
+        assert e.value.code == 4
     m.changed_mask(frames[:3])
     with pytest.raises(capi.SlideoError):
         m.match_kept_frames([3])                                        # outside the kept frames

@@ -107,3 +107,26 @@ def test_sift_sub_batches_equal_single_frames(capi, oracle, synth, monkeypatch):
     ok, od, _ = oracle.sift(frames[3], oracle.sift_config(nfeatures=300))
     assert np.array_equal(hd[qofs[3]: qofs[4]], od)
     m.close()
+
+
+def test_sift_list_capacities_grow_on_demand(capi, oracle, cfg0_data, monkeypatch):
+    """The per-frame extrema / keypoint lists have fixed capacities (65536 / 32768: far above what a 4095 x 4095 image yields); a
+    frame beyond one re-runs the pass over the same pyramids with that list doubled instead of failing.  Started
+    at 64 / 32 entries, every image of the batch overflows several times on the way — same keypoints, same descriptors."""
+    pages, frames, _, _ = cfg0_data
+    monkeypatch.setenv("SLIDEO_SIFT_LIST_CAP", "64")
+    mm = capi.Matcher(capi.default_config())
+    for img in (frames[0], pages[2]):
+        assert _cmp(capi, oracle, mm, img) > 300
+    # as a matcher: pages and frames through the grown lists, verdicts equal to the default capacities'
+    from conftest import small_cfg
+    def run():
+        g = capi.Matcher(small_cfg(capi)); g.use_sift(capi.sift_config(nfeatures=300), 0.0)
+        g.add_pages(list(pages)); g.finalize()
+        v = g.match_frames(frames)
+        g.close()
+        return v
+    va = run()
+    monkeypatch.delenv("SLIDEO_SIFT_LIST_CAP")
+    assert run().tobytes() == va.tobytes()
+    mm.close()

@@ -91,4 +91,10 @@ def test_sift_matcher_state_and_limits(capi, synth):
         m2 = capi.Matcher(small_cfg(capi)); m2.use_sift(capi.sift_config(), 0.75)
         m2.add_page_features(640, 360, np.zeros(0, capi.KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((259, 461, 3), np.uint8))
     assert e.value.code == 5
+    # a frame side above 4095 (the doubled image's coordinates travel in 13 bits) is refused, not matched wrongly;
+    # the ORB path takes the same frame
+    wide = np.zeros((40, 4096, 3), np.uint8)
+    with pytest.raises(capi.SlideoError) as e:
+        m.match_frames(wide[None])
+    assert e.value.code == 5 and "4095" in str(e.value)
     m.close()
