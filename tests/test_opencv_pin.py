@@ -20,7 +20,8 @@ import pytest
 from PIL import Image
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-PIN = os.path.join(HERE, "golden", "opencv")
+# (SLIDEO_PIN_DIR: another dump directory — tests/test_pin_harness_selfcheck.py runs this module on the stand-in's dump)
+PIN = os.environ.get("SLIDEO_PIN_DIR") or os.path.join(HERE, "golden", "opencv")
 HAVE = os.path.exists(os.path.join(PIN, "meta.json"))
 pytestmark = pytest.mark.skipif(not HAVE, reason="tests/golden/opencv/ absent: run tools/pin_opencv.py where cv2 (4.5.2) is installed "
                                                  "and commit its output; until then parity with OpenCV is UNPINNED")

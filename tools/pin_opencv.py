@@ -7,7 +7,7 @@ which exists neither under the reference repository nor in the build image (no c
 wherever `import cv2` works — ideally `cv2.__version__ == "4.5.2"` built like ci/install-bionic.sh (SSE3 baseline, AVX2
 dispatch, IPP on) — from the repository root:
 
-    python tools/pin_opencv.py            # writes tests/golden/opencv/{meta.json, <image>.npz, points.npz}
+    python tools/pin_opencv.py [--out DIR]     # writes tests/golden/opencv/{meta.json, <image>.npz, points.npz}
 
 and commit the directory.  tests/test_opencv_pin.py then (a) names, per slideo_ocv_variants switch (include/slideo_amd.h),
 the value whose restatement reproduces OpenCV bit for bit, (b) fails if that value is not the default, and (c) compares the
@@ -67,6 +67,9 @@ def lcg_points(seed, n, w, h, a, b, tx, ty, outlier_frac):
 def main():
     import cv2
     from PIL import Image
+    global OUT
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":          # another target directory (tests/test_pin_harness_selfcheck.py)
+        OUT = sys.argv[2]
     os.makedirs(OUT, exist_ok=True)
     meta = {"cv2_version": cv2.__version__, "build_information": cv2.getBuildInformation(),
             "numpy": np.__version__, "images": IMAGES,
