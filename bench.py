@@ -40,7 +40,7 @@ WORKLOADS = {
     # BASELINE.json configs[4] shape on one GPU: 4K frames, ORB-2000, 1000-page deck (2 M train descriptors)
     # ("RANSAC homography verify": verify_model 1 = the 8-DOF model of include/slideo_amd.h on frames generated under a true
     # projective map; --verify-model 0 --persp 0 gives the reference's similarity model on similarity frames)
-    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64, verify_model=1, persp=0.1,
+    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64, verify_model=1, persp=0.1, hdlt=1,
                  name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000, homography verification"),
     # BASELINE.json configs[2]: SIFT-128 descriptors, L2 BFMatcher as an N x M x 128 MFMA contraction, 1080p vs 500 pages:
     # SIFT on the device (csrc/sift.hip.h) feeding the int8 matrix-core L2 matcher (bench_cfg2).
@@ -244,9 +244,11 @@ def main():
     ap.add_argument("--verify-model", type=int, default=-1, choices=[-1, 0, 1],
                     help="geometric model of the verification: 0 = the reference's 4-DOF similarity (estimateAffinePartial2D), 1 = 8-DOF homography "
                          "(findHomography + warpPerspective; default: the workload's, 1 for cfg4, else 0)")
-    ap.add_argument("--hdlt", type=int, default=0, choices=[0, 1, 2],
-                    help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors, "
-                         "1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample), 2 = the closed form (square-to-quad maps; cheapest)")
+    ap.add_argument("--hdlt", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors "
+                         "(the library's default: fidelity), 1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample; "
+                         "what cfg4 runs by default — end-to-end agreement with form 0 measured in profiles/r04_hdlt_agreement.json), 2 = the closed form "
+                         "(square-to-quad maps); default: the workload's, else 0")
     ap.add_argument("--matcher", default="exact", choices=["exact", "lsh"],
                     help="descriptor index: exact brute force (default; north_star) or the LSH candidate rule of the reference's FLANN index "
                          "(slideo_config.matcher 1: 6 tables, 12-bit keys, multi-probe 1 — recall < 1, and on these descriptors SLOWER than the exact "
@@ -317,6 +319,8 @@ def main():
     pages = synth.pages(P, pw, ph, threads=gen_threads)
     verify_model = wl.get("verify_model", 0) if args.verify_model < 0 else args.verify_model
     persp = wl.get("persp", 0.0) if args.persp < 0 else args.persp
+    if args.hdlt < 0:
+        args.hdlt = wl.get("hdlt", 0) if verify_model == 1 else 0
     if persp > 0:
         frames, truth, _ = synth.frames_persp(pages, B, fw, fh, persp=persp, first=rank * B, threads=gen_threads)
     else:

@@ -169,7 +169,7 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     vp.rng_len = m->rng_len;
     HIP_CHECK(hipMemsetAsync(S.d_fcs.p, 0, (size_t)n * sizeof(FrameCands), st));
     if (prof) HIP_CHECK(hipEventRecord(S.ev[1], st));
-    if (qtot > 0) unit_knn(m, S, n, qplan, qtot, async, prof);      // (records S.ev[2] behind the search when profiling)
+    if (qtot > 0) unit_knn(m, S, n, qplan, qtot, async, prof, st);      // (records S.ev[2] behind the search when profiling)
     unit_verify(m, S, vp, frames_dev, n, w, h, stride, frame_stride, qtot);
 }
 

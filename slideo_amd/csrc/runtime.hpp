@@ -226,7 +226,7 @@ void knn_build_index(slideo_matcher* m, const std::vector<uint8_t>& train, int64
 // workspace of a unit's search (before the timed interval) and the search itself: S.d_desc -> S.d_keys (+ the expansion of the
 // collapsed rows).  qplan: the query count the launch is planned for, qtot: the capacity (async) or the real count.
 void knn_reserve_unit(slideo_matcher* m, Slot& S, uint32_t qplan, uint32_t qtot);
-void unit_knn(slideo_matcher* m, Slot& S, int n, uint32_t qplan, uint32_t qtot, bool async, bool prof);
+void unit_knn(slideo_matcher* m, Slot& S, int n, uint32_t qplan, uint32_t qtot, bool async, bool prof, hipStream_t st);
 bool knn_unit_is_valu(const slideo_matcher* m, int nq);
 int knn_unit_rows(const slideo_matcher* m, int nq);        // train rows a unit's search evaluates (Mu, or M for the VALU engine)
 void l2_prepare(slideo_matcher::L2Set& L, const uint8_t* t, int nt, hipStream_t st);

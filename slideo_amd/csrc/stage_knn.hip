@@ -157,9 +157,9 @@ struct TrainOps {             // device operands of one train set, per engine
 // nq_dev != null: the real query count lives on the device (the host did not wait for the ORB counts); then `nq` is the
 // estimate the plan is made for and nq_grid the capacity the grid and the buffers cover.  Only the matrix-core engine.
 static void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, const TrainOps& T, int nt, float prune_tol,
-             const uint32_t* nq_dev = nullptr, int nq_grid = 0) {
+             const uint32_t* nq_dev = nullptr, int nq_grid = 0, hipStream_t st_arg = nullptr) {
     if (nq <= 0 && !nq_dev) return;
-    hipStream_t st = S.st;
+    hipStream_t st = st_arg ? st_arg : S.st;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
     const KnnPlan p = knn_plan(m, nq, nt, nq_grid);
     knn_reserve(m, S, nq, nt, nq_grid);
@@ -199,9 +199,8 @@ void knn_reserve_unit(slideo_matcher* m, Slot& S, uint32_t qplan, uint32_t qtot)
 
 // A unit's search: S.d_desc (n frames' descriptors, offsets S.d_qofs) -> S.d_keys.  async: the real query count lives on the
 // device (S.d_qofs[n]), qplan is what the launch is planned for and qtot the capacity the grid covers.
-void unit_knn(slideo_matcher* m, Slot& S, int n, uint32_t qplan, uint32_t qtot, bool async, bool prof) {
+void unit_knn(slideo_matcher* m, Slot& S, int n, uint32_t qplan, uint32_t qtot, bool async, bool prof, hipStream_t st) {
     const slideo_config& c = m->cfg;
-    hipStream_t st = S.st;
     const bool dedup = knn_unit_dedup(m, (int)qplan);
     const int nt_knn = knn_unit_rows(m, (int)qplan);
     // a neighbour counts iff d < best * vote_tolerance (verify.hip.h vote_kernel); with tolerance < 1 rows below the
@@ -232,7 +231,7 @@ void unit_knn(slideo_matcher* m, Slot& S, int n, uint32_t qplan, uint32_t qtot, 
             check_launch("knn_merge_kernel");
         }
     } else
-        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot);
+        run_knn(m, S, S.d_desc.as<uint32_t>(), (int)qplan, T, nt_knn, prune, async ? S.d_qofs.as<uint32_t>() + n : nullptr, (int)qtot, st);
     if (prof) HIP_CHECK(hipEventRecord(S.ev[2], st));      // the kNN interval ends here: the search kernel (+ its segment merge)
     if (dedup) {
         knn_expand_dups_kernel<KLIST><<<cdiv((int)std::max(qtot, 1u), KNN_BLOCK), KNN_BLOCK, 0, st>>>(

@@ -247,7 +247,9 @@ def test_configs2_shape_sift_matcher_traces_vs_oracle(capi, oracle, synth, deck5
     against the CPU restatement in the same mode; until r04 this size was checked by frame 0's SIFT output and 64 neighbour pairs
     inside bench.py only.  The L2 prune bound and the k <= 32 list instance are on by themselves here."""
     from conftest import small_cfg  # noqa: F401
-    pages = deck500
+    # (the tolerance vote — bench.py's default — against the whole deck; Lowe's test against its first 150 pages: the CPU leg's SIFT
+    # of 500 pages is two minutes per mode)
+    pages = deck500 if vote == "tolerance" else deck500[:150]
     B, fw, fh = 16, 1920, 1080
     frames, truth, _ = synth.frames(pages, B, fw, fh, first=3, threads=min(64, NCPU))
     ratio = 0.0 if vote == "tolerance" else 0.75
@@ -258,11 +260,11 @@ def test_configs2_shape_sift_matcher_traces_vs_oracle(capi, oracle, synth, deck5
     assert db.finalize() == 0
     m = capi.Matcher(capi.default_config())
     m.use_sift(capi.sift_config(**sk), ratio)
-    for i in range(0, 500, 50):
+    for i in range(0, len(pages), 50):
         m.add_pages(list(pages[i:i + 50]))
     m.finalize()
-    assert m.descriptor_count == db.descriptor_count > 400000
-    for p in (0, 137, 499):
+    assert m.descriptor_count == db.descriptor_count > 100000
+    for p in (0, 137, len(pages) - 1):
         gk, gd = m.page_features(p)
         ok, od = db.page_features(p)
         assert np.array_equal(gd, od) and np.array_equal(gk, ok.view(gk.dtype)), p

@@ -201,3 +201,20 @@ def test_lane_lm_equals_wave_lm(capi, oracle, synth, monkeypatch):
     assert np.array_equal(runs["0"][0], runs["1"][0])
     for ca, cb in zip(runs["0"][1], runs["1"][1]):
         assert ca.tobytes() == cb.tobytes()
+
+
+def test_sample_solver_forms_agree_end_to_end(capi, synth):
+    """hdlt 1 / 2 against cv::findHomography's own form (hdlt 0), end to end on 1080p perspective frames against a 60-page deck: the
+    models of a sample agree to f64 round-off, so candidates, inlier counts and verdicts agree except where round-off flips an
+    inlier at the 3 px threshold (tools/hdlt_agreement.py measures the headline shape: profiles/r04_hdlt_agreement.json).
+    This is what licenses bench.py --workload cfg4 to default to the cheap form."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hdlt_agreement as HA
+    pages = synth.pages(60)
+    frames, truth, _ = synth.frames_persp(pages, 24, 1920, 1080, persp=0.1, seed=3)
+    res = {h: HA.run(pages, frames, h, 1000) for h in (0, 1, 2)}
+    for h in (1, 2):
+        c = HA.compare(res[h], res[0])
+        assert c["verdict_page_agreement"] >= 0.95 and c["candidate_inlier_count_agreement"] >= 0.95, (h, c)
+        assert c["max_similarity_difference"] <= 0.05, (h, c)
