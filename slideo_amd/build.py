@@ -44,8 +44,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found; cannot build the gfx950 library")
 
 
-def build_hip(force=False, verbose=False):
-    """Compiles the changed units (in parallel) and links libslideo_amd.so."""
+def build_hip(force=False, verbose=False, tag=None):
+    """Compiles the changed units (in parallel) and links libslideo_amd.so.  tag: an experiment build (SLIDEO_HIP_EXTRA_FLAGS) into
+    lib/variants/<tag>/ — loaded through SLIDEO_LIB_PATH, the product library stays as it is (tools/ab_variants.sh)."""
+    global_lib, objdir = HIP_LIB, OBJDIR
+    if tag:
+        objdir = os.path.join(LIBDIR, "variants", tag)
+        global_lib = os.path.join(objdir, "libslideo_amd.so")
+    return _build_hip(force, verbose, global_lib, objdir)
+
+
+def _build_hip(force, verbose, HIP_LIB, OBJDIR):
     os.makedirs(OBJDIR, exist_ok=True)
     common = [os.path.join(CSRC, h) for h in HIP_COMMON_HEADERS] + [os.path.join(INCLUDE, "slideo_amd.h")]
     extra = os.environ.get("SLIDEO_HIP_EXTRA_FLAGS", "").split()           # (experiments: -D switches of the kernels)
@@ -110,4 +119,7 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     import sys
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--tag" in sys.argv:
+        print(build_hip(verbose=False, tag=sys.argv[sys.argv.index("--tag") + 1]))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

@@ -191,7 +191,10 @@ __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsi
 // A block walks FAST_TPB consecutive tiles.  The raw pixels of tile i+1 are fetched into registers right after
 // tile i's have been committed to LDS, so the global-load latency (the longest single wait of a tile: about 10 k of
 // its 25 k cycles, per-wave s_memtime profile) overlaps tile i's three phases.
-constexpr int FAST_TPB = 8;
+#ifndef FAST_TPB_V
+#define FAST_TPB_V 8
+#endif
+constexpr int FAST_TPB = FAST_TPB_V;
 constexpr int FAST_STAGE_CAP = 128;                                    // survivors staged per block before one list append (a tile keeps ~10; LDS: 8 blocks per CU)
 constexpr int FAST_NDW = FAST_RW / 4;                                  // dwords per raw row
 constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dwords per thread and tile

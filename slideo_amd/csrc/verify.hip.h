@@ -675,7 +675,10 @@ __global__ __launch_bounds__(256) void ssd_kernel(const uint8_t* __restrict__ a,
 // source row — are computed once per block into LDS for the source window of the block's 32x8 small pixels,
 // so the per-tap work is two LDS reads, two adds/shifts and one 3-byte gather.
 constexpr int RP_SPAN_X = 512, RP_SPAN_Y = 160;
-constexpr int RP_WIN_BYTES = 32 * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
+#ifndef RP_WIN_KB
+#define RP_WIN_KB 32
+#endif
+constexpr int RP_WIN_BYTES = RP_WIN_KB * 1024;      // LDS window of the frame, 4 bytes per pixel (B,G,R,0)
 constexpr int RP_PRE = 6;                    // window groups (of 4 pixels) per thread that are fetched one tile ahead
 constexpr int RP_MAX_TILES = 64;             // tiles per strip with a precomputed descriptor (small images up to 2048 px wide)
 constexpr int RP_XY_MAX = 6144;              // PERSP: source pixels of a tile whose warped coordinates are tabled in LDS (141 x 37 for 2001 -> 461)

@@ -1,12 +1,15 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/ab1
-for rep in 1 2; do for p in 0 1 2; do
-  SLIDEO_KNN_PRIO=$p python bench.py --steps 60 --warmup 6 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab1/prio${p}_$rep.json
-done; done
+cd $GRAFT_REPO_ROOT; out=gpurun_out/prof1; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python bench.py --workload cfg4 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 > $out/cfg4_hdlt1.json
+python bench.py --workload cfg4 --hdlt 2 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 > $out/cfg4_hdlt2.json
+python bench.py --workload cfg2 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $out/cfg2_tol.json
+rocprofv3 --kernel-trace --stats -d $out/s1 -o t -- python bench.py --workload cfg4 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $out/cfg4_rocprof.log 2>&1
+python profiles/summarize_rocpd.py $out/s1/t_results.db | grep -v rocclr > $out/kernel_stats_cfg4_hdlt1_no_overlap.txt
+rocprofv3 --kernel-trace --stats -d $out/s2 -o t -- python bench.py --workload cfg2 --steps 3 --warmup 1 --no-cpu-baseline > $out/cfg2_rocprof.log 2>&1
+python profiles/summarize_rocpd.py $out/s2/t_results.db | grep -v rocclr > $out/kernel_stats_cfg2_tol.txt
+rm -rf $out/s1 $out/s2
 python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/ab1/*.json')):
-    j=json.load(open(f)); r=j['roofline']
-    print(f.split('/')[-1], j['value'], j['ms_per_step'], 'knn launch', r['avg_launch_ms'], 'frac', r['frac'], 'alone', r['one_batch_in_flight']['avg_launch_ms'], j['stage_ms_per_step'])
+import json
+for f in ('cfg4_hdlt1','cfg4_hdlt2','cfg2_tol'):
+    j=json.load(open('gpurun_out/prof1/%s.json'%f)); print(f, j['value'], j['ms_per_step'], j.get('stage_ms_per_step') or j.get('stage_ms_per_batch'), j.get('stage_ms_one_batch_in_flight'), j['config'].get('accuracy_vs_synthetic_truth'))
 PY
-python tools/hdlt_agreement.py > gpurun_out/r04_hdlt_agreement.json 2> gpurun_out/r04_hdlt_agreement.err; cat gpurun_out/r04_hdlt_agreement.json
-python -m pytest tests/test_gpu_homography.py -q -x -k "sample_solver_forms" 2>&1 | tail -3
+head -32 $out/kernel_stats_cfg4_hdlt1_no_overlap.txt; head -30 $out/kernel_stats_cfg2_tol.txt
