@@ -22,13 +22,15 @@ rm -rf $out/stats $out/stats2 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmcov
   python bench.py --workload cfg4 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload tiny --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload cfg2 2>/dev/null | tail -1; } > $out/bench_other_workloads.jsonl
-# round-3 modes: the 8-DOF homography verifier (both sample solvers), the LSH-compatible index, configs[4] with either verifier
+# the modes: the 8-DOF homography verifier (the sample solvers), the LSH-compatible index, configs[4] with either verifier (its default since r04:
+# hdlt 1), configs[2] with Lowe's test instead of its default tolerance vote
 { python bench.py --verify-model 1 --hdlt 1 --persp 0.1 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --verify-model 1 --hdlt 0 --persp 0.1 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --matcher lsh --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload cfg4 --verify-model 0 --persp 0 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1
   python bench.py --workload cfg4 --hdlt 0 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
-  python bench.py --workload cfg2 --sift-vote tolerance --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; } > $out/bench_modes.jsonl
+  python bench.py --workload cfg4 --hdlt 2 --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1
+  python bench.py --workload cfg2 --sift-vote ratio --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; } > $out/bench_modes.jsonl
 rocprofv3 --kernel-trace --stats -d $out/stats3 -o t -- python bench.py --workload cfg2 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_cfg2_under_rocprof.json 2>&1
 python profiles/summarize_rocpd.py $out/stats3/t_results.db | grep -v rocclr > $out/kernel_stats_cfg2.txt
 rocprofv3 --kernel-trace --stats -d $out/stats4 -o t -- python bench.py --verify-model 1 --hdlt 1 --persp 0.1 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $out/bench_homography_under_rocprof.json 2>&1
@@ -40,3 +42,8 @@ python profiles/summarize_rocpd.py $out/stats6/t_results.db | grep -v rocclr > $
 rm -rf $out/stats3 $out/stats4 $out/stats5 $out/stats6
 python tools/host_path_rate.py > $out/host_path_rate.txt 2>&1
 tail -c 600 $out/bench_default.json; head -16 $out/kernel_stats_no_overlap.txt
+python tools/group_rate.py > $out/group_rate.txt 2>/dev/null
+python tools/hdlt_agreement.py > $out/hdlt_agreement.json 2>/dev/null
+python tools/host_path_rate.py > $out/host_path_rate.txt 2>/dev/null
+bash tools/pmc_kernels.sh > /dev/null 2>&1; cp gpurun_out/pmc_kernels.txt $out/pmc_orb_verify_kernels.txt
+python tools/stress_determinism.py 2000 > $out/stress_determinism.txt 2>&1
