@@ -145,3 +145,31 @@ def test_trait_surface_on_a_two_member_group(tmp_path, capi, synth):
         runs.append(r.stdout)
     assert runs[0] == runs[1]
     assert [tuple(int(x) for x in ln.split()) for ln in runs[0].strip().splitlines()] == [(int(round(t * 1000)), nr or 0) for t, _, nr in outs[0]]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_group_random_shards(capi, synth, seed):
+    """A seeded sweep over member counts, deck splits across add_pages calls, frame counts (fewer frames than members included),
+    changed-mask runs with repeated frames and random kept selections: the shard arithmetic of capi_group.hip against one matcher."""
+    rng = np.random.default_rng(4200 + seed)
+    members = int(rng.integers(1, 6))
+    n_pages = int(rng.integers(1, 8))
+    pages = synth.pages(n_pages, 800, 450, seed=int(rng.integers(1, 1 << 30)))
+    frames, _, _ = synth.frames(pages, int(rng.integers(1, 14)), 640, 360, seed=int(rng.integers(1, 1 << 30)))
+    cfg = small_cfg(capi, nfeatures=int(rng.choice([200, 500])))
+    m = capi.Matcher(cfg); g = capi.Group(cfg, devices=[0] * members)
+    cut = int(rng.integers(0, n_pages + 1))
+    for part in (pages[:cut], pages[cut:]):
+        m.add_pages(list(part)); g.add_pages(list(part))          # (an empty call is legal)
+    m.finalize(); g.finalize()
+    assert g.descriptor_count == m.descriptor_count
+    n = int(rng.integers(0, len(frames) + 1))
+    assert g.match_frames(frames[:n]).tobytes() == m.match_frames(frames[:n]).tobytes()
+    seq = frames[rng.integers(0, len(frames), int(rng.integers(1, 12)))]          # repeated frames: runs of "unchanged"
+    prev = m.small_image(frames[0]) if rng.integers(0, 2) else None
+    c1, s1, l1 = m.changed_mask(seq, prev_small=prev)
+    cg, sg, lg = g.changed_mask(seq, prev_small=prev)
+    assert list(cg) == list(c1) and np.array_equal(sg, s1) and np.array_equal(lg, l1)
+    sel = rng.permutation(len(seq))[: int(rng.integers(0, len(seq) + 1))].astype(np.int32)
+    assert g.match_kept_frames(sel).tobytes() == m.match_kept_frames(sel).tobytes()
+    m.close(); g.close()
