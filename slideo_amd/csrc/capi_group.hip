@@ -79,7 +79,12 @@ void for_each_member(slideo_group* g, F fn) {
     if (n == 1) body(0);
     else {
         std::vector<std::thread> th;
-        for (int r = 0; r < n; ++r) th.emplace_back(body, r);
+        th.reserve((size_t)n);
+        try {
+            for (int r = 0; r < n; ++r) th.emplace_back(body, r);
+        } catch (...) {                                     // (a thread could not be started: the members it would have driven run here)
+            for (int r = (int)th.size(); r < n; ++r) body(r);
+        }
         for (auto& t : th) t.join();
     }
     for (int r = 0; r < n; ++r)
