@@ -494,7 +494,7 @@ int32_t     slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_
  * One matcher per device behind ONE handle: what the reference's fan-out over every core of the machine becomes on a node
  * with several GPUs (rayon: one task per changed frame, mo/lib.rs:174,213; pages par_iter, mo/lib.rs:45-47).  The page
  * database is replicated on every member device, a call's frames are cut into contiguous shards — member r
- * takes frames [r n / N, (r + 1) n / N), block sizes differing by at most one — each shard runs through its device's matcher
+ * takes the r-th contiguous block, the blocks differing in size by at most one (the first n mod N take one more) — each shard runs through its device's matcher
  * on a host thread of its own, and every shard's verdicts land in the caller's array at the shard's offset: the gather of the
  * in-process form is the device-to-host copy each member makes anyway.  Page analysis is sharded the same way and every
  * member appends the whole call in page order.  Results are those of a single matcher, bit for bit, whatever N is.
