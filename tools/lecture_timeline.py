@@ -8,7 +8,7 @@ One process, or sharded: rank r of `world` takes a contiguous block of the sampl
 the whole page DB, and the ranks exchange ONE all-gather of per-frame records.  tests/test_gpu_big_shapes.py
 runs the sharded form with two ranks that both drive the HIP library on one GPU (gloo) and compares with the one-process run.
 
-usage (GPU box): python tools/lecture_timeline.py [--pages 200] [--hours 2] > gpurun_out/lecture.json
+usage (GPU box): python tools/lecture_timeline.py [--pages 200] [--hours 2] [--devices 0,0] > gpurun_out/lecture.json
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -104,8 +104,10 @@ def timeline_from_samples(page_of, n_samples, imgs):
     return dedup_timeline(results)
 
 
-def build_matcher(pages, nfeatures=1000, device=0):
-    m = _capi.Matcher(_capi.default_config(nfeatures=nfeatures), device=device)
+def build_matcher(pages, nfeatures=1000, device=0, devices=None):
+    """one matcher, or — `devices` given — the N-device group of include/slideo_amd.h (same calls, frames sharded inside)"""
+    cfg = _capi.default_config(nfeatures=nfeatures)
+    m = _capi.Group(cfg, devices=devices) if devices else _capi.Matcher(cfg, device=device)
     for i in range(0, len(pages), 50):
         m.add_pages(list(pages[i:i + 50]))
     m.finalize()
@@ -117,12 +119,14 @@ def main():
     ap.add_argument("--pages", type=int, default=200)
     ap.add_argument("--hours", type=float, default=2.0)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--devices", default="", help="comma-separated ordinals: run through slideo_group_* (an ordinal may repeat)")
     a = ap.parse_args()
+    devices = [int(x) for x in a.devices.split(",") if x != ""]
     S = int(a.hours * 3600 / INTERVAL)                       # sampled frames
     pages = synth.pages(a.pages, 2001, 1125, threads=64)
     visits = make_visits(S, a.pages)
     t0 = time.time()
-    m = build_matcher(pages)
+    m = build_matcher(pages, devices=devices)
     t_db = time.time() - t0
     imgs = [Page(i + 1) for i in range(a.pages)]
     changed, page_of, t_gpu, t_gen = run_shard(m, pages, visits, S, 0, 1, a.batch)
@@ -137,6 +141,7 @@ def main():
            "missing": len(want - got), "spurious": len(got - want), "videos_mapping_rows": len(rows),
            "page_db_build_s": round(t_db, 2), "gpu_path_s_incl_h2d": round(t_gpu, 2), "frame_synthesis_s": round(t_gen, 1),
            "sampled_frames_per_s_incl_h2d": round(S / t_gpu, 1),
+           "devices": devices or [0], "boundary": "slideo_group_*" if devices else "slideo_matcher_*",
            "note": "host frames in, mask + match + timeline out; the mask call and the H2D copies are inside gpu_path_s"}
     print(json.dumps(out))
 
