@@ -126,6 +126,8 @@ uint32_t kp_cap_for(const slideo_matcher* m, const PyrGeom& g) {
 
 void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, int w, int h, int stride, int64_t frame_stride,
                  bool allow_async) {
+    // (does this unit share the chip with others?  the search then runs one block per CU: stage_knn.hip share_pad)
+    { bool others = m->units_pending; for (const Slot& o : m->slots) others |= (&o != &S && o.busy); S.u_shared = others; }
     if (m->sift_on) { unit_submit_sift(m, S, frames_dev, n, w, h, stride, frame_stride); return; }
     const slideo_config& c = m->cfg;
     hipStream_t st = S.st;
@@ -257,6 +259,7 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
         }
     int done = 0;
     const bool src_pinned = !on_device && host_is_pinned(frames);
+    m->units_pending = n > unit;
     try {
         for (int i = 0; i < n; i += unit) {
             const int cnt = std::min(unit, n - i);
@@ -287,7 +290,9 @@ void match_frames_impl(slideo_matcher* m, int n, const uint8_t* frames, bool on_
             done += p.S->n;
             if (m->progress) m->progress(m->progress_user, (uint64_t)done, (uint64_t)n, "Processing frames...");
         }
+        m->units_pending = false;
     } catch (...) {
+        m->units_pending = false;
         (void)hipStreamSynchronize(m->copy_st);          // (DMA from the caller's pinned buffer may still be running)
         for (Slot& S : m->slots) { (void)hipStreamSynchronize(S.st); S.busy = false; }
         throw;
@@ -408,6 +413,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     mm->cfg = *cfg; mm->device = device;
     // environment switches of a matcher (include/slideo_amd.h, "Environment"); none changes a result
     { const long v = env_long("SLIDEO_KNN_ENGINE", 0); if (v >= 0 && v <= 3) mm->knn_engine = (int)v; }
+    { const long v = env_long("SLIDEO_KNN_SHARE", -1); if (v >= -1 && v <= 1) mm->knn_share = (int)v; }
     mm->async_submit = env_long("SLIDEO_ASYNC_SUBMIT", 1) != 0;
     mm->knn_dedup = env_long("SLIDEO_KNN_DEDUP", 1) != 0;
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
@@ -437,7 +443,13 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     API_CATCH(nullptr)
 }
 
+#ifdef KT_PROBE
+extern "C++" { namespace slideo { void knn_probe_report(); } }
+#endif
 void slideo_matcher_destroy(slideo_matcher* m) {
+#ifdef KT_PROBE
+    if (m) { (void)hipDeviceSynchronize(); slideo::knn_probe_report(); }
+#endif
     if (!m) return;
     (void)hipSetDevice(m->device);
     for (Slot& S : m->slots) {

@@ -66,6 +66,14 @@ constexpr int KT_TPS = KT_ST_ROWS / 32;        // tiles per super-tile
 constexpr int KT_PEND_CAP = (KT_FLUSH_AT - 1 + (KT_ST_ROWS / 32) * 16 + 7) & ~7;   // = 80;               // >= KT_FLUSH_AT - 1 + KT_TPS * 16 (flush test once per super-tile; a lane pushes <= 16 keys per tile and query)
 constexpr float KT_PAD_NORM = 1024.f;          // norm of the pad rows: no distance bound (<= 512) admits them
 
+#ifdef KT_PROBE        /* experiment: where a wave's cycles go (s_memtime), summed over all waves of all launches */
+__device__ unsigned long long kt_probe[8];
+#define KT_T0(v) const unsigned long long v = __builtin_readcyclecounter()
+#define KT_T1(i, v) kt_acc[i] += __builtin_readcyclecounter() - v
+#else
+#define KT_T0(v)
+#define KT_T1(i, v)
+#endif
 template <int NT> constexpr int knn_qpb() { return KT_WAVES * 32 * NT; }                         // queries per block
 template <int NT> constexpr size_t knn_pend_words_per_wave() { return (size_t)NT * KT_PEND_CAP * 64; }
 
@@ -203,6 +211,10 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     // ORB stage's counts); blocks past the last query leave at once — before any barrier, the test is block-uniform
     if (nq_dev) nq = (int)*nq_dev;
     if ((int)blockIdx.x * knn_qpb<NT>() >= nq) return;
+#ifdef KT_PROBE
+    unsigned long long kt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    KT_T0(kt_all);
+#endif
     constexpr int G = NT / 2;                                          // accumulators per skew group
     __shared__ uint4 lds[KT_RING][KT_ST_U4];
     __shared__ __attribute__((aligned(16))) uint32_t lds_side[KT_RING][KT_SIDE_U32];
@@ -348,18 +360,31 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     for (int j = 0; j < KT_AHEAD && j < nst; ++j) stage(j, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int j = 0; j < KT_AHEAD && j < nst; ++j) signal(&s_filled[j]);
-    auto acquire = [&](int j) {                                        // group A is about to read super-tile j
+    // e_done / e_filled: the two counters as read one tile EARLIER (counters only grow, so an early value that already meets the
+    // target is as good as a fresh one; a wave that tests a fresh read pays the LDS round trip — behind the operand reads of
+    // every wave of the CU — twice per super-tile with its matrix pipe idle: a quarter of a wave's time at 2 waves per SIMD)
+    auto acquire = [&](int j, uint32_t e_done, uint32_t e_filled) {    // group A is about to read super-tile j
         const int jp = j - 1 + KT_AHEAD, jn = j + KT_AHEAD;
         if (j > 0 && jp < nst) {                                       // publish this wave's share staged at acquire(j - 1)
+            KT_T0(t_a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KT_T1(1, t_a);
             signal(&s_filled[jp % KT_RING]);
         }
         if (jn < nst) {                                                // the slot was last read for super-tile jn - KT_RING
-            wait_ge(&s_done[jn % KT_RING], (uint32_t)KT_WAVES * (uint32_t)(jn / KT_RING));
+            KT_T0(t_b);
+            const uint32_t tgt = (uint32_t)KT_WAVES * (uint32_t)(jn / KT_RING);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)e_done) < tgt) wait_ge(&s_done[jn % KT_RING], tgt);
+            KT_T1(2, t_b);
             stage(jn, jn % KT_RING);
         }
-        wait_ge(&s_filled[j % KT_RING], (uint32_t)KT_WAVES * (uint32_t)(j / KT_RING + 1));
+        KT_T0(t_c);
+        const uint32_t tgf = (uint32_t)KT_WAVES * (uint32_t)(j / KT_RING + 1);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)e_filled) < tgf) wait_ge(&s_filled[j % KT_RING], tgf);
+        asm volatile("" ::: "memory");
+        KT_T1(3, t_c);
     };
+    auto peek = [&](const uint32_t* f) -> uint32_t { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto mfma = [&](Acc acc, const uint4& f, const typename M::Bop& b) { return M::mfma(acc, f, b); };
     // maxima of the raw bit patterns: triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
     // (only the overall maximum is kept: the slow path recomputes the triple maxima it gates on — ten registers per skew group
@@ -465,9 +490,11 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             bool any_ = false;                                                                                        \
             _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) any_ |= mx_[g_] > ti_[g_];                               \
             if (__builtin_amdgcn_ballot_w64(any_) != 0ull) {                                                          \
+                KT_T0(t_s);                                                                                           \
                 _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_)                                                      \
                     if (__builtin_amdgcn_ballot_w64(mx_[g_] > ti_[g_]) != 0ull)                                       \
                         candidates(a[GB + g_], ti_[g_], sd_, tt_, h[GB + g_], GB + g_, pend(GB + g_));                \
+                KT_T1(4, t_s);                                                                                        \
             }                                                                                                         \
         }
         // One tile (tt = its index in the super-tile, compile time): (c*) = F(t) are live on entry, (n*) = F(t + 1) on exit;
@@ -498,7 +525,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                 KT_TEST(G, sdc, tt)                                                                                   \
             }                                                                                                         \
         }
-        acquire(0);
+        acquire(0, 0u, 0u);
         const uint4* Lc = lds[0] + lane;
         uint4 x0 = Lc[0], x1 = Lc[64], x2 = Lc[128], x3 = Lc[192];                                 // F(t)
         uint4 y0, y1, y2, y3;                                                                      // F(t + 1)
@@ -513,15 +540,22 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             const uint4* Ln = j + 1 < nst ? lds[(j + 1) % KT_RING] + lane : Lc + (KT_TPS - 1) * 256;
             KT_TILE(0, x0, x1, x2, x3, y0, y1, y2, y3)
             KT_TILE(1, y0, y1, y2, y3, x0, x1, x2, x3)
+            uint32_t e_done = 0, e_filled = 0;                           // (0 never meets a positive target: the fresh read decides)
+            if (j + 1 < nst) {
+                e_filled = peek(&s_filled[(j + 1) % KT_RING]);
+                if (j + 1 + KT_AHEAD < nst) e_done = peek(&s_done[(j + 1 + KT_AHEAD) % KT_RING]);
+            }
             KT_TILE(2, x0, x1, x2, x3, y0, y1, y2, y3)
-            if (j + 1 < nst) acquire(j + 1);                           // group A enters the next super-tile in tile 3
+            if (j + 1 < nst) acquire(j + 1, e_done, e_filled);         // group A enters the next super-tile in tile 3
             KT_TILE(3, y0, y1, y2, y3, x0, x1, x2, x3)
             signal(&s_done[slot]);
             bool need = false;
 #pragma unroll
             for (int i = 0; i < NT; ++i) need |= cnt_of(cntp, i) >= (uint32_t)KT_FLUSH_AT;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                KT_T0(t_f);
                 flush();
+                KT_T1(5, t_f);
                 // everything the loop carries is rebuilt after the (rare) flush instead of kept alive across it: the flush
                 // needs 32 registers for the list, and values live across it would be spilled on every path
                 load_queries();
@@ -536,6 +570,11 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
 #undef KT_MFMAS
     }
     flush();
+#ifdef KT_PROBE
+    KT_T1(0, kt_all);
+    kt_acc[6] = 1;
+    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&kt_probe[i], kt_acc[i]);
+#endif
 }
 
 // The two wave shapes.  KT4_VGPRS caps the 4-tile shape's register allocation: at 2 waves per SIMD the compiler would take up

@@ -69,7 +69,7 @@ struct Slot {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_up = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
-    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0;
+    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0; bool u_shared = false;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys, d_tail, d_refine;
     PinBuf h_info, h_out;
@@ -147,6 +147,8 @@ struct slideo_matcher {
     // the frames slideo_changed_mask_bgr8 uploaded last (slot 0's staging buffer), for slideo_match_kept_frames
     struct Kept { bool valid = false; int n = 0, w = 0, h = 0, stride = 0; } kept;
     slideo::DevBuf d_kept;
+    bool units_pending = false;   // the call being served has more units than the one submitted now
+    int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one (SLIDEO_KNN_SHARE)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)

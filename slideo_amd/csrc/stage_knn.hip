@@ -90,6 +90,28 @@ static void build_lsh_set(const slideo_config& c, const uint8_t* t_host, int nt,
     S.ready = true;
 }
 
+// One search block per CU instead of two (knn_tile.hip.h: 2 instead of 4 waves per SIMD) while other units are in flight: two
+// blocks hold every register of a CU (4 waves x 128 per SIMD), so the ORB and verify kernels of the other units cannot share
+// a CU with them and run in the gaps the search launches leave.  With one block the other half of the registers and 72 KB of
+// LDS stay free; the search alone is slower (9.4 instead of 7.9 ms for the headline launch), the step of overlapped units
+// is 5 % shorter (profiles/r04_experiments.txt).  The block count is capped through the launch's dynamic LDS size: the
+// kernel's own 70 KB + this pad exceed half of the CU's 160 KB.  The exact Hamming search only: the LSH-filtered stream is
+// VALU-bound on its row filter and dominates its step (one block per CU: 26.2 instead of 21.4 ms per step), and the SIFT
+// matcher's step is its extraction stage (L2 search one or two blocks per CU: 73.3 ms either way).
+constexpr unsigned KT_SHARE_PAD = 16 * 1024;
+static_assert(KT_RING * (KT_ST_U4 * 16 + KT_SIDE_U32 * 4) + KT_SHARE_PAD > 160 * 1024 / 2, "the pad must push a block past half of the CU's LDS");
+#ifdef KT_PROBE
+void knn_probe_report() {
+    unsigned long long v[8] = {0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(slideo::kt_probe), sizeof(v)) != hipSuccess || !v[6]) return;
+    const double w = (double)v[6];
+    fprintf(stderr, "KT_PROBE waves %.0f  cycles per wave: total %.0f  vmcnt %.0f  wait_done %.0f  wait_filled %.0f  slow %.0f  flush %.0f\n",
+            w, v[0] / w, v[1] / w, v[2] / w, v[3] / w, v[4] / w, v[5] / w);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(slideo::kt_probe), z, sizeof(z));
+}
+#endif
+static unsigned share_pad(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 1 || (m->knn_share < 0 && S.u_shared)) ? KT_SHARE_PAD : 0u; }
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // Engine 0 ("mfma") = the 2-tile wave shape (knn_tile2_kernel: 4 waves/SIMD, two 512-query blocks per CU) at every size: since the
 // {0,1} operand alphabet it runs the headline launch in 10.0 ms alone against 11.3 for the 4-tile shape and the step is 2 %
@@ -169,7 +191,7 @@ static void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, c
             knn_tile4_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
         else
-            knn_tile2_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+            knn_tile2_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, share_pad(m, S), st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
         check_launch("knn_tile_kernel");
         if (p.nseg > 1) {

@@ -770,6 +770,25 @@ def test_train_set_dedup_is_exact(capi, oracle, synth, monkeypatch):
     m0.close()
 
 
+def test_search_blocks_per_cu_modes_agree(capi, oracle, cfg0_data, monkeypatch):
+    """SLIDEO_KNN_SHARE: the exact Hamming search with one block per CU (what units that share the chip with others get:
+    stage_knn.hip share_pad) or two — the launch's LDS size is all that differs; verdicts and traces against the oracle, and a
+    call of several units (where the default switches by itself) equal to both."""
+    pages, frames, truth, _ = cfg0_data
+    big = np.concatenate([frames] * 12)                                 # > one 64-frame unit: units in flight together
+    out = {}
+    for mode in ("0", "1", None):
+        if mode is not None: monkeypatch.setenv("SLIDEO_KNN_SHARE", mode)
+        m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
+        if mode is not None: monkeypatch.delenv("SLIDEO_KNN_SHARE")
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v)
+        out[mode] = (v.tobytes(), m.match_frames(big).tobytes())
+        m.close()
+    assert out["0"] == out["1"] == out[None]
+    assert out[None][1] == out[None][0] * 12
+
+
 def test_match_kept_frames_equals_a_second_upload(capi, cfg0_data):
     """slideo_match_kept_frames: the frames the changed-mask call uploaded are matched from the device copy — same verdicts
     and traces as uploading the changed subset again (what process() did before), in any selection order."""
