@@ -51,10 +51,6 @@ constexpr int KT_ST_ROWS = 128;                // rows per super-tile (the unit 
 #endif
 constexpr int KT_RING = KT_RING_V;             // LDS ring slots (super-tiles resident per block)
 constexpr int KT_AHEAD = KT_AHEAD_V;           // a super-tile is staged this many iterations before it is consumed
-#ifndef KT_MFMA_PRIO_V
-#define KT_MFMA_PRIO_V 1
-#endif
-constexpr int KT_MFMA_PRIO = KT_MFMA_PRIO_V;                // wave priority while its MFMAs are issued (0 elsewhere)
 constexpr int KT_ST_U4 = KT_ST_ROWS * 128 / 16;  // uint4 per super-tile of operand (1024)
 constexpr int KT_SIDE_U32 = 2 * KT_ST_ROWS;    // per super-tile: 128 f32 norms, then 128 i32 original rows
 #ifndef KT_FLUSH_AT_V
@@ -68,6 +64,7 @@ constexpr float KT_PAD_NORM = 1024.f;          // norm of the pad rows: no dista
 
 #ifdef KT_PROBE        /* experiment: where a wave's cycles go (s_memtime), summed over all waves of all launches */
 __device__ unsigned long long kt_probe[8];
+__device__ unsigned int kt_wave[64][8][4];            // per block (the first 64 of a launch) and wave: total, slow, wait_done, wait_filled (x 1024 cycles)
 #define KT_T0(v) const unsigned long long v = __builtin_readcyclecounter()
 #define KT_T1(i, v) kt_acc[i] += __builtin_readcyclecounter() - v
 #else
@@ -214,6 +211,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
 #ifdef KT_PROBE
     unsigned long long kt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     KT_T0(kt_all);
+    const unsigned long long kt_wall = wall_clock64();
 #endif
     constexpr int G = NT / 2;                                          // accumulators per skew group
     __shared__ uint4 lds[KT_RING][KT_ST_U4];
@@ -506,25 +504,26 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             n0 = Lx_[0]; n1 = Lx_[64];                                                                                \
             const uint32_t nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                  \
             {                                                                                                         \
-                __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);                                                             \
                 KT_MFMAS(G, c0, c1, c2, c3)                                                                            \
                 KT_TREES(0, nmh_)                                                                                     \
                 KT_INTERLEAVE                                                                                         \
                 _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) asm volatile("" : "+v"(a[G + g_]));   /* keeps the MFMAs above the branch below */ \
-                __builtin_amdgcn_s_setprio(0);                                                                        \
                 n2 = Lx_[128]; n3 = Lx_[192];                                                                         \
                 KT_TEST(0, sdc, tt)                                                                                   \
             }                                                                                                         \
             {                                                                                                         \
-                __builtin_amdgcn_s_setprio(KT_MFMA_PRIO);                                                             \
                 KT_MFMAS(0, n0, n1, n2, n3)                                                                            \
                 KT_TREES(G, nmh_)                                                                                     \
                 KT_INTERLEAVE                                                                                         \
                 _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) asm volatile("" : "+v"(a[g_]));                      \
-                __builtin_amdgcn_s_setprio(0);                                                                        \
                 KT_TEST(G, sdc, tt)                                                                                   \
             }                                                                                                         \
         }
+        // Wave priority: the two waves a block has on a SIMD (w and w + 4) lead in turns, one super-tile each.  With equal
+        // priorities the arbiter favours the older wave (0 .. 3): it runs ahead until the ring stops it (15 % of its time
+        // waiting for a slot, against 5 % for waves 4 .. 7 — per-wave s_memtime sums, profiles/r04_experiments.txt) and the
+        // SIMD then runs ONE wave's instruction stream; taking turns keeps both within a super-tile of each other.
+        static_assert(KT_WAVES == 8, "waves w and w + 4 share a SIMD");
         acquire(0, 0u, 0u);
         const uint4* Lc = lds[0] + lane;
         uint4 x0 = Lc[0], x1 = Lc[64], x2 = Lc[128], x3 = Lc[192];                                 // F(t)
@@ -533,6 +532,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
 #pragma unroll 1
         for (int j = 0; j < nst; ++j) {
             const int slot = j % KT_RING;
+            if ((j ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
             Lc = lds[slot] + lane;
             const uint32_t* sdc = lds_side[slot];
             const uint4 nm4 = nminh[st0 + j];                          // (wave-uniform address: scalar loads; float / int bit patterns)
@@ -572,8 +572,9 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     flush();
 #ifdef KT_PROBE
     KT_T1(0, kt_all);
-    kt_acc[6] = 1;
-    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&kt_probe[i], kt_acc[i]);
+    kt_acc[6] = 1; kt_acc[7] = wall_clock64() - kt_wall;
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&kt_probe[i], kt_acc[i]);
+    if (lane == 0 && blockIdx.x >= 100 && blockIdx.x < 164 && blockIdx.y == 0) { unsigned int* w = kt_wave[blockIdx.x - 100][wave]; w[0] = (unsigned)(kt_acc[0] >> 10); w[1] = (unsigned)(kt_acc[4] >> 10); w[2] = (unsigned)(kt_acc[2] >> 10); w[3] = (unsigned)(kt_acc[3] >> 10); }
 #endif
 }
 

@@ -107,6 +107,14 @@ void knn_probe_report() {
     const double w = (double)v[6];
     fprintf(stderr, "KT_PROBE waves %.0f  cycles per wave: total %.0f  vmcnt %.0f  wait_done %.0f  wait_filled %.0f  slow %.0f  flush %.0f\n",
             w, v[0] / w, v[1] / w, v[2] / w, v[3] / w, v[4] / w, v[5] / w);
+    fprintf(stderr, "KT_PROBE s_memtime ticks per 100 MHz wall tick: %.3f (x 100 MHz = the shader clock the waves saw, if s_memtime counts it)\n", (double)v[0] / (double)std::max<unsigned long long>(v[7], 1));
+    static unsigned int ww[64][8][4];
+    if (hipMemcpyFromSymbol(ww, HIP_SYMBOL(slideo::kt_wave), sizeof(ww)) == hipSuccess)
+        for (int b = 0; b < 64; b += 7) {
+            fprintf(stderr, "KT_WAVE block %3d:", 100 + b);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, "  [%u s%u d%u f%u]", ww[b][k][0], ww[b][k][1], ww[b][k][2], ww[b][k][3]);
+            fprintf(stderr, "\n");
+        }
     unsigned long long z[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(slideo::kt_probe), z, sizeof(z));
 }
