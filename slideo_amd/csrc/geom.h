@@ -302,7 +302,14 @@ struct AreaGeom {        // one per distinct (source size -> small size) class
     int32_t xtap_ofs, xidx_ofs;   // taps (AreaTap) and per-dx start indices (dw+1 ints), generic path
     int32_t ytap_ofs, yidx_ofs;
     int32_t max_xtaps, max_ytaps;
+    // re-projection through a tile of the WARPED image (verify.hip.h reproject_vt_kernel): the largest source span of a 32 x 8
+    // tile of small pixels, and whether the class fits that kernel's limits (else reproject_kernel's frame window does it)
+    int32_t vt_ok, vt_spw, vt_sph;
 };
+
+// limits of reproject_vt_kernel: a thread prefetches VT_CG x VT_RI source pixels of a tile (32-column groups x 8-row steps)
+constexpr int AREA_TW = 32, AREA_TH = 8;       // small pixels per tile (= SM_TW x SM_TH of verify.hip.h)
+constexpr int VT_CG = 5, VT_RI = 5, VT_PX = 6144;
 
 // variant = slideo_ocv_variants.area: 0 = computeResizeAreaTab, 1 = exact box-overlap weights (no 1e-3 cut-off)
 inline void area_taps(int ssize, int dsize, double scale, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int& max_taps, int variant = 0) {
@@ -359,6 +366,22 @@ inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vect
         std::vector<AreaTap> t; std::vector<int32_t> i; area_taps(h, a.dh, scale_y, t, i, a.max_ytaps, variant);
         taps.insert(taps.end(), t.begin(), t.end()); idx.insert(idx.end(), i.begin(), i.end());
     }
+    // source spans of the tiles; the taps of an output are consecutive source pixels (computeResizeAreaTab: optional left
+    // fraction, whole pixels, optional right fraction) — checked, reproject_vt_kernel addresses them as first + k
+    auto span = [&](int tap_ofs, int idx_ofs, int dsize, int tile, bool& consecutive) {
+        int mx = 0;
+        for (int d0 = 0; d0 < dsize; d0 += tile) {
+            const int d1 = std::min(dsize, d0 + tile) - 1;
+            mx = std::max(mx, taps[tap_ofs + idx[idx_ofs + d1 + 1] - 1].si - taps[tap_ofs + idx[idx_ofs + d0]].si + 1);
+        }
+        for (int d = 0; d < dsize; ++d)
+            for (int k = idx[idx_ofs + d] + 1; k < idx[idx_ofs + d + 1]; ++k) consecutive &= taps[tap_ofs + k].si == taps[tap_ofs + k - 1].si + 1;
+        return mx;
+    };
+    bool cons = true;
+    a.vt_spw = span(a.xtap_ofs, a.xidx_ofs, a.dw, AREA_TW, cons);
+    a.vt_sph = span(a.ytap_ofs, a.yidx_ofs, a.dh, AREA_TH, cons);
+    a.vt_ok = !a.fast && cons && a.max_xtaps <= 8 && a.max_ytaps <= 8 && a.vt_spw <= 32 * VT_CG && a.vt_sph <= 8 * VT_RI && a.vt_spw * a.vt_sph <= VT_PX;
     return true;
 }
 

@@ -122,19 +122,29 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
         HIP_CHECK(hipMemsetAsync(pair_count, 0, 16, st));
         rate_kernel<<<n, 64, 0, st>>>(vp, n, S.d_fcs.as<FrameCands>(), m->d_pageinfo.as<PageInfo>(), pair_list, pair_count);
         check_launch("rate_kernel");
+        // the pairs of size classes inside reproject_vt_kernel's limits go through the warped-image tile, the others through the
+        // frame window of reproject_kernel (each kernel skips the other's pairs; the second launch only if such a class exists)
         int max_tile_rows = 0;
-        for (const AreaGeom& ag : m->area_geoms) max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));
-        if (c.verify_model == 1)
-            reproject_kernel<true><<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
-                                                                                            m->d_area_idx.as<int32_t>(),
-                                                                                            m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
-                                                                                            stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
-        else
-            reproject_kernel<false><<<dim3(max_tile_rows, std::min(n, 65535)), 256, 0, st>>>(m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(),
-                                                                                             m->d_area_idx.as<int32_t>(),
-                                                                                             m->d_page_small.as<uint8_t>(), frames_dev, frame_stride,
-                                                                                             stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count);
-        check_launch("reproject_kernel");
+        bool any_vt = false, any_win = false;
+        for (const AreaGeom& ag : m->area_geoms) {
+            max_tile_rows = std::max(max_tile_rows, cdiv(ag.dh, SM_TH));
+            const bool vt = ag.vt_ok && cdiv(ag.dw, SM_TW) <= RP_MAX_TILES;
+            any_vt |= vt; any_win |= !vt;
+        }
+        const dim3 rgrid(max_tile_rows, std::min(n, 65535));
+#define SLIDEO_RP_ARGS m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(), m->d_area_idx.as<int32_t>(), m->d_page_small.as<uint8_t>(), \
+                       frames_dev, frame_stride, stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count
+        if (any_vt) {
+            if (c.verify_model == 1) reproject_vt_kernel<true><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
+            else reproject_vt_kernel<false><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
+            check_launch("reproject_vt_kernel");
+        }
+        if (any_win) {
+            if (c.verify_model == 1) reproject_kernel<true><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
+            else reproject_kernel<false><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
+            check_launch("reproject_kernel");
+        }
+#undef SLIDEO_RP_ARGS
     }
     verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), S.d_fcs.as<FrameCands>(),
                                                S.d_verdicts.as<slideo_verdict>());

@@ -630,7 +630,7 @@ __device__ __noinline__ void area_pixel_simple(const AreaGeom& ag, const AreaTap
     out[0] = sat_u8_f(s0); out[1] = sat_u8_f(s1); out[2] = sat_u8_f(s2);
 }
 
-constexpr int SM_TW = 32, SM_TH = 8;   // small-image tile per 256-thread block
+constexpr int SM_TW = AREA_TW, SM_TH = AREA_TH;   // small-image tile per 256-thread block (32 x 8)
 
 // to_small_image of n equally sized images.  grid (tiles, n), block 256.
 __global__ __launch_bounds__(256) void small_image_kernel(AreaGeom ag, const AreaTap* __restrict__ taps,
@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
         const int f = pd.f;
         const AreaGeom ag = ags[pd.area_idx];
         const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
+        if (ag.vt_ok && tiles_x <= RP_MAX_TILES) continue;            // (uniform per block) reproject_vt_kernel's pair
         const int ty = blockIdx.x;
         if (ty >= tiles_y) continue;                                  // uniform per block
         double M[PERSP ? 9 : 6];
@@ -998,6 +999,212 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
                 }
                 const uint8_t* ref = page_small + pd.small_ofs + ((int64_t)dy * ag.dw + dx) * 3;
                 int d0 = (int)o[0] - ref[0], d1 = (int)o[1] - ref[1], d2 = (int)o[2] - ref[2];
+                acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&fcs[f].ssd[pd.s], red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// reproject_vt_kernel: the same sum through a tile of the WARPED image instead of a window of the frame.
+// reproject_kernel evaluates the warp per TAP (a small pixel of a 2001 -> 461 shrink has up to 6 x 6 taps: 9216 per tile, each
+// with its own fixed-point coordinate pair, window offset and in-frame test), although the taps of a tile are only the
+// spw x sph (141 x 37 = 5217) pixels of its source span, most of them shared by no one but a few by two outputs.  Here
+//   pass 1  warps every source pixel of the span ONCE: nearest frame pixel -> one unaligned 4-byte global load (B, G, R, x),
+//           issued one tile ahead into registers (VT_CG x VT_RI per thread), stored as a dword of the LDS tile `vt`;
+//   pass 2  is INTER_AREA over that tile: the taps of an output are consecutive dwords of consecutive rows (geom.h checks
+//           it), so a row of taps is three ds_read2_b32 at immediate offsets and the per-tap work is the arithmetic only —
+//           3 conversions, 3 multiplies, 3 adds, same order as ResizeArea_Invoker ([OCV A.11]).
+// Per tile ~470 VALU instructions per thread instead of ~650, 24 KB of LDS instead of 41.  Pairs of a size class outside the
+// limits (AreaGeom::vt_ok: shrink factors above ~5) stay with reproject_kernel; each kernel skips the other's pairs.
+// grid / pair walk / strip structure: as reproject_kernel.
+struct VtTile { int sx_lo, spw, all_in; };
+
+template <bool PERSP>
+__global__ __launch_bounds__(256) void reproject_vt_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
+                                                           const int32_t* __restrict__ idx,
+                                                           const uint8_t* __restrict__ page_small,
+                                                           const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
+                                                           int fw, int fh, FrameCands* __restrict__ fcs,
+                                                           const PairDesc* __restrict__ pair_list, const uint32_t* __restrict__ pair_count) {
+    __shared__ unsigned long long red[4];
+    __shared__ uint32_t vt[VT_PX + 8];                                // + slack: a padding tap (weight 0) may read past the last pixel
+    __shared__ int2 s_col[2][32 * VT_CG];                             // (adelta, bdelta) per source column of a tile, double buffered
+    __shared__ VtTile s_tile[RP_MAX_TILES];
+    const uint32_t npairs = *pair_count;
+    constexpr int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
+    constexpr int NP = VT_CG * VT_RI;
+    const int c32 = threadIdx.x & 31, hw = threadIdx.x >> 5;         // pass 1: column within a 32-column group, row within an 8-row step
+    if (threadIdx.x < 8) vt[VT_PX + threadIdx.x] = 0;
+    for (uint32_t pi = blockIdx.y; pi < npairs; pi += gridDim.y) {
+        const PairDesc pd = pair_list[pi];
+        const AreaGeom ag = ags[pd.area_idx];
+        if (!ag.vt_ok) continue;                                      // (uniform per block) reproject_kernel's pair
+        const int tiles_x = (ag.dw + SM_TW - 1) / SM_TW, tiles_y = (ag.dh + SM_TH - 1) / SM_TH;
+        const int ty = blockIdx.x;
+        if (ty >= tiles_y || tiles_x > RP_MAX_TILES) continue;        // (uniform per block; wider small images: reproject_kernel)
+        const int f = pd.f;
+        double M[PERSP ? 9 : 6];
+#pragma unroll
+        for (int j = 0; j < (PERSP ? 9 : 6); ++j) M[j] = pd.M[j];
+        [[maybe_unused]] const int bw0 = max(1, min(1024 / max(min(16, ag.sh), 1), ag.sw));   // PERSP: WarpPerspectiveInvoker's block width
+        const uint8_t* frame = frames + (int64_t)f * frame_stride;
+        const int dy = ty * SM_TH + (threadIdx.x / SM_TW);
+        const int dya = ty * SM_TH, dyb = min(ag.dh, dya + SM_TH) - 1;
+        const int sy_lo = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dya]].si, sy_hi = taps[ag.ytap_ofs + idx[ag.yidx_ofs + dyb + 1] - 1].si;
+        const int sph = sy_hi - sy_lo + 1;
+        // the rows of this thread's small pixel (the same for every tile of the strip): weights, count and the first row of the
+        // span; rows are consecutive (geom.h), a row past the count repeats the last one with weight 0 (s + 0 * b = s exactly)
+        constexpr int YB = 8;
+        float be[YB]; int ny = 0, ry0 = 0;
+        {
+            const int dyc = min(dy, ag.dh - 1);
+            const int yb = idx[ag.yidx_ofs + dyc], ye = idx[ag.yidx_ofs + dyc + 1];
+            ny = ye - yb; ry0 = taps[ag.ytap_ofs + yb].si - sy_lo;
+#pragma unroll
+            for (int j = 0; j < YB; ++j) be[j] = j < ny ? taps[ag.ytap_ofs + yb + j].alpha : 0.f;
+        }
+        const int ny_wave = __builtin_amdgcn_readfirstlane(max(ny, __shfl_xor(ny, 32)));      // (a wave holds two rows of small pixels)
+        // this thread's source rows (hw, hw + 8, ...) and their fixed-point row terms; rows past the span repeat its last one
+        // (their pixels are fetched and dropped)
+        [[maybe_unused]] int X0r[VT_RI], Y0r[VT_RI];
+        if constexpr (!PERSP) {
+#pragma unroll
+            for (int ri = 0; ri < VT_RI; ++ri) {
+                const int y = sy_lo + min(hw + 8 * ri, sph - 1);
+                X0r[ri] = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+                Y0r[ri] = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+            }
+        }
+        __syncthreads();                                              // previous pair's readers of s_tile / s_col / vt are done
+        if ((int)threadIdx.x < tiles_x) {
+            const int tx = threadIdx.x;
+            VtTile T{};
+            const int dxa = tx * SM_TW, dxb = min(ag.dw, dxa + SM_TW) - 1;
+            T.sx_lo = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxa]].si;
+            const int sx_hi = taps[ag.xtap_ofs + idx[ag.xidx_ofs + dxb + 1] - 1].si;
+            T.spw = sx_hi - T.sx_lo + 1;
+            if constexpr (!PERSP) {
+                // X, Y are monotone in x and in y: the corners of the source span bound every pixel's image.  all_in: no in-frame
+                // test needed — and none of them is the frame's last pixel, whose 4-byte load would end one byte past the frame
+                auto XY = [&](int x, int y, int& X, int& Y) {
+                    X = (int)((uint32_t)(sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta) + (uint32_t)sat_int_d(M[0] * x * AB_SCALE)) >> AB_BITS;
+                    Y = (int)((uint32_t)(sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta) + (uint32_t)sat_int_d(M[3] * x * AB_SCALE)) >> AB_BITS;
+                };
+                int X00, Y00, X10, Y10, X01, Y01, X11, Y11;
+                XY(T.sx_lo, sy_lo, X00, Y00); XY(sx_hi, sy_lo, X10, Y10); XY(T.sx_lo, sy_hi, X01, Y01); XY(sx_hi, sy_hi, X11, Y11);
+                const int ux0 = min(min(X00, X10), min(X01, X11)), ux1 = max(max(X00, X10), max(X01, X11));
+                const int uy0 = min(min(Y00, Y10), min(Y01, Y11)), uy1 = max(max(Y00, Y10), max(Y01, Y11));
+                T.all_in = ux0 >= 0 && ux1 < fw && uy0 >= 0 && uy1 < fh && !(ux1 == fw - 1 && uy1 == fh - 1);
+            }
+            s_tile[tx] = T;
+        }
+        __syncthreads();
+        [[maybe_unused]] auto col_table = [&](int tile, int buf) {   // (adelta, bdelta) of the tile's columns
+            if (tile < tiles_x) {
+                const VtTile T = s_tile[tile];
+                for (int i = threadIdx.x; i < T.spw; i += 256) {
+                    const int x = T.sx_lo + i;
+                    s_col[buf][i] = make_int2(sat_int_d(M[0] * x * AB_SCALE), sat_int_d(M[3] * x * AB_SCALE));
+                }
+            }
+        };
+        if constexpr (!PERSP) { col_table(0, 0); col_table(1, 1); __syncthreads(); }
+        // pass 1, issue side: the tile's pixels into registers.  oob / lastp: one bit per register — the pixel lies outside the
+        // frame (stored as 0, the load goes to the frame's first pixel) / is the frame's last pixel (loaded one byte early).
+        uint32_t P[NP], oob = 0, lastp = 0;
+        const int lim = fh * stride - 4;
+        auto fetch_tile = [&](int tile) {
+            const VtTile T = s_tile[tile];
+            oob = 0; lastp = 0;
+#pragma unroll
+            for (int cg = 0; cg < VT_CG; ++cg) {
+                if (cg * 32 >= T.spw) continue;                         // (uniform)
+                const int col = min(cg * 32 + c32, T.spw - 1);
+                [[maybe_unused]] int2 ab = make_int2(0, 0);
+                if constexpr (!PERSP) ab = s_col[tile & 1][col];
+#pragma unroll
+                for (int ri = 0; ri < VT_RI; ++ri) {
+                    if (8 * ri >= sph) continue;                        // (uniform)
+                    const int k = cg * VT_RI + ri;
+                    int X, Y;
+                    if constexpr (PERSP) persp_src(M, bw0, T.sx_lo + col, sy_lo + min(hw + 8 * ri, sph - 1), X, Y);
+                    else {
+                        X = (int)((uint32_t)X0r[ri] + (uint32_t)ab.x) >> AB_BITS;
+                        Y = (int)((uint32_t)Y0r[ri] + (uint32_t)ab.y) >> AB_BITS;
+                        // (saturate_cast<short> of imgwarp.cpp cannot change the in-frame test for frames < 32768 px)
+                    }
+                    int o = (int)__mul24(Y, stride) + 3 * X;
+                    if (PERSP || !T.all_in) {
+                        const bool in = (unsigned)X < (unsigned)fw && (unsigned)Y < (unsigned)fh;
+                        o = in ? o : 0;
+                        oob |= in ? 0u : (1u << k);
+                        lastp |= o > lim ? (1u << k) : 0u;
+                        o = min(o, lim);
+                    }
+                    __builtin_memcpy(&P[k], frame + (uint32_t)o, 4);
+                }
+            }
+        };
+        fetch_tile(0);
+        unsigned long long acc = 0;
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            const VtTile T = s_tile[tx];
+            const int spw = T.spw;
+            // this tile's small pixel of the thread: its x taps and the slide's pixel, requested now, used after barrier B
+            const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1));
+            const bool live = dx < ag.dw && dy < ag.dh;
+            constexpr int XBM = 8;
+            const int xtaps_max = ag.max_xtaps;
+            float al[XBM]; int x_first = 0; uint32_t ref01 = 0, ref2 = 0;
+            {
+                const int dxc = min(dx, ag.dw - 1);
+                const int xb = idx[ag.xidx_ofs + dxc], xe = idx[ag.xidx_ofs + dxc + 1];
+                x_first = taps[ag.xtap_ofs + xb].si - T.sx_lo;
+#pragma unroll
+                for (int k = 0; k < XBM; ++k) al[k] = (k < xtaps_max && xb + k < xe) ? taps[ag.xtap_ofs + xb + k].alpha : 0.f;   // (padding taps: weight 0 on whatever follows)
+                const uint8_t* ref = page_small + pd.small_ofs + ((int64_t)min(dy, ag.dh - 1) * ag.dw + dxc) * 3;
+                ref01 = (uint32_t)ref[0] | ((uint32_t)ref[1] << 8); ref2 = ref[2];
+            }
+            __syncthreads();                                          // A: the previous tile's taps are done with vt
+#pragma unroll
+            for (int cg = 0; cg < VT_CG; ++cg) {
+                if (cg * 32 >= spw) continue;
+#pragma unroll
+                for (int ri = 0; ri < VT_RI; ++ri) {
+                    if (8 * ri >= sph) continue;
+                    const int k = cg * VT_RI + ri, col = cg * 32 + c32, r = hw + 8 * ri;
+                    uint32_t v = P[k];
+                    if (PERSP || !T.all_in) { v = ((lastp >> k) & 1u) ? v >> 8 : v; v = ((oob >> k) & 1u) ? 0u : v; }
+                    if (col < spw && r < sph) vt[r * spw + col] = v;
+                }
+            }
+            if (tx + 1 < tiles_x) fetch_tile(tx + 1);                 // in flight during this tile's taps
+            __syncthreads();                                          // B: vt is complete, tile tx + 1's column table has been read
+            if constexpr (!PERSP) col_table(tx + 2, tx & 1);
+            if (live) {
+                const uint32_t* row = vt + (x_first + ry0 * spw);
+                float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int j = 0; j < YB; ++j) {
+                    if (j >= ny_wave) break;                            // (uniform)
+                    uint32_t px[XBM];
+#pragma unroll
+                    for (int k = 0; k < XBM; ++k) px[k] = row[k];
+                    float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+                    for (int k = 0; k < XBM; ++k) {
+                        if (k >= xtaps_max) break;                      // (uniform: the class has no output with more taps)
+                        b0 = b0 + (float)(px[k] & 255u) * al[k]; b1 = b1 + (float)((px[k] >> 8) & 255u) * al[k]; b2 = b2 + (float)((px[k] >> 16) & 255u) * al[k];
+                    }
+                    s0 += be[j] * b0; s1 += be[j] * b1; s2 += be[j] * b2;      // (0 + x = x exactly: the first row needs no case of its own)
+                    row += j + 1 < ny ? spw : 0;
+                }
+                const int d0 = (int)sat_u8_f(s0) - (int)(ref01 & 255u), d1 = (int)sat_u8_f(s1) - (int)(ref01 >> 8), d2 = (int)sat_u8_f(s2) - (int)ref2;
                 acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
             }
         }
