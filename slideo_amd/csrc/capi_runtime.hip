@@ -32,7 +32,7 @@ int area_class_for(slideo_matcher* m, int w, int h) {
     for (size_t i = 0; i < m->area_geoms.size(); ++i)
         if (m->area_geoms[i].sw == w && m->area_geoms[i].sh == h) return (int)i;
     AreaGeom a;
-    if (!build_area_geom(w, h, m->cfg.small_area, a, m->area_taps, m->area_idx, m->cfg.ocv.area))
+    if (!build_area_geom(w, h, m->cfg.small_area, a, m->area_taps, m->area_idx, m->cfg.ocv.area, &m->area_recs))
         fail(SLIDEO_ERR_UNSUPPORTED, "image %dx%d has area below small_area=%d: to_small_image would upscale (INTER_AREA falls back to bilinear in OpenCV), not implemented",
              w, h, m->cfg.small_area);
     m->area_geoms.push_back(a);
@@ -45,9 +45,11 @@ void upload_area(slideo_matcher* m) {
     m->d_area_geoms.reserve(m->area_geoms.size() * sizeof(AreaGeom));
     m->d_area_taps.reserve(m->area_taps.size() * sizeof(AreaTap));
     m->d_area_idx.reserve(m->area_idx.size() * 4);
+    m->d_area_recs.reserve(std::max<size_t>(m->area_recs.size() * sizeof(AreaRec), 64));
     HIP_CHECK(hipMemcpyAsync(m->d_area_geoms.p, m->area_geoms.data(), m->area_geoms.size() * sizeof(AreaGeom), hipMemcpyHostToDevice, m->stream));
     HIP_CHECK(hipMemcpyAsync(m->d_area_taps.p, m->area_taps.data(), m->area_taps.size() * sizeof(AreaTap), hipMemcpyHostToDevice, m->stream));
     HIP_CHECK(hipMemcpyAsync(m->d_area_idx.p, m->area_idx.data(), m->area_idx.size() * 4, hipMemcpyHostToDevice, m->stream));
+    if (!m->area_recs.empty()) HIP_CHECK(hipMemcpyAsync(m->d_area_recs.p, m->area_recs.data(), m->area_recs.size() * sizeof(AreaRec), hipMemcpyHostToDevice, m->stream));
     HIP_CHECK(hipStreamSynchronize(m->stream));
     m->area_dirty = false;
 }
@@ -583,7 +585,7 @@ int32_t slideo_matcher_finalize_pages(slideo_matcher* m) {
     m->d_train_page.reserve(std::max<size_t>(tpage.size() * 4, 16));
     m->d_page_xy.reserve(std::max<size_t>(xy.size() * sizeof(float2), 16));
     m->d_pageinfo.reserve(std::max<size_t>(info.size() * sizeof(PageInfo), 16));
-    m->d_page_small.reserve(std::max<size_t>(smalls.size(), 16));
+    m->d_page_small.reserve(smalls.size() + 16);       // (+ slack: reproject_vt_kernel reads a 3-byte pixel as one dword)
     if (M > 0 && m->sift_on) {
         // SIFT mode: the rows become the train set of the squared-L2 engine (norm order, centred tile-major operand)
         HIP_CHECK(hipMemcpy(m->d_train_page.p, tpage.data(), tpage.size() * 4, hipMemcpyHostToDevice));

@@ -305,7 +305,12 @@ struct AreaGeom {        // one per distinct (source size -> small size) class
     // re-projection through a tile of the WARPED image (verify.hip.h reproject_vt_kernel): the largest source span of a 32 x 8
     // tile of small pixels, and whether the class fits that kernel's limits (else reproject_kernel's frame window does it)
     int32_t vt_ok, vt_spw, vt_sph;
+    int32_t xrec_ofs, yrec_ofs;   // AreaRec per small column / row (vt_ok classes)
 };
+
+// One small pixel's taps along an axis as ONE 32-byte record (two 16-byte loads instead of the index pair, the first tap and
+// up to 7 weights one by one): first source pixel | count << 24, then the weights, 0 past the count.
+struct alignas(16) AreaRec { int32_t first_n; float alpha[7]; };
 
 // limits of reproject_vt_kernel: a thread prefetches VT_CG x VT_RI source pixels of a tile (32-column groups x 8-row steps)
 constexpr int AREA_TW = 32, AREA_TH = 8;       // small pixels per tile (= SM_TW x SM_TH of verify.hip.h)
@@ -347,7 +352,8 @@ inline void small_size(int w, int h, int small_area, int& sw, int& sh) {
 }
 
 // Returns false when the resize is not a shrink (INTER_AREA would fall back to bilinear).
-inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int variant = 0) {
+inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vector<AreaTap>& taps, std::vector<int32_t>& idx, int variant = 0,
+                            std::vector<AreaRec>* recs = nullptr) {
     a = AreaGeom();
     a.sw = w; a.sh = h;
     small_size(w, h, small_area, a.dw, a.dh);
@@ -381,7 +387,23 @@ inline bool build_area_geom(int w, int h, int small_area, AreaGeom& a, std::vect
     bool cons = true;
     a.vt_spw = span(a.xtap_ofs, a.xidx_ofs, a.dw, AREA_TW, cons);
     a.vt_sph = span(a.ytap_ofs, a.yidx_ofs, a.dh, AREA_TH, cons);
-    a.vt_ok = !a.fast && cons && a.max_xtaps <= 8 && a.max_ytaps <= 8 && a.vt_spw <= 32 * VT_CG && a.vt_sph <= 8 * VT_RI && a.vt_spw * a.vt_sph <= VT_PX;
+    a.vt_ok = recs && !a.fast && cons && a.max_xtaps <= 7 && a.max_ytaps <= 7 && std::max(w, h) < (1 << 24) &&
+              a.vt_spw <= 32 * VT_CG && a.vt_sph <= 8 * VT_RI && a.vt_spw * a.vt_sph <= VT_PX;
+    if (a.vt_ok) {
+        auto emit = [&](int tap_ofs, int idx_ofs, int dsize) {
+            const int32_t at = (int32_t)recs->size();
+            for (int d = 0; d < dsize; ++d) {
+                const int b = idx[idx_ofs + d], e = idx[idx_ofs + d + 1];
+                AreaRec r{};
+                r.first_n = taps[tap_ofs + b].si | ((e - b) << 24);
+                for (int k = 0; k < 7; ++k) r.alpha[k] = b + k < e ? taps[tap_ofs + b + k].alpha : 0.f;
+                recs->push_back(r);
+            }
+            return at;
+        };
+        a.xrec_ofs = emit(a.xtap_ofs, a.xidx_ofs, a.dw);
+        a.yrec_ofs = emit(a.ytap_ofs, a.yidx_ofs, a.dh);
+    }
     return true;
 }
 

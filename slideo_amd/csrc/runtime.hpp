@@ -116,7 +116,8 @@ struct slideo_matcher {
     std::vector<slideo::AreaGeom> area_geoms;
     std::vector<slideo::AreaTap> area_taps;
     std::vector<int32_t> area_idx;
-    slideo::DevBuf d_area_geoms, d_area_taps, d_area_idx;
+    std::vector<slideo::AreaRec> area_recs;
+    slideo::DevBuf d_area_geoms, d_area_taps, d_area_idx, d_area_recs;
     bool area_dirty = true;
 
     // pages

@@ -132,11 +132,12 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
             any_vt |= vt; any_win |= !vt;
         }
         const dim3 rgrid(max_tile_rows, std::min(n, 65535));
-#define SLIDEO_RP_ARGS m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(), m->d_area_idx.as<int32_t>(), m->d_page_small.as<uint8_t>(), \
-                       frames_dev, frame_stride, stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count
+#define SLIDEO_RP_TAIL m->d_page_small.as<uint8_t>(), frames_dev, frame_stride, stride, w, h, S.d_fcs.as<FrameCands>(), pair_list, pair_count
+#define SLIDEO_RP_ARGS m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(), m->d_area_idx.as<int32_t>(), SLIDEO_RP_TAIL
+#define SLIDEO_VT_ARGS m->d_area_geoms.as<AreaGeom>(), m->d_area_taps.as<AreaTap>(), m->d_area_idx.as<int32_t>(), m->d_area_recs.as<AreaRec>(), SLIDEO_RP_TAIL
         if (any_vt) {
-            if (c.verify_model == 1) reproject_vt_kernel<true><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
-            else reproject_vt_kernel<false><<<rgrid, 256, 0, st>>>(SLIDEO_RP_ARGS);
+            if (c.verify_model == 1) reproject_vt_kernel<true><<<rgrid, 256, 0, st>>>(SLIDEO_VT_ARGS);
+            else reproject_vt_kernel<false><<<rgrid, 256, 0, st>>>(SLIDEO_VT_ARGS);
             check_launch("reproject_vt_kernel");
         }
         if (any_win) {
@@ -145,6 +146,8 @@ void unit_verify(slideo_matcher* m, Slot& S, const VerifyParams& vp, const uint8
             check_launch("reproject_kernel");
         }
 #undef SLIDEO_RP_ARGS
+#undef SLIDEO_VT_ARGS
+#undef SLIDEO_RP_TAIL
     }
     verdict_kernel<<<cdiv(n, 64), 64, 0, st>>>(vp, n, S.d_qofs.as<uint32_t>(), m->d_pageinfo.as<PageInfo>(), S.d_fcs.as<FrameCands>(),
                                                S.d_verdicts.as<slideo_verdict>());

@@ -1024,9 +1024,12 @@ __global__ __launch_bounds__(256) void reproject_kernel(const AreaGeom* __restri
 // grid / pair walk / strip structure: as reproject_kernel.
 struct VtTile { int sx_lo, spw, all_in; };
 
+#ifndef VT_WAVES_EU
+#define VT_WAVES_EU 4      /* 128 registers: four blocks per CU (3: 1.58 ms, 4: 1.37 ms for the headline launch) */
+#endif
 template <bool PERSP>
-__global__ __launch_bounds__(256) void reproject_vt_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
-                                                           const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
+                                                           const int32_t* __restrict__ idx, const AreaRec* __restrict__ recs,
                                                            const uint8_t* __restrict__ page_small,
                                                            const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
                                                            int fw, int fh, FrameCands* __restrict__ fcs,
@@ -1059,14 +1062,14 @@ __global__ __launch_bounds__(256) void reproject_vt_kernel(const AreaGeom* __res
         const int sph = sy_hi - sy_lo + 1;
         // the rows of this thread's small pixel (the same for every tile of the strip): weights, count and the first row of the
         // span; rows are consecutive (geom.h), a row past the count repeats the last one with weight 0 (s + 0 * b = s exactly)
-        constexpr int YB = 8;
-        float be[YB]; int ny = 0, ry0 = 0;
+        constexpr int YB = 7;
+        float be[YB]; int ny, ry0;
         {
-            const int dyc = min(dy, ag.dh - 1);
-            const int yb = idx[ag.yidx_ofs + dyc], ye = idx[ag.yidx_ofs + dyc + 1];
-            ny = ye - yb; ry0 = taps[ag.ytap_ofs + yb].si - sy_lo;
-#pragma unroll
-            for (int j = 0; j < YB; ++j) be[j] = j < ny ? taps[ag.ytap_ofs + yb + j].alpha : 0.f;
+            const uint4* rp = reinterpret_cast<const uint4*>(recs + ag.yrec_ofs + min(dy, ag.dh - 1));
+            const uint4 r0 = rp[0], r1 = rp[1];
+            ny = (int)(r0.x >> 24); ry0 = (int)(r0.x & 0xFFFFFFu) - sy_lo;
+            be[0] = __uint_as_float(r0.y); be[1] = __uint_as_float(r0.z); be[2] = __uint_as_float(r0.w);
+            be[3] = __uint_as_float(r1.x); be[4] = __uint_as_float(r1.y); be[5] = __uint_as_float(r1.z); be[6] = __uint_as_float(r1.w);
         }
         const int ny_wave = __builtin_amdgcn_readfirstlane(max(ny, __shfl_xor(ny, 32)));      // (a wave holds two rows of small pixels)
         // this thread's source rows (hw, hw + 8, ...) and their fixed-point row terms; rows past the span repeat its last one
@@ -1158,17 +1161,18 @@ __global__ __launch_bounds__(256) void reproject_vt_kernel(const AreaGeom* __res
             // this tile's small pixel of the thread: its x taps and the slide's pixel, requested now, used after barrier B
             const int dx = tx * SM_TW + (threadIdx.x & (SM_TW - 1));
             const bool live = dx < ag.dw && dy < ag.dh;
-            constexpr int XBM = 8;
+            constexpr int XBM = 7;
             const int xtaps_max = ag.max_xtaps;
-            float al[XBM]; int x_first = 0; uint32_t ref01 = 0, ref2 = 0;
+            float al[XBM]; int x_first; uint32_t refpx;
             {
                 const int dxc = min(dx, ag.dw - 1);
-                const int xb = idx[ag.xidx_ofs + dxc], xe = idx[ag.xidx_ofs + dxc + 1];
-                x_first = taps[ag.xtap_ofs + xb].si - T.sx_lo;
-#pragma unroll
-                for (int k = 0; k < XBM; ++k) al[k] = (k < xtaps_max && xb + k < xe) ? taps[ag.xtap_ofs + xb + k].alpha : 0.f;   // (padding taps: weight 0 on whatever follows)
-                const uint8_t* ref = page_small + pd.small_ofs + ((int64_t)min(dy, ag.dh - 1) * ag.dw + dxc) * 3;
-                ref01 = (uint32_t)ref[0] | ((uint32_t)ref[1] << 8); ref2 = ref[2];
+                const uint4* rp = reinterpret_cast<const uint4*>(recs + ag.xrec_ofs + dxc);
+                const uint4 r0 = rp[0], r1 = rp[1];
+                x_first = (int)(r0.x & 0xFFFFFFu) - T.sx_lo;
+                al[0] = __uint_as_float(r0.y); al[1] = __uint_as_float(r0.z); al[2] = __uint_as_float(r0.w);
+                al[3] = __uint_as_float(r1.x); al[4] = __uint_as_float(r1.y); al[5] = __uint_as_float(r1.z); al[6] = __uint_as_float(r1.w);
+                // (padding taps: weight 0 on whatever follows in the row)
+                __builtin_memcpy(&refpx, page_small + pd.small_ofs + (uint32_t)((min(dy, ag.dh - 1) * ag.dw + dxc) * 3), 4);   // B, G, R (+ a byte of the next pixel)
             }
             __syncthreads();                                          // A: the previous tile's taps are done with vt
 #pragma unroll
@@ -1204,7 +1208,7 @@ __global__ __launch_bounds__(256) void reproject_vt_kernel(const AreaGeom* __res
                     s0 += be[j] * b0; s1 += be[j] * b1; s2 += be[j] * b2;      // (0 + x = x exactly: the first row needs no case of its own)
                     row += j + 1 < ny ? spw : 0;
                 }
-                const int d0 = (int)sat_u8_f(s0) - (int)(ref01 & 255u), d1 = (int)sat_u8_f(s1) - (int)(ref01 >> 8), d2 = (int)sat_u8_f(s2) - (int)ref2;
+                const int d0 = (int)sat_u8_f(s0) - (int)(refpx & 255u), d1 = (int)sat_u8_f(s1) - (int)((refpx >> 8) & 255u), d2 = (int)sat_u8_f(s2) - (int)((refpx >> 16) & 255u);
                 acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
             }
         }
