@@ -590,7 +590,9 @@ void knn_tile4_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __res
     knn_tile_body<4, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
                                 prune_tol, nq_dev);
 }
-#ifdef KT2_VGPRS           /* experiments only (tools/knn_experiments.sh): a cap below the 128 that 4 waves per SIMD allow */
+#ifdef KT2_CLOBBER
+__global__ __launch_bounds__(KT_THREADS, 2)
+#elif defined(KT2_VGPRS)   /* experiments only: a cap below the 128 that 4 waves per SIMD allow */
 __global__ __attribute__((amdgpu_num_vgpr(KT2_VGPRS))) __launch_bounds__(KT_THREADS, 4)
 #else
 __global__ __launch_bounds__(KT_THREADS, 4)
@@ -598,6 +600,9 @@ __global__ __launch_bounds__(KT_THREADS, 4)
 void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                       const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
                       uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+#ifdef KT2_CLOBBER      /* experiment: the register allocation of a larger wave shape without its code */
+    asm volatile("" ::: KT2_CLOBBER);
+#endif
     knn_tile_body<2, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
                                 prune_tol, nq_dev);
 }

@@ -98,8 +98,11 @@ static void build_lsh_set(const slideo_config& c, const uint8_t* t_host, int nt,
 // kernel's own 70 KB + this pad exceed half of the CU's 160 KB.  The exact Hamming search only: the LSH-filtered stream is
 // VALU-bound on its row filter and dominates its step (one block per CU: 26.2 instead of 21.4 ms per step), and the SIFT
 // matcher's step is its extraction stage (L2 search one or two blocks per CU: 73.3 ms either way).
-constexpr unsigned KT_SHARE_PAD = 16 * 1024;
-static_assert(KT_RING * (KT_ST_U4 * 16 + KT_SIDE_U32 * 4) + KT_SHARE_PAD > 160 * 1024 / 2, "the pad must push a block past half of the CU's LDS");
+#ifndef KT_SHARE_PAD_V
+#define KT_SHARE_PAD_V (16 * 1024)
+#endif
+constexpr unsigned KT_SHARE_PAD = KT_SHARE_PAD_V;
+static_assert(KT_SHARE_PAD == 0 || KT_RING * (KT_ST_U4 * 16 + KT_SIDE_U32 * 4) + KT_SHARE_PAD > 160 * 1024 / 2, "the pad must push a block past half of the CU's LDS");
 #ifdef KT_PROBE
 void knn_probe_report() {
     unsigned long long v[8] = {0};
