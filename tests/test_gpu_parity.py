@@ -789,6 +789,37 @@ def test_search_blocks_per_cu_modes_agree(capi, oracle, cfg0_data, monkeypatch):
     assert out[None][1] == out[None][0] * 12
 
 
+@pytest.mark.parametrize("verify_model", [0, 1])
+def test_reprojection_through_both_kernels_and_the_frame_edges(capi, oracle, synth, verify_model):
+    """The re-projection sum of a deck whose size classes go through BOTH kernels in one launch pair — 800 x 450 and 1280 x 720 pages
+    through the warped-image tile (verify.hip.h reproject_vt_kernel), 2600 x 1462 pages (shrink 5.6: outside its limits) through the
+    frame window (reproject_kernel) — and of frames that ARE a page (every second pixel of a 1280 x 720 page: the slide fills the
+    frame, so the tiles along the right and bottom edges tap out-of-frame pixels and the frame's last pixel, whose 4-byte load is
+    moved one byte back): candidates, transforms and similarities against the oracle."""
+    small = synth.pages(3, 800, 450, seed=31)
+    mid = synth.pages(2, 1280, 720, seed=32)
+    big = synth.pages(2, 2600, 1462, seed=33)
+    over = dict(verify_model=verify_model)
+    gcfg, ocfg = small_cfg(capi, **over), small_cfg(oracle, **over)
+    m = capi.Matcher(gcfg); db = oracle.PageDB(ocfg)
+    for stack in (small, mid, big):
+        m.add_pages(list(stack))
+        for pg in stack: db.add_page(pg)
+    m.finalize(); assert db.finalize() == 0
+    fa, _, _ = synth.frames(small, 4, 640, 360, seed=41)
+    fc = np.ascontiguousarray(mid[:, ::2, ::2])                          # the slide IS the frame
+    fb, _, _ = synth.frames(big, 4, 1280, 720, seed=42)                  # (a second call: another frame size)
+    seen = set()
+    for frames in (np.concatenate([fa, fc]), fb):
+        v = m.match_frames(frames)
+        _compare_traces(m, db, frames, v, skip_ill_conditioned=verify_model == 1)
+        for i in range(len(frames)):                                     # re-projected candidates (similarity set) by size class
+            for c in m.last_candidates(i):
+                if c["similarity"] != 0: seen.add(0 if c["page_idx"] < 3 else 1 if c["page_idx"] < 5 else 2)
+    assert seen == {0, 1, 2}, "both kernels must have had work"
+    m.close()
+
+
 def test_match_kept_frames_equals_a_second_upload(capi, cfg0_data):
     """slideo_match_kept_frames: the frames the changed-mask call uploaded are matched from the device copy — same verdicts
     and traces as uploading the changed subset again (what process() did before), in any selection order."""
