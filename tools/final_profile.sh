@@ -5,8 +5,13 @@ out=gpurun_out/final_$tag; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRA
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 rocprofv3 --kernel-trace --stats -d $out/stats -o t -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap > $out/bench_no_overlap.json 2>&1
 python profiles/summarize_rocpd.py $out/stats/t_results.db | grep -v rocclr > $out/kernel_stats_no_overlap.txt
-rocprofv3 --kernel-trace --stats -d $out/stats2 -o t -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/bench_overlap.json 2>&1
+rocprofv3 --kernel-trace --stats -d $out/stats2 -o t -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline > $out/bench_overlap.json 2>&1
 python profiles/summarize_rocpd.py $out/stats2/t_results.db | grep -v rocclr > $out/kernel_stats_overlap.txt
+python tools/timeline_overlap.py $out/stats2/t_results.db 100 > $out/timeline_overlap.txt
+# the search with ONE block per CU (what overlapped units launch), alone on the chip
+SLIDEO_KNN_SHARE=1 rocprofv3 --kernel-trace --stats -d $out/stats1b -o t -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap > $out/bench_no_overlap_one_block.json 2>&1
+python profiles/summarize_rocpd.py $out/stats1b/t_results.db | grep -v rocclr | head -4 > $out/kernel_stats_no_overlap_one_block_per_cu.txt
+rm -rf $out/stats1b
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > $out/pmc_$c.log 2>&1
   python profiles/summarize_pmc.py $out/pmc_$c/t_results.db > $out/pmc_$c.txt

@@ -22,7 +22,7 @@ def main(path, res=100.0):
     rows = [(group(re.sub(r"\(.*", "", n)), s, s + d) for n, s, d in c.execute("select name, start, duration from kernels order by start")]
     ks = [(s, e) for g, s, e in rows if g == "K"]
     if len(ks) < 6: print("too few search launches"); return
-    lo, hi = ks[2][0], ks[-3][1]                      # skip the warm-up edge and the drain
+    lo, hi = ks[len(ks) // 4][0], ks[(3 * len(ks)) // 4][1]      # the middle half of the search launches: steady state (no warm-up, no drain, not bench.py's one-batch-in-flight tail)
     ev = []
     for g, s, e in rows:
         if g and e > lo and s < hi: ev.append((max(s, lo), 1, g)); ev.append((min(e, hi), -1, g))
