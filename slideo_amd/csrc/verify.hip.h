@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
         // pass 1, issue side: the tile's pixels into registers.  oob / lastp: one bit per register — the pixel lies outside the
         // frame (stored as 0, the load goes to the frame's first pixel) / is the frame's last pixel (loaded one byte early).
         uint32_t P[NP], oob = 0, lastp = 0;
-        const int lim = fh * stride - 4;
+        const int lim = max(fh * stride - 4, 0);
         auto fetch_tile = [&](int tile) {
             const VtTile T = s_tile[tile];
             oob = 0; lastp = 0;
