@@ -820,6 +820,19 @@ def test_reprojection_through_both_kernels_and_the_frame_edges(capi, oracle, syn
     m.close()
 
 
+@pytest.mark.parametrize("pw,ph", [(2150, 1210), (2200, 1238), (1999, 1124)])
+def test_reprojection_at_the_limits_of_the_warped_tile(capi, oracle, synth, pw, ph):
+    """Page sizes around reproject_vt_kernel's limits (a tile's source span of at most 160 x 40 pixels, 6144 in all: shrink factors up
+    to ~4.7) — whichever kernel a size class gets, the sums are the oracle's; 1999 x 1124: odd sizes, partial tiles on both axes."""
+    pages = synth.pages(3, pw, ph, seed=pw)
+    frames, _, _ = synth.frames(pages, 5, 1280, 720, seed=ph)
+    m, db = _build_both(capi, oracle, small_cfg(capi, nfeatures=1000), small_cfg(oracle, nfeatures=1000), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v)
+    assert any(c["similarity"] != 0 for i in range(len(frames)) for c in m.last_candidates(i)), "no candidate reached the re-projection"
+    m.close()
+
+
 def test_match_kept_frames_equals_a_second_upload(capi, cfg0_data):
     """slideo_match_kept_frames: the frames the changed-mask call uploaded are matched from the device copy — same verdicts
     and traces as uploading the changed subset again (what process() did before), in any selection order."""
