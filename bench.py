@@ -429,7 +429,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl["name"], "frame": [fw, fh], "page": [pw, ph], "pages": P, "nfeatures": wl["nfeatures"],
                    "train_descriptors_M": int(M), "train_descriptors_unique": int(Mu), "frames_per_step_per_gpu": B,
-                   "knn": ("exact brute force, k=30, engine=%s" % args.knn) if args.matcher == "exact" else "LSH candidates (6 tables x 12 bits, multi-probe 1), k=30 nearest candidates",
+                   "knn": ("exact brute force, k=30, engine=%s; overlapped batches launch the search with one block per CU (SLIDEO_KNN_SHARE=%s)" % (args.knn, os.environ.get("SLIDEO_KNN_SHARE", "auto"))) if args.matcher == "exact" else "LSH candidates (6 tables x 12 bits, multi-probe 1), k=30 nearest candidates",
                    "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
