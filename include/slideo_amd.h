@@ -50,7 +50,7 @@
  *   SLIDEO_ORB_CHAIN=0            ORB stages of consecutive units free-running instead of taking turns
  *   SLIDEO_HOST_UNIT n            frames per unit of a host-memory batch (32; 0 = the device-path rule)
  *   SLIDEO_WS_GB x                workspace budget of all slots together (48)
- *   SLIDEO_SIFT_WS_MB n           SIFT pyramid budget per pass (24576)                                          [per call]
+ *   SLIDEO_SIFT_WS_MB n           SIFT pyramid budget per pass (98304 on a device with >= 192 GB, else 24576)  [per call]
  *   SLIDEO_SIFT_LIST_CAP n        start capacity of SIFT's per-frame extrema list (65536; the tests force its growth path) [per call]
  *   SLIDEO_RNG_STREAM_LEN n       start length of the pre-drawn cv::RNG stream (the tests force its growth path)
  *   SLIDEO_RANSAC_WINDOW=0        ransac_kernel's redraw schedule by the fixed point only                       [per unit]

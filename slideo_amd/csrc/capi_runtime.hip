@@ -421,6 +421,10 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
     mm->host_unit = (int)std::max(0l, env_long("SLIDEO_HOST_UNIT", 32));
     mm->orb_chain = env_long("SLIDEO_ORB_CHAIN", 1) != 0;
+    {   // a third of a 288 GB device for the SIFT pyramids (a pass of 256 1080p frames: 90 GB; three passes of 86 at 24 GB cost 6 ms of 68)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b >= ((size_t)192 << 30)) mm->sift_ws_mb = 96l << 10;
+    }
     if (const char* e = std::getenv("SLIDEO_WS_GB")) { double gb = std::atof(e); if (gb > 0.1) mm->ws_budget = (size_t)(gb * (double)((size_t)1 << 30)); }
     for (Slot& S : mm->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));

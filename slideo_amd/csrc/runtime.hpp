@@ -105,6 +105,7 @@ struct slideo_matcher {
     slideo_progress_fn progress = nullptr;
     void* progress_user = nullptr;
     size_t ws_budget = (size_t)48 << 30;      // all slots together (SLIDEO_WS_GB); 288 GB of HBM per GPU
+    long sift_ws_mb = 24l << 10;              // pyramids of one SIFT pass (SLIDEO_SIFT_WS_MB); 96 GB on a device with >= 192 GB: 256 1080p frames in ONE pass
 
     slideo::DevBuf d_tables, d_rng, d_ictab;
     struct L2Set { slideo::DevBuf d_tx, d_tn, d_side, d_perm, d_keys, d_pend; int nt = 0, nt_pad = 0; bool ready = false; } l2;   // cfg2: the L2 train set

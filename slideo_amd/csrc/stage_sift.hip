@@ -147,9 +147,10 @@ static int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, i
     sp.contrast_threshold = (float)sc.contrast_threshold; sp.edge_threshold = (float)sc.edge_threshold; sp.sigma = (float)sc.sigma;
     sp.threshold = (int)std::floor(0.5 * sc.contrast_threshold / SIFT_NL * 255);
     sp.atan_fma = m->cfg.ocv.atan; sp.blur_fma = m->cfg.ocv.blur != 1;
-    // frames per pass under a 24 GB budget for the pyramids (265 MB + 33 MB per 1080p frame; SLIDEO_SIFT_WS_MB: tests)
+    // frames per pass under the budget for the pyramids (265 MB + 33 MB per 1080p frame; 96 GB on an MI355X, 24 GB on a small device;
+    // SLIDEO_SIFT_WS_MB: tests)
     const size_t per = ((size_t)g.g_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
-    const size_t budget = (size_t)std::max(env_long("SLIDEO_SIFT_WS_MB", 24l << 10), 1l) << 20;          // (read per call: a test squeezes it)
+    const size_t budget = (size_t)std::max(env_long("SLIDEO_SIFT_WS_MB", m->sift_ws_mb), 1l) << 20;       // (read per call: a test squeezes it)
     const int nb_max = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
     int64_t rows = 0;
     for (int f0 = 0; f0 < n; f0 += nb_max) {
