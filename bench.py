@@ -7,8 +7,9 @@ synthetic frames that is already resident in HBM when the timed region starts.
 One process per GPU; ranks shard frames (weak scaling: the per-GPU batch is
 fixed; --total-frames T: a fixed job, strong scaling), the page DB is replicated, and
 each step ends with ONE RCCL all-gather of the per-frame verdict records, left on
-the device by the library.  --workload cfg2: the L2 k-NN stage of
-BASELINE configs[2] instead.
+the device by the library.  --workload cfg3: BASELINE configs[3] (the
+216 000-frame lecture against a 1000-page deck: a fixed job, strong scaling, the page
+timeline on rank 0); --workload cfg2: the SIFT + L2 matcher of configs[2] instead.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -37,10 +38,17 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "cfg1": dict(frame=(1920, 1080), page=(2001, 1125), pages=100, nfeatures=1000, batch=256,
                  name="configs[1]: 1080p batch=256 vs 100 pages, ORB-1000"),
+    # BASELINE.json configs[3]: the 2 h 1080p@30fps lecture (216 000 frames) against a 1000-page deck, sharded over the GPUs, one
+    # RCCL all-gather of the verdict records per step, the page timeline on rank 0.  A FIXED job (strong scaling): the K timed
+    # steps process total_frames / (K x N) frames per GPU each, in units of `batch` frames drawn from a pool of `batch` distinct
+    # synthetic frames per GPU that stays resident in HBM (the lecture's frames cycle through the pool; every unit runs the whole
+    # hot path, nothing is cached).  ORB-1000 as in configs[1] (the config names no feature count).
+    "cfg3": dict(frame=(1920, 1080), page=(2001, 1125), pages=1000, nfeatures=1000, batch=256, total_frames=216000, lecture=True,
+                 name="configs[3]: 216 000-frame 1080p lecture vs 1000-page deck, ORB-1000, frames sharded over the GPUs, all-gather of verdicts, timeline on rank 0"),
     # BASELINE.json configs[4] shape on one GPU: 4K frames, ORB-2000, 1000-page deck (2 M train descriptors)
     # ("RANSAC homography verify": verify_model 1 = the 8-DOF model of include/slideo_amd.h on frames generated under a true
     # projective map; --verify-model 0 --persp 0 gives the reference's similarity model on similarity frames)
-    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64, verify_model=1, persp=0.1, hdlt=1,
+    "cfg4": dict(frame=(3840, 2160), page=(2001, 1125), pages=1000, nfeatures=2000, batch=64, verify_model=1, persp=0.1,
                  name="configs[4] shape: 4K frames batch=64 vs 1000 pages, ORB-2000, homography verification"),
     # BASELINE.json configs[2]: SIFT-128 descriptors, L2 BFMatcher as an N x M x 128 MFMA contraction, 1080p vs 500 pages:
     # SIFT on the device (csrc/sift.hip.h) feeding the int8 matrix-core L2 matcher (bench_cfg2).
@@ -246,9 +254,13 @@ def main():
                          "(findHomography + warpPerspective; default: the workload's, 1 for cfg4, else 0)")
     ap.add_argument("--hdlt", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="verify_model 1: how a 4-point sample becomes a model (slideo_ocv_variants.hdlt): 0 = cv::findHomography's L^T L + Jacobi eigenvectors "
-                         "(the library's default: fidelity), 1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample; "
-                         "what cfg4 runs by default — end-to-end agreement with form 0 measured in profiles/r04_hdlt_agreement.json), 2 = the closed form "
-                         "(square-to-quad maps); default: the workload's, else 0")
+                         "(the fidelity switch), 1 = the 8x8 system by Gaussian elimination (same models to f64 round-off, ~60x cheaper per sample; "
+                         "the LIBRARY'S DEFAULT since ABI 6 — end-to-end agreement with form 0 measured in profiles/r04_hdlt_agreement.json), 2 = the closed form "
+                         "(square-to-quad maps); default: the library's")
+    ap.add_argument("--verdict-rule", type=int, default=0, choices=[0, 1],
+                    help="0 = the reference's verdict (best re-projection similarity wins, mo/lib.rs:370-389); 1 = the opt-in departure "
+                         "slideo_config.verdict_rule: rating order, similarity only accepts")
+    ap.add_argument("--pool", type=int, default=0, help="distinct resident frames per GPU a step's units cycle through (default: the workload's batch)")
     ap.add_argument("--matcher", default="exact", choices=["exact", "lsh"],
                     help="descriptor index: exact brute force (default; north_star) or the LSH candidate rule of the reference's FLANN index "
                          "(slideo_config.matcher 1: 6 tables, 12-bit keys, multi-probe 1 — recall < 1, and on these descriptors SLOWER than the exact "
@@ -279,6 +291,12 @@ def main():
     # SLIDEO_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks (ranks then
     # share devices and the verdict all-gather goes through host memory); the driver's runs use nccl = RCCL.
     backend = os.environ.get("SLIDEO_BENCH_BACKEND", "nccl")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and torch.cuda.device_count() < local_world:
+        # RCCL needs one device per rank; two ranks on one device do not fail, they hang in the first collective
+        raise SystemExit("bench.py: %d ranks on this node but %d GPU(s) visible — the nccl (= RCCL) backend needs one GPU per rank "
+                         "[rank %d of %d]; SLIDEO_BENCH_BACKEND=gloo lets ranks share devices (control-flow tests only)"
+                         % (local_world, torch.cuda.device_count(), rank, world))
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -308,9 +326,16 @@ def main():
         return
     fw, fh = wl["frame"]; pw, ph = wl["page"]
     B, P = wl["batch"], wl["pages"]
+    if not args.total_frames:
+        args.total_frames = wl.get("total_frames", 0)
     strong = args.total_frames > 0
     if strong:                                   # fixed total job: per-GPU frames per step shrink as GPUs are added
         B = max(1, args.total_frames // (max(args.steps, 1) * world))
+    # A step's B frames go through the library in UNITS of at most `pool` frames, drawn from a pool of `pool` distinct frames per
+    # GPU that is resident in HBM before the timed region (weak mode and the small strong-mode jobs: pool = B, one unit per step,
+    # as before; configs[3]: 10 800 frames per step at N = 1 cycle through 256 resident ones — every unit runs the whole hot path).
+    pool = min(B, args.pool or wl["batch"])
+    units = [(o, min(pool, B - o)) for o in range(0, B, pool)]              # (offset in the step, frames): each reads pool[0:n]
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(64, ncpu // max(world, 1)))
 
@@ -320,14 +345,16 @@ def main():
     verify_model = wl.get("verify_model", 0) if args.verify_model < 0 else args.verify_model
     persp = wl.get("persp", 0.0) if args.persp < 0 else args.persp
     if args.hdlt < 0:
-        args.hdlt = wl.get("hdlt", 0) if verify_model == 1 else 0
+        args.hdlt = _capi.default_config().ocv.hdlt          # the library's default (1 since ABI 6)
     if persp > 0:
-        frames, truth, _ = synth.frames_persp(pages, B, fw, fh, persp=persp, first=rank * B, threads=gen_threads)
+        frames, truth, _ = synth.frames_persp(pages, pool, fw, fh, persp=persp, first=rank * pool, threads=gen_threads)
     else:
-        frames, truth, _ = synth.frames(pages, B, fw, fh, first=rank * B, threads=gen_threads)
+        frames, truth, _ = synth.frames(pages, pool, fw, fh, first=rank * pool, threads=gen_threads)
+    truth_step = np.concatenate([truth[:n] for _, n in units])             # the truth of a step's B frames
     t_gen = time.time() - t0
 
-    cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0)
+    cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0,
+                               verdict_rule=args.verdict_rule)
     m = _capi.Matcher(cfg, device=local_rank)
     m.set_knn_engine(args.knn)
     args.inflight = min(args.inflight or m.max_in_flight(), m.max_in_flight())
@@ -345,45 +372,52 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     verdict_words = 4
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    # The library leaves a unit's verdict records in one of NBUF device tensors (rotating), the step's all-gather reads it on
-    # torch's stream, and an event recorded behind the collective guards the tensor's NEXT use, NBUF steps later — by then it
-    # has long completed, so no step ends in a host wait for the collective (r03 synchronised the stream every step).
+    # The library leaves a unit's verdict records in the step's slice of one of NBUF device tensors (rotating), the step's
+    # all-gather reads it on torch's stream, and an event recorded behind the collective guards the tensor's NEXT use, NBUF steps
+    # later — by then it has long completed, so no step ends in a host wait for the collective.
     NBUF = max(2, args.inflight + 1)
     d_verdicts = [torch.zeros((B, verdict_words), dtype=torch.int32, device=coll_dev) for _ in range(NBUF)]
     buf_free = [None] * NBUF
     d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device=coll_dev) if use_dist else None
     on_dev = use_dist and coll_dev == "cuda"          # the library leaves the records on the device
     step_no = [0]
+    v_step = [np.zeros(B, _capi.VERDICT_DTYPE), np.zeros(B, _capi.VERDICT_DTYPE)]    # host copy of the step being collected / the last complete one
 
-    def collect_step(ticket, local):
-        """Collects one unit; unless `local`, runs the step's one collective (RCCL over xGMI) on its verdict records."""
-        if local or not use_dist:
-            return m.collect(ticket)
+    def collect_unit(item, local):
+        """Collects one unit into its step's slice; behind a step's LAST unit — unless `local` — the step's one collective (RCCL
+        over xGMI) runs on the step's verdict records."""
+        ticket, ofs, n, last = item
+        gather = use_dist and not local
         b = step_no[0] % NBUF
-        step_no[0] += 1
-        if buf_free[b] is not None:
+        if gather and ofs == 0 and buf_free[b] is not None:
             buf_free[b].synchronize()                # an event NBUF steps old: returns at once
-        v = m.collect(ticket, dev_out=d_verdicts[b].data_ptr() if on_dev else 0)
-        if not on_dev:                               # gloo stand-in: host tensors
-            d_verdicts[b].copy_(torch.from_numpy(v.view(np.int32).reshape(B, verdict_words)), non_blocking=False)
-        dist.all_gather_into_tensor(d_all, d_verdicts[b])      # the one collective of the path
-        if on_dev:
-            buf_free[b] = torch.cuda.Event()
-            buf_free[b].record()
-        return v
+        v = m.collect(ticket, dev_out=(d_verdicts[b].data_ptr() + ofs * 4 * verdict_words) if (gather and on_dev) else 0)
+        v_step[0][ofs:ofs + n] = v
+        if gather and not on_dev:                    # gloo stand-in: host tensors
+            d_verdicts[b][ofs:ofs + n].copy_(torch.from_numpy(v.view(np.int32).reshape(n, verdict_words)), non_blocking=False)
+        if last:
+            v_step[0], v_step[1] = v_step[1], v_step[0]
+            if gather:
+                dist.all_gather_into_tensor(d_all, d_verdicts[b])      # the one collective of the path
+                step_no[0] += 1
+                if on_dev:
+                    buf_free[b] = torch.cuda.Event()
+                    buf_free[b].record()
 
-    def run_steps(k, depth=None, local=False):
-        """k steps; a step = one batch of B frames through the whole hot path.  `depth` batches are kept in flight
-        (submit i+depth-1 before collecting i) so that the ORB / verify stages of some batches share the GPU with the kNN of others."""
-        v, pending = None, []
+    def run_steps(k, depth=None, local=False, units_of_step=None):
+        """k steps; a step = B frames through the whole hot path, in units of <= `pool` frames.  `depth` units are kept in flight
+        (submit i+depth-1 before collecting i) so that the ORB / verify stages of some units share the GPU with the kNN of others.
+        Returns the verdicts of the last step."""
+        pending = []
         depth = depth or (1 if args.no_overlap else max(1, args.inflight))
         for _ in range(k):
-            if len(pending) == depth:
-                v = collect_step(pending.pop(0), local)
-            pending.append(m.submit_dev(d_frames.data_ptr(), B, fw, fh, stream=stream))
+            for ui, (ofs, n) in enumerate(units_of_step or units):
+                if len(pending) == depth:
+                    collect_unit(pending.pop(0), local)
+                pending.append((m.submit_dev(d_frames.data_ptr(), n, fw, fh, stream=stream), ofs, n, ui == len(units_of_step or units) - 1))
         while pending:
-            v = collect_step(pending.pop(0), local)
-        return v
+            collect_unit(pending.pop(0), local)
+        return v_step[1].copy()
 
     def barrier():
         if use_dist:
@@ -405,7 +439,7 @@ def main():
     prof_alone = None
     if rank == 0 and not args.no_overlap and args.inflight > 1:
         m.set_profiling(True)
-        run_steps(3, depth=1, local=True)
+        run_steps(3, depth=1, local=True, units_of_step=units[:1])      # (three launches of a step's first unit)
         torch.cuda.synchronize()
         prof_alone, pairs_alone = m.read_profile()
         m.set_profiling(False)
@@ -418,9 +452,34 @@ def main():
         mine = d_all[rank * B:(rank + 1) * B].cpu().numpy().view(_capi.VERDICT_DTYPE).reshape(-1)
         gathered_ok = bool(np.array_equal(mine, v))
 
-    acc = float((v["page_idx"] == truth).mean())
+    acc = float((v["page_idx"] == truth_step).mean())
     total_frames = args.steps * B * world
     fps = total_frames / dt
+
+    # configs[3]: the page timeline on rank 0 from the gathered records of the last step — the end-of-video sentinel, the sort by
+    # time and the removal of consecutive duplicates of mo/lib.rs:185-189,229-244 (slideo_amd/distributed.py timeline) over this
+    # step's share of the lecture (its world x B sampled frames, 5 s apart: mo/lib.rs:145,175), beside the same over the truth
+    lecture = None
+    if wl.get("lecture"):
+        from slideo_amd import distributed as D
+        if use_dist:
+            t_all = torch.zeros(world * B, dtype=torch.int32, device=coll_dev)
+            dist.all_gather_into_tensor(t_all, torch.from_numpy(truth_step.astype(np.int32)).to(coll_dev))
+            truth_all = t_all.cpu().numpy()
+            v_all = d_all.cpu().numpy().view(_capi.VERDICT_DTYPE).reshape(-1)
+        else:
+            truth_all, v_all = truth_step, v
+        if rank == 0:
+            S = len(v_all)
+            times = 5.0 * np.arange(S)
+            fidx = (times * 30.0).astype(np.int64)
+            tl = D.timeline(v_all, times, fidx, 5.0 * S, int(5.0 * S * 30.0))
+            tv = np.zeros(S, _capi.VERDICT_DTYPE); tv["page_idx"] = truth_all
+            tt = D.timeline(tv, times, fidx, 5.0 * S, int(5.0 * S * 30.0))
+            lecture = {"sampled_frames_in_the_last_step": S, "timeline_entries": len(tl), "truth_entries": len(tt),
+                       "entries_equal_to_truth": len(set(tl) & set(tt)),
+                       "job": "%d frames = %d steps x %d GPU(s) x %d frames; a step's frames per GPU run as %d unit(s) of <= %d frames"
+                              % (total_frames, args.steps, world, B, len(units), pool)}
 
     out = {
         "metric": "frames/sec matched (1080p vs 500-page ORB set)" if args.workload == "headline" else "frames/sec matched",
@@ -433,7 +492,8 @@ def main():
                    "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
-                   "inputs": "the same %d synthetic frames per GPU are re-submitted every step, resident in HBM before the timed region (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % B,
+                   "inputs": "%d distinct synthetic frames per GPU, resident in HBM before the timed region; a step submits its %d frames per GPU as %d unit(s) of <= %d frames read from that pool, every step again (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % (pool, B, len(units), pool),
+                   "units_per_step": len(units), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
                    "collective": ({"backend": backend, "all_gather_of_verdicts_checked": gathered_ok} if use_dist else None),
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
                    "accuracy_vs_synthetic_truth": round(acc, 4),
@@ -509,9 +569,10 @@ def main():
                 # launches of overlapped batches run one block per CU — stage_knn.hip share_pad — beside the other stages: a
                 # launch then lasts longer than a step while the job as a whole gets faster; this is the figure that follows the job.)
                 step_s = out["ms_per_step"] * 1e-3
-                out["roofline"]["over_step"] = {"achieved": round(2.0 * 256 * pairs_per_launch / step_s / 1e12, 2),
-                                                "frac": round(2.0 * 256 * pairs_per_launch / step_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                "note": "executed flops of one launch / ms_per_step (one launch per step and GPU)"}
+                per_step = pairs_per_launch * len(units)                      # (one launch per unit)
+                out["roofline"]["over_step"] = {"achieved": round(2.0 * 256 * per_step / step_s / 1e12, 2),
+                                                "frac": round(2.0 * 256 * per_step / step_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
+                                                "note": "executed flops of a step's launches / ms_per_step (%d launch(es) per step and GPU)" % len(units)}
             if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
                 a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
                 unit_work = (2.0 * 256 if args.knn != "valu" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
@@ -549,7 +610,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0)
+        ocfg = pyoracle.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0,
+                                       verdict_rule=args.verdict_rule)
         budget = host_cpu_budget()
         cores = max(1, min(ncpu, budget["usable"]))
         db = pyoracle.PageDB(ocfg)
@@ -560,7 +622,7 @@ def main():
         assert rc == 0 and db.descriptor_count == M, "CPU restatement and GPU page DB disagree"
         # one frame per thread (mirrors rayon's spawn_fifo, mo/lib.rs:213); the sample is the benchmark batch, repeated until the
         # leg has run for ~10 s so that start-up and the slowest thread do not dominate
-        ns = args.cpu_sample or B
+        ns = min(args.cpu_sample or pool, pool)
         reps, t_cpu = 0, 0.0
         while t_cpu < 10.0 and reps < 20:
             t0 = time.time()

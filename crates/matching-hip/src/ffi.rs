@@ -1,10 +1,10 @@
-//! Hand-written declarations of include/slideo_amd.h (ABI 5) — what bindgen would emit for the entry points this crate
+//! Hand-written declarations of include/slideo_amd.h (ABI 6) — what bindgen would emit for the entry points this crate
 //! uses.  Field order and types mirror the C structs exactly; tests/test_capi_load.py pins the C side's layout
-//! (sizeof(slideo_config) == 160) and `assert_abi()` below pins the version at run time.
+//! (sizeof(slideo_config) == 168) and `assert_abi()` below pins the version at run time.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_char;
 
-pub const SLIDEO_ABI_VERSION: u32 = 5;
+pub const SLIDEO_ABI_VERSION: u32 = 6;
 
 /// slideo_ocv_variants: which restatement of each OpenCV primitive runs.  slideo_config_default fills it; the
 /// application never touches it.
@@ -54,6 +54,8 @@ pub struct slideo_config {
     pub lsh_tables: i32,
     pub lsh_key_bits: i32,
     pub lsh_multi_probe: i32,
+    /// 0 = the reference's verdict (best similarity, mo/lib.rs:370-389; default); 1 = rating order, similarity only accepts
+    pub verdict_rule: i32,
     pub ocv: slideo_ocv_variants,
 }
 
@@ -88,7 +90,8 @@ pub struct slideo_group {
 extern "C" {
     pub fn slideo_abi_version() -> u32;
     pub fn slideo_config_default(cfg: *mut slideo_config);
-    pub fn slideo_device_count() -> i32;
+    /// members of a group (n_devices 0 at create = every gfx950 device of the node)
+    pub fn slideo_group_device_count(g: *const slideo_group) -> i32;
     pub fn slideo_group_create(
         cfg: *const slideo_config,
         n_devices: i32,
@@ -148,6 +151,6 @@ pub fn assert_abi() {
         "libslideo_amd.so has ABI {} but this crate was written for ABI {}",
         v, SLIDEO_ABI_VERSION
     );
-    assert_eq!(std::mem::size_of::<slideo_config>(), 160);
+    assert_eq!(std::mem::size_of::<slideo_config>(), 168);
     assert_eq!(std::mem::size_of::<slideo_verdict>(), 16);
 }

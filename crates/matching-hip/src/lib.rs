@@ -85,16 +85,14 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
         let len = images.len() as u64;
         let mut cfg = std::mem::MaybeUninit::<ffi::slideo_config>::uninit();
         let mut h: *mut ffi::slideo_group = std::ptr::null_mut();
-        let devices: Vec<i32> = if self.devices.is_empty() {
-            (0..unsafe { ffi::slideo_device_count() }.max(1)).collect() // (no device at all: create reports it)
-        } else {
-            self.devices.clone()
-        };
+        // no explicit list: n_devices 0 = every gfx950 device of the node, enumerated by the library by its own HIP
+        // ordinals (no device at all: create reports it)
+        let devices_ptr = if self.devices.is_empty() { std::ptr::null() } else { self.devices.as_ptr() };
         unsafe {
             ffi::slideo_config_default(cfg.as_mut_ptr()); // the reference's literals (mo/feature_extractor.rs:13-23 etc.)
             check(
                 std::ptr::null_mut(),
-                ffi::slideo_group_create(cfg.as_ptr(), devices.len() as i32, devices.as_ptr(), &mut h),
+                ffi::slideo_group_create(cfg.as_ptr(), self.devices.len() as i32, devices_ptr, &mut h),
             );
             if let Some(ratio) = self.sift_ratio {
                 let mut sc = std::mem::MaybeUninit::<ffi::slideo_sift_config>::uninit();
@@ -107,7 +105,8 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
         // (slideo_group_set_progress — a C callback for callers without a reporter of their own — is not needed).
         progress_reporter.report(0, len, "Analyzing PDF pages...");
         let mut done = 0u64;
-        for group in images.chunks(32 * devices.len()) {
+        let n_members = unsafe { ffi::slideo_group_device_count(h) }.max(1) as usize;
+        for group in images.chunks(32 * n_members) {
             let decoded: Vec<decode::BgrImage> =
                 group.iter().map(|i| decode::decode_page_bgr(i.get_path())).collect();
             let ptrs: Vec<*const u8> = decoded.iter().map(|d| d.data.as_ptr()).collect();
@@ -138,7 +137,7 @@ impl<'i> ImageVideoMatcher<'i> for HipImageVideoMatcher {
         Box::new(HipVideoMatcher {
             handle: Arc::new(Handle { raw: Mutex::new(RawHandle(h)) }),
             images: Arc::new(images),
-            n_devices: devices.len(),
+            n_devices: n_members,
         })
     }
 }

@@ -68,7 +68,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 5
+#define SLIDEO_ABI_VERSION 6
 
 enum {
     SLIDEO_OK = 0,
@@ -85,9 +85,10 @@ enum {
  * (Cargo.lock:1723-1724, .github/workflows/ci.yml:18), whose source is neither under the reference
  * repository nor in this image; every primitive whose exact rounding could only be RECALLED (SURVEY.md
  * Appendix A, confidence M / L) is therefore restated in more than one form, selected here, shared by the
- * kernels' host tables (csrc/geom.h) and by the CPU restatement (oracle/).  Value 0 is always the default
- * = the best estimate of what a stock 4.5.2 build (SSE3 baseline, AVX2 dispatch, IPP on: ci/install-bionic.sh)
- * runs for the reference's calls; DESIGN.md section 5 says why.  tools/pin_opencv.py dumps OpenCV's own
+ * kernels' host tables (csrc/geom.h) and by the CPU restatement (oracle/).  Value 0 is the default of every switch that
+ * restates a call the reference makes = the best estimate of what a stock 4.5.2 build (SSE3 baseline, AVX2 dispatch, IPP on:
+ * ci/install-bionic.sh) runs for it; DESIGN.md section 5 says why.  (`hdlt`, which belongs to an extension the reference never
+ * runs, defaults to 1: see there.)  tools/pin_opencv.py dumps OpenCV's own
  * outputs where cv2 4.5.2 exists, and tests/test_opencv_pin.py then names the matching value of each switch.
  * The HIP library implements the values marked [hip]; others fail slideo_matcher_create with
  * SLIDEO_ERR_UNSUPPORTED (the CPU restatement implements all of them). */
@@ -134,6 +135,9 @@ typedef struct slideo_ocv_variants {
     uint32_t rng_mul;             /* 4164903690 */
     /* verify_model 1 only: the homography of a point set, HomographyEstimatorCallback::runKernel of
      * calib3d/src/fundam.cpp (recalled; no counterpart in the reference, which never fits a homography)
+     * DEFAULT 1 since ABI 6: the three forms give identical verdicts, survivals and inlier counts on all 9000 candidates of
+     * the headline shape (profiles/r04_hdlt_agreement.json; form 2: 99.98 %), form 0 costs 7.5x the whole step, and there
+     * is no reference behaviour to be faithful to — 0 stays as the switch for fidelity to cv::findHomography's rounding.
      *   0 [hip] normalised DLT: centroid / mean-absolute-deviation normalisation, the 9x9 normal matrix L^T L
      *           accumulated in f64, cv::eigen = the Jacobi sweep of core/src/lapack.cpp (JacobiImpl_, pivot =
      *           largest off-diagonal element, its own hypot), H = the eigenvector of the smallest eigenvalue,
@@ -210,6 +214,13 @@ typedef struct slideo_config {
     int32_t lsh_tables;           /* 6  (mo/flann.rs:16) */
     int32_t lsh_key_bits;         /* 12 (mo/flann.rs:17) */
     int32_t lsh_multi_probe;      /* 1  (mo/flann.rs:18) */
+    /* Opt-in DEPARTURE from the reference's verdict (mo/lib.rs:370-389: survivors sorted by re-projection similarity, the
+     * first above min_similarity wins).  0 = that rule.  1 = survivors keep their RATING order (inlier count descending, ties
+     * in candidate order: mo/lib.rs:329) and the first whose similarity exceeds min_similarity wins — the similarity becomes
+     * an acceptance test instead of the ranking.  Why it exists: with verify_model 1 a template-sharing sibling page
+     * re-projects its shared template as well as the true page and wins by a few thousandths of similarity on ~13 % of the
+     * synthetic headline frames, while the true page has the most inliers (DESIGN.md section 5 has the measured effect). */
+    int32_t verdict_rule;         /* 0 */
     /* which restatement of each OpenCV primitive to run (all 0 / 4164903690 by default) */
     slideo_ocv_variants ocv;
 } slideo_config;
@@ -500,12 +511,17 @@ int32_t     slideo_last_frame_candidates(const slideo_matcher* m, int32_t frame_
  * in-process form is the device-to-host copy each member makes anyway.  Page analysis is sharded the same way and every
  * member appends the whole call in page order.  Results are those of a single matcher, bit for bit, whatever N is.
  * `devices`: HIP ordinals, one member each (an ordinal may repeat: two members then share a device).  A group is not
- * re-entrant (like a matcher); progress callbacks fire from the member threads.  (One PROCESS per GPU — where every rank needs
+ * re-entrant (like a matcher); progress callbacks fire from the member threads, one at a time, with a count that never
+ * decreases.  (One PROCESS per GPU — where every rank needs
  * the whole timeline — is the other multi-GPU form: slideo_match_frames_collect_dev leaves a rank's records in device memory
  * for ONE RCCL all-gather, bench.py / slideo_amd/distributed.py.) */
 typedef struct slideo_group slideo_group;
 /* gfx950 devices visible to this process (0 when there is none: nothing here runs without one). */
 int32_t     slideo_device_count(void);
+/* Their HIP ordinals, ascending: fills at most `capacity` entries of ordinals_out (may be NULL) and returns how many there
+ * are.  On a node whose HIP ordinals also name other architectures the ordinals are not 0 .. count-1. */
+int32_t     slideo_device_list(int32_t* ordinals_out, int32_t capacity);
+/* n_devices == 0 (devices may then be NULL): one member per gfx950 device of the node = slideo_device_list's ordinals. */
 int32_t     slideo_group_create(const slideo_config* cfg, int32_t n_devices, const int32_t* devices, slideo_group** out);
 void        slideo_group_destroy(slideo_group* g);
 /* Message of the last failure on `g` (of the last failed create when g is NULL); names the member and its device. */

@@ -31,7 +31,7 @@ class Config(C.Structure):
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
         ("verify_model", C.c_int32), ("matcher", C.c_int32), ("lsh_tables", C.c_int32), ("lsh_key_bits", C.c_int32),
-        ("lsh_multi_probe", C.c_int32), ("ocv", OcvVariants),
+        ("lsh_multi_probe", C.c_int32), ("verdict_rule", C.c_int32), ("ocv", OcvVariants),
     ]
 
 

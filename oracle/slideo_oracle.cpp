@@ -484,7 +484,7 @@ static bool config_supported(const slideo_config& c) {
            c.ocv.gray >= 0 && c.ocv.gray <= 1 && c.ocv.blur >= 0 && c.ocv.blur <= 3 && c.ocv.resize >= 0 && c.ocv.resize <= 1 &&
            c.ocv.atan >= 0 && c.ocv.atan <= 1 && c.ocv.warp >= 0 && c.ocv.warp <= 1 && c.ocv.area >= 0 && c.ocv.area <= 1 &&
            c.ocv.lm >= 0 && c.ocv.lm <= 1 && c.ocv.hdlt >= 0 && c.ocv.hdlt <= 2 &&
-           c.verify_model >= 0 && c.verify_model <= 1 && c.matcher >= 0 && c.matcher <= 1 &&
+           c.verify_model >= 0 && c.verify_model <= 1 && c.matcher >= 0 && c.matcher <= 1 && c.verdict_rule >= 0 && c.verdict_rule <= 1 &&
            (c.matcher == 0 || (c.lsh_tables >= 1 && c.lsh_tables <= 8 && c.lsh_key_bits >= 1 && c.lsh_key_bits <= 16 && c.lsh_multi_probe >= 0 &&
                                c.lsh_multi_probe <= 2 && !(c.ratio_test > 0.f)));
 }
@@ -1834,7 +1834,9 @@ static void match_frame(const so_pagedb& db, const uint8_t* bgr, int w, int h, i
         r.survived = true;
     }
     std::vector<Rated> fin = surv;
-    std::stable_sort(fin.begin(), fin.end(), [](const Rated& a, const Rated& b) { return a.sim > b.sim; });  // :370
+    // verdict_rule 1 (opt-in departure, include/slideo_amd.h): the survivors keep their rating order (:329) and the similarity
+    // only accepts; 0 = the reference: sorted by similarity
+    if (c.verdict_rule == 0) std::stable_sort(fin.begin(), fin.end(), [](const Rated& a, const Rated& b) { return a.sim > b.sim; });  // :370
     for (const Rated& r : fin)
         if (r.sim > c.min_similarity) {                        // :381
             out.page_idx = r.page; out.similarity = r.sim; out.inliers = (int)r.rating;
@@ -1874,8 +1876,10 @@ void so_config_default(slideo_config* c) {
     c->ratio_test = 0.0f;                                          // extension, off
     c->verify_model = 0;                                           // the reference's estimateAffinePartial2D
     c->matcher = 0; c->lsh_tables = 6; c->lsh_key_bits = 12; c->lsh_multi_probe = 1;   // exact search; mo/flann.rs:16-18
+    c->verdict_rule = 0;                                           // mo/lib.rs:370-389: the best re-projection similarity wins
     std::memset(&c->ocv, 0, sizeof(c->ocv));                       // every OpenCV-variant switch at its default (0)
     c->ocv.rng_mul = 4164903690u;                                  // CV_RNG_COEFF
+    c->ocv.hdlt = 1;                                               // verify_model 1 only (no reference counterpart): the elimination form, as the library's default
 }
 
 int so_config_supported(const slideo_config* c) { return config_supported(*c) ? 1 : 0; }

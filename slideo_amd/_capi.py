@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("min_rating", C.c_double), ("min_rating_ratio", C.c_double), ("min_similarity", C.c_float),
         ("small_area", C.c_int32), ("changed_similarity", C.c_float), ("ratio_test", C.c_float),
         ("verify_model", C.c_int32), ("matcher", C.c_int32), ("lsh_tables", C.c_int32), ("lsh_key_bits", C.c_int32),
-        ("lsh_multi_probe", C.c_int32),
+        ("lsh_multi_probe", C.c_int32), ("verdict_rule", C.c_int32),
         ("ocv", OcvVariants),
     ]
 
@@ -74,7 +74,7 @@ EXPORTS = [
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
     "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
     "slideo_sift_config_default", "slideo_sift_bgr8", "slideo_sift_frames_dev", "slideo_sift_layer_bgr8", "slideo_knn_lsh",
-    "slideo_device_count", "slideo_group_create", "slideo_group_destroy", "slideo_group_last_error", "slideo_group_device_count",
+    "slideo_device_count", "slideo_device_list", "slideo_group_create", "slideo_group_destroy", "slideo_group_last_error", "slideo_group_device_count",
     "slideo_group_member", "slideo_group_set_progress", "slideo_group_use_sift", "slideo_group_add_pages_bgr8",
     "slideo_group_finalize_pages", "slideo_group_page_count", "slideo_group_descriptor_count", "slideo_group_match_frames_bgr8",
     "slideo_group_last_frame_candidates", "slideo_group_changed_mask_bgr8", "slideo_group_match_kept_frames",
@@ -117,6 +117,7 @@ def lib():
         L.slideo_group_member.restype = C.c_void_p
         L.slideo_group_member.argtypes = [C.c_void_p, C.c_int32]
         L.slideo_group_device_count.argtypes = [C.c_void_p]
+        L.slideo_device_list.argtypes = [C.c_void_p, C.c_int32]
         L.slideo_group_page_count.argtypes = [C.c_void_p]
         L.slideo_group_descriptor_count.argtypes = [C.c_void_p]
         L.slideo_group_descriptor_count.restype = C.c_int64
@@ -440,13 +441,16 @@ class Group:
 
     def __init__(self, cfg=None, devices=None):
         self.cfg = cfg if cfg is not None else default_config()
-        if devices is None:
-            devices = list(range(max(1, int(lib().slideo_device_count()))))
-        self.devices = [int(d) for d in devices]
         self._h = C.c_void_p()
         self._cb = None
-        arr = (C.c_int32 * len(self.devices))(*self.devices)
-        rc = lib().slideo_group_create(C.byref(self.cfg), len(self.devices), arr, C.byref(self._h))
+        if devices is None:
+            # every gfx950 device of the node: the library enumerates them by their own HIP ordinals (n_devices 0)
+            rc = lib().slideo_group_create(C.byref(self.cfg), 0, None, C.byref(self._h))
+            self.devices = device_list() if rc == OK else []
+        else:
+            self.devices = [int(d) for d in devices]
+            arr = (C.c_int32 * len(self.devices))(*self.devices)
+            rc = lib().slideo_group_create(C.byref(self.cfg), len(self.devices), arr, C.byref(self._h))
         if rc != OK:
             raise SlideoError(rc, lib().slideo_group_last_error(None).decode())
 
@@ -544,6 +548,14 @@ class Group:
 def device_count():
     """gfx950 devices visible to this process."""
     return int(lib().slideo_device_count())
+
+
+def device_list():
+    """Their HIP ordinals (not necessarily 0 .. count-1 on a node that also holds other architectures)."""
+    n = int(lib().slideo_device_list(None, 0))
+    arr = (C.c_int32 * max(n, 1))()
+    n = min(n, int(lib().slideo_device_list(arr, n)))
+    return [int(arr[i]) for i in range(n)]
 
 
 def small_size(w, h, small_area=120000):

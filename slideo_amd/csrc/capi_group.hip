@@ -13,7 +13,6 @@
 // No kernel lives in this unit; it only drives the members through the functions of runtime.hpp.
 #include "runtime.hpp"
 
-#include <atomic>
 #include <thread>
 
 using namespace slideo;
@@ -26,7 +25,10 @@ struct slideo_group {
     // progress of a sharded call: the members report their own (done, total); the group reports the sum
     struct Tramp { slideo_group* g = nullptr; uint64_t last = 0; };
     std::vector<Tramp> tramps;
-    std::atomic<uint64_t> done{0};
+    // (reports are serialised: one member thread at a time advances `done` and calls the sink, so a sink sees a monotonic count
+    // and is never entered twice at once — what a single matcher's caller gets)
+    std::mutex progress_mutex;
+    uint64_t done = 0;
     uint64_t total = 0;
     const char* msg_override = nullptr;
     // shards of the last match call (trace lookup) and of the last changed-mask call (kept frames)
@@ -60,8 +62,9 @@ void group_progress_tramp(void* user, uint64_t done, uint64_t total, const char*
     if (!g->progress || done <= t->last) { t->last = std::max(t->last, done); return; }
     const uint64_t d = done - t->last;
     t->last = done;
-    const uint64_t now = g->done.fetch_add(d) + d;
-    g->progress(g->progress_user, std::min(now, g->total), g->total, g->msg_override ? g->msg_override : msg);
+    std::lock_guard<std::mutex> lk(g->progress_mutex);
+    g->done += d;
+    g->progress(g->progress_user, std::min(g->done, g->total), g->total, g->msg_override ? g->msg_override : msg);
 }
 
 // fn(member index) on one host thread per member; the first failure (lowest member) is rethrown on the caller's thread
@@ -112,22 +115,38 @@ void begin_progress(slideo_group* g, uint64_t total, const char* msg_override) {
 
 extern "C" {
 
-int32_t slideo_device_count(void) {
+int32_t slideo_device_list(int32_t* ordinals_out, int32_t capacity) {
     int ndev = 0, n = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
     for (int d = 0; d < ndev; ++d) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::string(prop.gcnArchName).find("gfx950") != std::string::npos) ++n;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::string(prop.gcnArchName).find("gfx950") != std::string::npos) {
+            if (ordinals_out && n < capacity) ordinals_out[n] = d;
+            ++n;
+        }
     }
     return n;
 }
 
+int32_t slideo_device_count(void) { return slideo_device_list(nullptr, 0); }
+
 int32_t slideo_group_create(const slideo_config* cfg, int32_t n_devices, const int32_t* devices, slideo_group** out) {
     slideo_group* none = nullptr;
     GROUP_TRY
-    if (!cfg || !out || !devices) fail(SLIDEO_ERR_INVALID_ARG, "null cfg/devices/out");
+    if (!cfg || !out) fail(SLIDEO_ERR_INVALID_ARG, "null cfg/out");
     *out = nullptr;
-    if (n_devices < 1 || n_devices > 64) fail(SLIDEO_ERR_INVALID_ARG, "n_devices must be 1..64");
+    // n_devices 0 (devices may be null): every gfx950 device of the node, by its own HIP ordinal — a device of another
+    // architecture at a lower ordinal shifts nothing (the count alone would name ordinals 0 .. n-1)
+    std::vector<int32_t> all;
+    if (n_devices == 0) {
+        all.resize(64);
+        const int32_t n = slideo_device_list(all.data(), 64);
+        if (n < 1) fail(SLIDEO_ERR_NO_DEVICE, "no gfx950 device visible (this library has no CPU fallback)");
+        all.resize((size_t)std::min(n, 64));
+        devices = all.data(); n_devices = (int32_t)all.size();
+    }
+    if (!devices) fail(SLIDEO_ERR_INVALID_ARG, "null devices with n_devices > 0");
+    if (n_devices < 1 || n_devices > 64) fail(SLIDEO_ERR_INVALID_ARG, "n_devices must be 0 (all) or 1..64");
     std::unique_ptr<slideo_group> g(new slideo_group());
     struct Guard { slideo_group* g; ~Guard() { if (g) for (slideo_matcher* m : g->members) slideo_matcher_destroy(m); } } guard{g.get()};
     for (int i = 0; i < n_devices; ++i) {
@@ -195,10 +214,12 @@ int32_t slideo_group_add_pages_bgr8(slideo_group* g, int32_t n_pages, const uint
         shard_range(n_pages, r, N, lo, hi);
         if (hi > lo) analyse_pages(g->members[r], hi - lo, data + lo, width + lo, height + lo, stride_bytes + lo, got[r], 0, (uint64_t)(hi - lo));
     });
-    // ... and every member's database receives the whole call, in page order
-    for (slideo_matcher* m : g->members)
+    // ... and every member's database receives the whole call, in page order — each on its own thread (the records are plain
+    // host data: N copies of the deck's records side by side instead of one after the other on the caller's thread)
+    for_each_member(g, [&](int me) {
         for (int r = 0; r < N; ++r)
-            for (const HostPage& pg : got[r]) append_page(m, pg);
+            for (const HostPage& pg : got[r]) append_page(g->members[me], pg);
+    });
     if (g->progress) g->progress(g->progress_user, total, total, "PDF page analysis successful.");   // lib.rs:58
     GROUP_CATCH(g)
 }

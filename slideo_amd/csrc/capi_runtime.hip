@@ -384,8 +384,10 @@ void slideo_config_default(slideo_config* c) {
     c->ratio_test = 0.0f;
     c->verify_model = 0;                             // the reference's estimateAffinePartial2D
     c->matcher = 0; c->lsh_tables = 6; c->lsh_key_bits = 12; c->lsh_multi_probe = 1;      // exact search; mo/flann.rs:16-18
+    c->verdict_rule = 0;                             // mo/lib.rs:370-389: the best re-projection similarity wins
     std::memset(&c->ocv, 0, sizeof(c->ocv));         // every OpenCV-variant switch at its default
     c->ocv.rng_mul = 4164903690u;                    // CV_RNG_COEFF
+    c->ocv.hdlt = 1;                                 // (verify_model 1 only, no reference counterpart: the form proven identical end to end, 1/60 of form 0's cost)
 }
 
 const char* slideo_last_error(const slideo_matcher* m) {
@@ -421,7 +423,8 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
     mm->host_unit = (int)std::max(0l, env_long("SLIDEO_HOST_UNIT", 32));
     mm->orb_chain = env_long("SLIDEO_ORB_CHAIN", 1) != 0;
-    {   // a third of a 288 GB device for the SIFT pyramids (a pass of 256 1080p frames: 90 GB; three passes of 86 at 24 GB cost 6 ms of 68)
+    {   // a third of a 288 GB device for the SIFT pyramids (a pass of 256 1080p frames: 90 GB; three passes of 86 at 24 GB cost 6 ms of 68);
+        // an upper bound only — every call also stays under half of the memory that is free when it runs (stage_sift.hip sift_batch)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b >= ((size_t)192 << 30)) mm->sift_ws_mb = 96l << 10;
     }

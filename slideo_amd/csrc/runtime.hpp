@@ -84,11 +84,14 @@ struct Slot {
     // (hipFree + hipMalloc, device-wide stalls, tens of ms for the GB-sized ones) in the middle of a steady-state
     // stream of batches; sizing every idle slot when one grows keeps every later unit allocation-free.
     void match_capacity(const Slot& o) {
-        DevBuf* mine[] = {&d_stage, &d_pyr, &d_blur, &d_cand, &d_hist, &d_candcount, &d_flags, &d_thr, &d_lvlofs, &d_kpcount, &d_qofs,
-                          &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs, &d_blurmask};
-        const DevBuf* theirs[] = {&o.d_stage, &o.d_pyr, &o.d_blur, &o.d_cand, &o.d_hist, &o.d_candcount, &o.d_flags, &o.d_thr, &o.d_lvlofs,
+        // (d_stage is NOT in the list: slot 0's holds the frames slideo_changed_mask_bgr8 kept, and host-frame units size it
+        // themselves before their copy)
+        DevBuf* mine[] = {&d_pyr, &d_blur, &d_cand, &d_hist, &d_candcount, &d_flags, &d_thr, &d_lvlofs, &d_kpcount, &d_qofs,
+                          &d_info, &d_items, &d_kp, &d_desc, &d_keys, &d_knn_pend, &d_votes, &d_gpts, &d_gmask, &d_fcs, &d_verdicts, &d_pairs, &d_blurmask,
+                          &d_qkeys, &d_tail, &d_refine};
+        const DevBuf* theirs[] = {&o.d_pyr, &o.d_blur, &o.d_cand, &o.d_hist, &o.d_candcount, &o.d_flags, &o.d_thr, &o.d_lvlofs,
                                   &o.d_kpcount, &o.d_qofs, &o.d_info, &o.d_items, &o.d_kp, &o.d_desc, &o.d_keys, &o.d_knn_pend, &o.d_votes,
-                                  &o.d_gpts, &o.d_gmask, &o.d_fcs, &o.d_verdicts, &o.d_pairs, &o.d_blurmask};
+                                  &o.d_gpts, &o.d_gmask, &o.d_fcs, &o.d_verdicts, &o.d_pairs, &o.d_blurmask, &o.d_qkeys, &o.d_tail, &o.d_refine};
         static_assert(sizeof(mine) / sizeof(mine[0]) == sizeof(theirs) / sizeof(theirs[0]), "same buffer lists");
         for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); ++i) mine[i]->reserve_cap(theirs[i]->cap);
         h_info.reserve_cap(o.h_info.cap); h_out.reserve_cap(o.h_out.cap);

@@ -150,7 +150,15 @@ static int64_t sift_batch(slideo_matcher* m, const uint8_t* frames_dev, int n, i
     // frames per pass under the budget for the pyramids (265 MB + 33 MB per 1080p frame; 96 GB on an MI355X, 24 GB on a small device;
     // SLIDEO_SIFT_WS_MB: tests)
     const size_t per = ((size_t)g.g_frame + (size_t)g.ow[0] * g.oh[0]) * 4;
-    const size_t budget = (size_t)std::max(env_long("SLIDEO_SIFT_WS_MB", m->sift_ws_mb), 1l) << 20;       // (read per call: a test squeezes it)
+    size_t budget = (size_t)std::max(env_long("SLIDEO_SIFT_WS_MB", m->sift_ws_mb), 1l) << 20;             // (read per call: a test squeezes it)
+    {
+        // ... and under what the device can give NOW: half of the free memory plus what the pyramids already hold (a co-tenant —
+        // a second matcher on the device, a group with a repeated ordinal, the caller's own tensors — shrinks the pass instead of
+        // failing its hipMalloc; the result does not depend on how the batch is cut)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max<size_t>((free_b + W.gauss.cap + W.base.cap) / 2, (size_t)64 << 20));
+        else (void)hipGetLastError();
+    }
     const int nb_max = (int)std::max<size_t>(1, budget / std::max<size_t>(per, 1));
     int64_t rows = 0;
     for (int f0 = 0; f0 < n; f0 += nb_max) {

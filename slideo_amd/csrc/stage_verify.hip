@@ -13,7 +13,7 @@ VerifyParams make_vp(const slideo_config& c) {
     v.tol = c.vote_tolerance; v.min_similarity = c.min_similarity; v.ratio = c.ratio_test;
     v.thr = c.ransac_threshold; v.conf = c.ransac_confidence; v.min_rating = c.min_rating;
     v.min_rating_ratio = c.min_rating_ratio; v.max_iters = c.ransac_max_iters; v.refine_iters = c.refine_iters;
-    v.model = c.verify_model;
+    v.model = c.verify_model; v.verdict_rule = c.verdict_rule;
     v.sched_window = env_long("SLIDEO_RANSAC_WINDOW", 1) != 0;      // (read per unit: the tests switch it)
     return v;
 }

@@ -63,6 +63,7 @@ struct VerifyParams {
     int32_t max_iters, refine_iters;
     uint32_t rng_len;                       // entries of the pre-drawn cv::RNG stream (grown on demand by the host)
     int32_t model;                          // slideo_config.verify_model: 0 similarity (2x3), 1 homography (3x3)
+    int32_t verdict_rule;                   // slideo_config.verdict_rule: 0 best similarity wins (mo/lib.rs:370-389), 1 rating order, similarity only accepts
     int32_t sched_window;                   // ransac_kernel: redraw schedule from the LDS-window jump tables (1) / by the fixed point only (0: A/B, tests)
 };
 

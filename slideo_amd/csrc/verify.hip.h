@@ -1237,13 +1237,15 @@ __global__ void verdict_kernel(VerifyParams vp, int nframes, const uint32_t* __r
     slideo_verdict v;
     v.page_idx = -1; v.similarity = 0.f; v.inliers = 0; v.n_keypoints = (int32_t)(qofs[f + 1] - qofs[f]);
     if (v.n_keypoints == 0) { fc.ncand = 0; fc.nsurv = 0; }
-    // stable: first maximal similarity among survivors in rating order
+    // stable: first maximal similarity among survivors in rating order; verdict_rule 1 (opt-in departure, slideo_amd.h): the
+    // first survivor in rating order whose similarity is accepted
     float best = 0.f; int bi = -1;
     for (int s = 0; s < fc.nsurv; ++s) {
         const PageInfo pg = pages[fc.page[fc.surv[s]]];
         float sim = similarity_from_ssd(fc.ssd[s], pg.sw, pg.sh);
         fc.sim[s] = sim;
-        if (bi < 0 || sim > best) { best = sim; bi = s; }
+        if (vp.verdict_rule == 1) { if (bi < 0 && sim > vp.min_similarity) { best = sim; bi = s; } }
+        else if (bi < 0 || sim > best) { best = sim; bi = s; }
     }
     if (bi >= 0 && best > vp.min_similarity) {
         v.page_idx = fc.page[fc.surv[bi]]; v.similarity = best; v.inliers = fc.inliers[fc.surv[bi]];

@@ -298,18 +298,17 @@ public:
     template <class I>
     std::unique_ptr<VideoMatcher<I>> create_video_matcher(std::vector<I> images, ProgressReporter reporter) const {
         auto h = std::make_shared<detail::Handle>();
-        std::vector<int32_t> devs = devices_;
-        if (devs.empty()) for (int d = 0; d < std::max(slideo_device_count(), 1); ++d) devs.push_back(d);   // (no device at all: create reports it)
-        int32_t rc = slideo_group_create(&cfg_, (int32_t)devs.size(), devs.data(), &h->g);
+        // no explicit list: every gfx950 device of the node, enumerated by the library (n_devices 0; no device at all: create reports it)
+        int32_t rc = slideo_group_create(&cfg_, (int32_t)devices_.size(), devices_.empty() ? nullptr : devices_.data(), &h->g);
         if (rc != SLIDEO_OK) throw std::runtime_error(std::string("slideo_amd error ") + std::to_string(rc) + ": " + slideo_group_last_error(nullptr));
-        h->n_devices = (int)devs.size();
+        h->n_devices = (int)slideo_group_device_count(h->g);
         if (sift_on_) {                                                                             // the north-star's SIFT + L2 front end
             slideo_sift_config sc;
             slideo_sift_config_default(&sc);
             h->check(slideo_group_use_sift(h->g, &sc, sift_ratio_));
         }
         h->check(slideo_group_set_progress(h->g, detail::tramp, &reporter));                         // "Analyzing PDF pages..." protocol, mo/lib.rs:43-58
-        const size_t CH = 32 * devs.size();
+        const size_t CH = 32 * (size_t)h->n_devices;
         for (size_t i = 0; i < images.size(); i += CH) {
             std::vector<Image8> dec;
             for (size_t j = i; j < std::min(images.size(), i + CH); ++j) dec.push_back(loader_(images[j].get_path()));

@@ -116,3 +116,37 @@ def test_cfg2_full_size():
     assert c["frames_per_step_per_gpu"] == 256 and c["pages"] == 500 and c["train_descriptors_M"] > 400000 and c["query_descriptors_per_step"] > 200000
     assert c["checked"]["knn_vs_numpy_64_queries"] is True and c["checked"]["sift_frame0_bit_exact_vs_cpu_restatement"] is True
     assert c["sift_vote"] == "tolerance" and c["accuracy_vs_synthetic_truth"] >= 0.97 and j["roofline"]["frac"] > 0.15     # (the path's own vote: 256 of 256; Lowe's test — --sift-vote ratio — reaches 0.71)
+
+
+def test_cfg3_lecture_two_ranks_over_gloo():
+    """--workload cfg3 = BASELINE configs[3] as worded (1080p lecture, 1000-page deck, a FIXED 216 000-frame job sharded over the
+    GPUs, one all-gather of the verdict records per step, the page timeline on rank 0), here at a small size: 20 pages, 192 frames
+    in all, two ranks sharing the GPU over gloo, a step's 48 frames per rank as three units of 16 cycling through the resident
+    pool.  The gathered slice of every rank equals its own verdicts, and rank 0's timeline equals the truth's."""
+    env = dict(os.environ, SLIDEO_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg3", "--pages", "20",
+                        "--total-frames", "192", "--pool", "16", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    c = j["config"]
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and c["frames_per_step_per_gpu"] == 48 and c["units_per_step"] == 3
+    assert c["resident_pool_frames_per_gpu"] == 16 and c["collective"] == {"backend": "gloo", "all_gather_of_verdicts_checked": True}
+    lec = c["lecture"]
+    assert lec["sampled_frames_in_the_last_step"] == 96 and lec["timeline_entries"] >= 2
+    assert c["accuracy_vs_synthetic_truth"] >= 0.9 and lec["entries_equal_to_truth"] >= 0.8 * lec["truth_entries"]
+    assert j["value"] > 0 and j["roofline"]["over_step"]["frac"] > 0
+
+
+def test_nccl_with_fewer_gpus_than_ranks_fails_fast():
+    """Two nccl ranks on a one-GPU box: RCCL would hang in its first collective; bench.py says what is wrong and exits."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has a GPU per rank")
+    env = dict(os.environ)
+    env.pop("SLIDEO_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "needs one GPU per rank" in r.stderr, r.stderr[-2000:]

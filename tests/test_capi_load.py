@@ -21,13 +21,13 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.EXPORTS) == names
-    assert L.slideo_abi_version() == 5        # ABI 5: + the N-device group (slideo_group_*, slideo_device_count); struct layouts as in 4
+    assert L.slideo_abi_version() == 6        # ABI 6: + slideo_config.verdict_rule, slideo_device_list, n_devices 0 at group create; ocv.hdlt defaults to 1
 
 
 def test_config_struct_matches_oracle_layout(capi, oracle):
     import ctypes as C
     a, b = capi.default_config(), oracle.default_config()
-    assert C.sizeof(a) == C.sizeof(b) == 160        # ABI 4: + verify_model, matcher, lsh_*, ocv.hdlt
+    assert C.sizeof(a) == C.sizeof(b) == 168        # ABI 6: + verdict_rule (160 since ABI 4: verify_model, matcher, lsh_*, ocv.hdlt)
     assert bytes(a) == bytes(b)
 
 

@@ -31,7 +31,7 @@ def test_group_equals_single_matcher(capi, cfg0_data, members):
     g.set_progress(lambda d, t, msg: log.append((d, t, msg)))
     g.add_pages(list(pages[:3]))                   # two calls: shards of 3 pages, then of 1 (members with an empty share)
     assert log[0] == (0, 3, "Analyzing PDF pages...") and log[-1] == (3, 3, "PDF page analysis successful.")
-    assert sorted(d for d, _, msg in log[1:-1]) == [1, 2, 3]
+    assert [d for d, _, msg in log[1:-1]] == [1, 2, 3]      # serialised by the group: monotonic whichever member thread reports
     g.add_pages(list(pages[3:]))
     g.set_progress(None)
     g.finalize()
@@ -173,3 +173,18 @@ def test_group_random_shards(capi, synth, seed):
     sel = rng.permutation(len(seq))[: int(rng.integers(0, len(seq) + 1))].astype(np.int32)
     assert g.match_kept_frames(sel).tobytes() == m.match_kept_frames(sel).tobytes()
     m.close(); g.close()
+
+
+def test_default_group_takes_the_nodes_gfx950_devices_by_ordinal(capi):
+    """n_devices 0 at slideo_group_create = one member per gfx950 device, named by its OWN HIP ordinal (slideo_device_list) — not
+    0 .. count-1, which is wrong on a node whose lower ordinals are another architecture."""
+    devs = capi.device_list()
+    assert len(devs) == capi.device_count() >= 1 and devs == sorted(set(devs))
+    g = capi.Group(small_cfg(capi))
+    assert g.devices == devs and len(g.devices) == int(capi.lib().slideo_group_device_count(g._h))
+    for r, d in enumerate(devs):
+        assert g.member(r) is not None
+    g.close()
+    import ctypes as C
+    few = (C.c_int32 * 1)(-7)
+    assert capi.lib().slideo_device_list(few, 0) == len(devs) and few[0] == -7        # capacity respected

@@ -218,3 +218,27 @@ def test_sample_solver_forms_agree_end_to_end(capi, synth):
         c = HA.compare(res[h], res[0])
         assert c["verdict_page_agreement"] >= 0.95 and c["candidate_inlier_count_agreement"] >= 0.95, (h, c)
         assert c["max_similarity_difference"] <= 0.05, (h, c)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_verdict_rule_1_equals_oracle(capi, oracle, synth, model):
+    """slideo_config.verdict_rule 1 (opt-in departure from mo/lib.rs:370-389: the survivors keep their rating order and the
+    re-projection similarity only accepts): verdict_kernel == the restatement, both verify models, thresholds loosened so that
+    frames have several accepted survivors (template-sharing sibling pages)."""
+    pages = synth.pages(8, 800, 450)
+    frames, truth, _ = synth.frames(pages, 10, 640, 360)
+    kw = dict(nfeatures=500, min_rating=8.0, min_rating_ratio=0.05, verify_model=model, verdict_rule=1)
+    m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
+    v = m.match_frames(frames)
+    _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
+    several = 0
+    for i in range(len(frames)):
+        c = m.last_candidates(i)
+        ok = c[(c["survived"] == 1) & (c["similarity"] > 0.5)]
+        several += len(ok) > 1
+        if len(ok):
+            assert v["page_idx"][i] == ok[np.argmax(ok["inliers"])]["page_idx"]
+    assert several >= 1, "no frame exercised the rule"
+    m.close()
+    with pytest.raises(capi.SlideoError):
+        capi.Matcher(capi.default_config(verdict_rule=2))

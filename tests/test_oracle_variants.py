@@ -162,3 +162,34 @@ def test_variants_reach_the_pipeline_and_range_checks(oracle, cfg0_data):
         assert db.match_frames(frames, threads=4)["page_idx"].tolist() == truth.tolist()
     for bad in (dict(ocv_blur=4), dict(ocv_gray=2), dict(ocv_lm=-1), dict(ocv_warp=2)):
         assert oracle.lib().so_config_supported(C.byref(oracle.default_config(**bad))) == 0
+
+
+def test_verdict_rule_is_opt_in_and_ranks_by_rating(oracle, synth):
+    """slideo_config.verdict_rule (ABI 6): 0 = the reference (best re-projection similarity wins, mo/lib.rs:370-389) is the default;
+    1 keeps the survivors' rating order and lets the similarity only accept.  Checked on the restatement's own trace: whatever the
+    candidates are, rule 1's verdict is the accepted survivor with the most inliers (first in candidate order among equals) and
+    rule 0's the accepted survivor with the highest similarity."""
+    assert oracle.default_config().verdict_rule == 0
+    pages = synth.pages(6, 800, 450)
+    frames, truth, _ = synth.frames(pages, 6, 640, 360)
+    seen_difference_possible = False
+    for rule in (0, 1):
+        kw = dict(nfeatures=500, min_rating=8.0, min_rating_ratio=0.05, verdict_rule=rule)
+        db = oracle.PageDB(oracle.default_config(**kw))
+        db.add_pages(pages, threads=4)
+        assert db.finalize() == 0
+        for fr in frames:
+            v, c = db.match_frame_trace(fr)
+            s = c[c["survived"] == 1]
+            ok = s[s["similarity"] > 0.5]
+            if len(ok) == 0:
+                assert v["page_idx"] == -1
+                continue
+            seen_difference_possible |= len(ok) > 1
+            if rule == 0:
+                want = ok[np.argmax(ok["similarity"])]          # (first maximum = stable sort's first)
+            else:
+                want = ok[np.argmax(ok["inliers"])]             # (candidate order = page order among equal ratings: first maximum)
+            assert v["page_idx"] == want["page_idx"] and v["inliers"] == want["inliers"]
+    bad = oracle.default_config(verdict_rule=2)
+    assert oracle.lib().so_config_supported(C.byref(bad)) == 0

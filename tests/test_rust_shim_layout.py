@@ -29,7 +29,7 @@ def test_ffi_structs_follow_the_header(capi):
             else:
                 assert rt == "slideo_ocv_variants" and cty is capi.OcvVariants
     assert [n for n, _ in _struct_fields(src, "slideo_verdict")] == list(capi.VERDICT_DTYPE.names)
-    assert "160" in src and C.sizeof(capi.Config) == 160                      # assert_abi()'s size check matches
+    assert "168" in src and C.sizeof(capi.Config) == 168                      # assert_abi()'s size check matches
 
 
 def test_ffi_functions_exist_and_abi_constant_matches():
