@@ -1,8 +1,8 @@
 //! Host-side decode helpers: page PNGs and sampled video frames, through the OpenCV modules the application already
 //! links (imgcodecs, videoio).  No matching logic lives here.
 //!
-//! The sampling rule is the reference's, crates/matching-opencv/src/video_capture.rs:42-57: every frame is grabbed, a
-//! frame is retrieved when `frame_idx % floor(fps * interval) < 1`, its time is `frame_idx / fps`.
+//! The sampling RULE is the reference's (crates/matching-opencv/src/video_capture.rs:42-57) and lives in `SamplingRule`; the
+//! decoder behind it is a trait (`FrameSource`), with OpenCV's VideoCapture as the one implementation shipped.
 use opencv::{
     core::Mat,
     imgcodecs::{imread, IMREAD_COLOR},
@@ -50,11 +50,53 @@ pub fn mat_to_bgr(mat: &Mat) -> BgrImage {
     BgrImage { data, width: w, height: h }
 }
 
-/// VideoCaptureIter of the reference (video_capture.rs:10-57), yielding packed BGR frames.
-pub struct SampledVideo {
-    video: VideoCapture,
+// ---- sampling ------------------------------------------------------------------------------------------------------
+// Three separate pieces, so that the decoder is replaceable (a VCN / FFmpeg-direct source, a test source) without touching
+// the rule that decides WHICH frames the matcher sees — the one thing here that must equal the reference:
+//   FrameSource     what a decoder has to offer: position, rate, length, "skip one frame", "decode the frame just skipped to"
+//   SamplingRule    the reference's rule (crates/matching-opencv/src/video_capture.rs:42-57): the frame at position p is sampled
+//                   iff p mod floor(fps * interval) < 1, and its time is p / fps
+//   Sampler         the iterator: walks a source frame by frame and decodes only what the rule keeps
+//   OpenCvSource    the FrameSource over opencv::videoio::VideoCapture (what the reference's VideoCaptureIter wraps)
+
+/// A frame-accurate sequential decoder.
+pub trait FrameSource {
+    /// frames per second of the stream (video_capture.rs:22)
+    fn fps(&self) -> f64;
+    /// frames in the stream as the container reports them (video_capture.rs:31)
+    fn frame_count(&self) -> f64;
+    /// position of the NEXT frame, counted in frames (video_capture.rs:45)
+    fn position(&self) -> f64;
+    /// moves past the next frame without decoding it; false at the end of the stream (video_capture.rs:48)
+    fn advance(&mut self) -> bool;
+    /// decodes the frame `advance` has just moved past (video_capture.rs:53)
+    fn decode_current(&mut self) -> BgrImage;
+}
+
+/// Which positions are sampled, and what time they carry.
+#[derive(Clone, Copy)]
+pub struct SamplingRule {
+    /// floor(fps * interval): the period in frames (video_capture.rs:52)
+    period: f64,
     fps: f64,
-    interval: Duration,
+}
+
+impl SamplingRule {
+    pub fn new(fps: f64, interval: Duration) -> Self {
+        SamplingRule { period: (fps * interval.as_secs_f64()).floor(), fps }
+    }
+    /// video_capture.rs:52 (f64 remainder, so a fractional position reported by a container still compares as there)
+    pub fn keeps(&self, position: f64) -> bool {
+        position % self.period < 1.0
+    }
+    /// video_capture.rs:46
+    pub fn time_of(&self, position: f64) -> Duration {
+        Duration::from_secs_f64(position / self.fps)
+    }
+    /// video_capture.rs:35
+    pub fn total_time(&self, frame_count: f64) -> Duration {
+        Duration::from_secs_f64(frame_count / self.fps)
+    }
 }
 
 pub struct SampledFrame {
@@ -63,42 +105,120 @@ pub struct SampledFrame {
     pub frame_idx: usize,
 }
 
-impl SampledVideo {
-    pub fn open(path: &Path, interval: Duration) -> Self {
-        let video = VideoCapture::from_file(&path.to_string_lossy(), 0).unwrap();
-        let fps = video.get(CAP_PROP_FPS).unwrap();
-        SampledVideo { video, fps, interval }
-    }
+/// The sampled frames of a source, in order.
+pub struct Sampler<S: FrameSource> {
+    source: S,
+    rule: SamplingRule,
+}
 
+impl<S: FrameSource> Sampler<S> {
+    pub fn new(source: S, interval: Duration) -> Self {
+        let rule = SamplingRule::new(source.fps(), interval);
+        Sampler { source, rule }
+    }
     pub fn total_frames(&self) -> f64 {
-        self.video.get(CAP_PROP_FRAME_COUNT).unwrap()
+        self.source.frame_count()
     }
-
     pub fn total_time(&self) -> Duration {
-        Duration::from_secs_f64(self.video.get(CAP_PROP_FRAME_COUNT).unwrap() / self.fps)
+        self.rule.total_time(self.source.frame_count())
     }
 }
 
-impl Iterator for SampledVideo {
+impl<S: FrameSource> Iterator for Sampler<S> {
     type Item = SampledFrame;
 
     fn next(&mut self) -> Option<SampledFrame> {
-        let mut frame = Mat::default();
+        // every frame is moved past (the reference grabs every frame); only the kept ones are decoded
         loop {
-            let frame_idx = self.video.get(CAP_PROP_POS_FRAMES).unwrap();
-            let time_passed = Duration::from_secs_f64(frame_idx / self.fps);
-            if !self.video.grab().unwrap() {
+            let at = self.source.position();
+            if !self.source.advance() {
                 return None;
             }
-            if frame_idx % (self.fps * self.interval.as_secs_f64()).floor() < 1.0 {
-                self.video.retrieve(&mut frame, 0).unwrap();
-                return Some(SampledFrame {
-                    image: mat_to_bgr(&frame),
-                    time: time_passed,
-                    frame_idx: frame_idx as usize,
-                });
+            if self.rule.keeps(at) {
+                let image = self.source.decode_current();
+                return Some(SampledFrame { image, time: self.rule.time_of(at), frame_idx: at as usize });
             }
         }
+    }
+}
+
+/// FrameSource over OpenCV's VideoCapture (FFmpeg inside videoio) — the decoder the application already links.
+pub struct OpenCvSource {
+    video: VideoCapture,
+    scratch: Mat,
+}
+
+impl OpenCvSource {
+    /// video_capture.rs:17-21 (backend 0 = any)
+    pub fn open(path: &Path) -> Self {
+        OpenCvSource { video: VideoCapture::from_file(&path.to_string_lossy(), 0).unwrap(), scratch: Mat::default() }
+    }
+}
+
+impl FrameSource for OpenCvSource {
+    fn fps(&self) -> f64 {
+        self.video.get(CAP_PROP_FPS).unwrap()
+    }
+    fn frame_count(&self) -> f64 {
+        self.video.get(CAP_PROP_FRAME_COUNT).unwrap()
+    }
+    fn position(&self) -> f64 {
+        self.video.get(CAP_PROP_POS_FRAMES).unwrap()
+    }
+    fn advance(&mut self) -> bool {
+        self.video.grab().unwrap()
+    }
+    fn decode_current(&mut self) -> BgrImage {
+        self.video.retrieve(&mut self.scratch, 0).unwrap();
+        mat_to_bgr(&self.scratch)
+    }
+}
+
+/// The sampled frames of a video file, decoded by OpenCV.
+pub fn sampled_video(path: &Path, interval: Duration) -> Sampler<OpenCvSource> {
+    Sampler::new(OpenCvSource::open(path), interval)
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    /// 100 synthetic frames at 30 fps, 1 s interval: the rule keeps every 30th position and nothing else is decoded.
+    struct Counting {
+        at: f64,
+        n: f64,
+        decoded: Vec<usize>,
+    }
+    impl FrameSource for Counting {
+        fn fps(&self) -> f64 {
+            30.0
+        }
+        fn frame_count(&self) -> f64 {
+            self.n
+        }
+        fn position(&self) -> f64 {
+            self.at
+        }
+        fn advance(&mut self) -> bool {
+            if self.at >= self.n {
+                return false;
+            }
+            self.at += 1.0;
+            true
+        }
+        fn decode_current(&mut self) -> BgrImage {
+            self.decoded.push(self.at as usize - 1);
+            BgrImage { data: vec![0; 3], width: 1, height: 1 }
+        }
+    }
+
+    #[test]
+    fn samples_every_period_and_decodes_nothing_else() {
+        let s = Sampler::new(Counting { at: 0.0, n: 100.0, decoded: vec![] }, Duration::from_secs(1));
+        assert_eq!(s.total_time(), Duration::from_secs_f64(100.0 / 30.0));
+        let got: Vec<(usize, Duration)> = s.map(|f| (f.frame_idx, f.time)).collect();
+        assert_eq!(got.iter().map(|g| g.0).collect::<Vec<_>>(), vec![0, 30, 60, 90]);
+        assert_eq!(got[2].1, Duration::from_secs(2));
     }
 }
 

@@ -155,7 +155,7 @@ impl<'i, I: MatchableImage + Send + Sync + Copy + Eq + 'i> VideoMatcher<'i, I> f
         progress_reporter: ProgressReporter,
     ) -> Box<dyn VideoMatcherTask<I> + 'i> {
         let interval = Duration::from_secs(5); // mo/lib.rs:145
-        let vid = decode::SampledVideo::open(video_path, interval);
+        let vid = decode::sampled_video(video_path, interval);
         let total_time = vid.total_time();
         let frames_to_process = (total_time.as_secs_f64() / interval.as_secs_f64()) as u64; // mo/lib.rs:148
         progress_reporter.report(0, frames_to_process, ""); // mo/lib.rs:150
@@ -180,7 +180,7 @@ struct HipVideoMatcherTask<I> {
 impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVideoMatcherTask<I> {
     fn process(&self) -> Vec<Matching<I>> {
         let interval = Duration::from_secs(5); // mo/lib.rs:175
-        let vid = decode::SampledVideo::open(&self.video_path, interval);
+        let vid = decode::sampled_video(&self.video_path, interval);
         let total_time = vid.total_time();
         let total_frames = vid.total_frames();
         let frames_to_process = (total_time.as_secs_f64() / interval.as_secs_f64()) as u32; // mo/lib.rs:179
@@ -265,21 +265,17 @@ impl<I: MatchableImage + Send + Sync + Copy + Eq> VideoMatcherTask<I> for HipVid
             &format!("Finished!"),
         ); // mo/lib.rs:223-227
 
-        // mo/lib.rs:229-244
-        results.sort_by_key(|m| m.video_time);
-        let mut cleaned: Vec<Matching<I>> = Vec::new();
-        let mut last: Option<Matching<I>> = None;
-        for mapping in results {
-            if let Some(l) = &last {
-                if l.image == mapping.image {
-                    continue;
-                }
-            }
-            last = Some(mapping.clone());
-            cleaned.push(mapping);
-        }
-        cleaned
+        timeline(results)
     }
+}
+
+/// The task's result as the application stores it (crates/app/src/db.rs:162-191): ordered by time, and a page (or "no page")
+/// listed only where it CHANGES — the reference's sort + removal of consecutive duplicates, mo/lib.rs:229-244.  `sort_by_key`
+/// is stable, so the end-of-video sentinel and equal-time entries keep their push order, as there.
+fn timeline<I: Clone + Eq>(mut results: Vec<Matching<I>>) -> Vec<Matching<I>> {
+    results.sort_by_key(|m| m.video_time);
+    results.dedup_by(|next, kept| next.image == kept.image); // (Vec::dedup_by keeps the first of a run, drops the followers)
+    results
 }
 
 /// to_small_image's output size (mo/image_utils.rs:8-20) times 3 channels: what slideo_changed_mask_bgr8 writes to

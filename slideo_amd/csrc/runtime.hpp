@@ -68,6 +68,10 @@ struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_orb = nullptr, ev_up = nullptr;
+    // SLIDEO_CU_SPLIT (measurement switch, off by default): the search on a stream of its own whose CU mask holds N CUs, the other
+    // stages on the complement — spatial instead of per-CU sharing; ev_k0 / ev_k1 order the search stream behind / before the slot's
+    hipStream_t st_knn = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
     const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0; bool u_shared = false;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
@@ -153,6 +157,7 @@ struct slideo_matcher {
     struct Kept { bool valid = false; int n = 0, w = 0, h = 0, stride = 0; } kept;
     slideo::DevBuf d_kept;
     bool units_pending = false;   // the call being served has more units than the one submitted now
+    int cu_split = 0;       // SLIDEO_CU_SPLIT=N: the search on N CUs (two blocks per CU), ORB / verify on the other 256 - N (0 = off: every stream on every CU)
     int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one (SLIDEO_KNN_SHARE)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)

@@ -225,9 +225,9 @@ def test_verdict_rule_1_equals_oracle(capi, oracle, synth, model):
     """slideo_config.verdict_rule 1 (opt-in departure from mo/lib.rs:370-389: the survivors keep their rating order and the
     re-projection similarity only accepts): verdict_kernel == the restatement, both verify models, thresholds loosened so that
     frames have several accepted survivors (template-sharing sibling pages)."""
-    pages = synth.pages(8, 800, 450)
-    frames, truth, _ = synth.frames(pages, 10, 640, 360)
-    kw = dict(nfeatures=500, min_rating=8.0, min_rating_ratio=0.05, verify_model=model, verdict_rule=1)
+    pages = synth.pages(24, 800, 450)
+    frames, truth, _ = synth.frames(pages, 24, 640, 360)
+    kw = dict(nfeatures=500, min_rating=6.0, min_rating_ratio=0.02, min_similarity=0.05, verify_model=model, verdict_rule=1)
     m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
