@@ -33,6 +33,13 @@
 
 namespace slideo {
 
+// compile-time experiment hook (-DORB_PRIO=n, tools/ab_matrix.sh; not in the product build): the ORB stage's waves at instruction priority n
+// (the search's matrix sections run at 1 / 2, everything else at 0)
+#ifdef ORB_PRIO
+#define SLIDEO_ORB_PRIO() __builtin_amdgcn_s_setprio(ORB_PRIO)
+#else
+#define SLIDEO_ORB_PRIO()
+#endif
 
 // ---------------------------------------------------------------------------
 // [OCV A.1] gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
@@ -41,6 +48,7 @@ namespace slideo {
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride,
                                                    int stride, uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
                                                    int w, int h, int pitch, int aligned4, GrayCoef gc) {
+    SLIDEO_ORB_PRIO();
     const uint32_t half = 1u << (gc.shift - 1);
     auto gray_of = [&](uint32_t b, uint32_t g, uint32_t r) { return (b * gc.cb + g * gc.cg + r * gc.cr + half) >> gc.shift; };
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -83,6 +91,7 @@ constexpr int RESIZE_ROWS = 4;
 __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
                                                      LevelGeom src, LevelGeom dst,
                                                      const uint32_t* __restrict__ lin_tab, int nxq, uint32_t nxq_magic) {
+    SLIDEO_ORB_PRIO();
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const int yg = nxq_magic ? (int)__umulhi(t, nxq_magic) : (int)t;     // t / nxq (exact, see build_pyr_geom)
     const int y0 = yg * RESIZE_ROWS;
@@ -249,6 +258,7 @@ __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTil
 __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist, const int4* __restrict__ tile_tab) {
+    SLIDEO_ORB_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t raw[FAST_RH][FAST_RW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
     // a wave's private share of the queue: its score rows (sy % 4 == wave), back to back
@@ -325,6 +335,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     // max(sat(max(top, bottom) - v), sat(v - min(top, bottom))), "> t" = a saturating subtract of t that leaves a non-zero half.
     // Survivors (5 - 10 % of the positions of a text frame) are queued; every wave appends to its own quarter of the queue
     // with a wave-uniform count: no atomics, no waits.
+#if defined(FAST_ABL) && FAST_ABL == 0      /* timing experiments only (results invalid): 0 = load + commit only, 1 = + A1, 2 = + A2, 3 = + B */
+    T = Tn; continue;
+#endif
     const fast_us2 tt = {(unsigned short)t, (unsigned short)t};
     uint32_t myn = 0;
     const int qbase = (wave == 0 ? 0 : wave == 1 ? FAST_QR0 : wave == 2 ? FAST_QR0 + FAST_QR1 : FAST_QR0 + FAST_QR1 + FAST_QR2) * FAST_SW;
@@ -371,6 +384,10 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
             push1((fl & 8u) != 0u, p0 + 3);
         }
     }
+#if defined(FAST_ABL) && FAST_ABL == 1
+    if (myn == 0xFFFFFFFFu) sc[0][0] = 1;
+    T = Tn; continue;
+#endif
     // A2 — the horizontal pair and the two diagonals, one survivor per lane, by the wave that queued it (score rows are dealt
     // to the waves modulo 4, so the shares are balanced): its quarter of the queue is compacted in place — a chunk's 64 reads
     // precede its writes, and the write position never passes the read position.  No barrier between A1 and A2.
@@ -393,6 +410,10 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         if (pass) myq[mym + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)i;
         mym += (uint32_t)__popcll(mk);
     }
+#if defined(FAST_ABL) && FAST_ABL == 2
+    if (mym == 0xFFFFFFFFu) sc[0][0] = 1;
+    T = Tn; continue;
+#endif
     if (lane == 0) qcnt[wave] = mym;
     __syncthreads();
     // the queue = the four quarters back to back
@@ -453,6 +474,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         }
         sc[sy][sx] = (uint8_t)score;      // every other position keeps score 0
     }
+#if defined(FAST_ABL) && FAST_ABL == 3
+    T = Tn; continue;
+#endif
     __syncthreads();
     // Phase C — NMS (strictly greater than all 8 neighbours) + emit, again only over the queue: a survivor is a
     // queued corner inside the output tile and the keep-region.
@@ -627,6 +651,7 @@ __global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t*
                                                        uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab,
                                                        const uint8_t* __restrict__ strip_mask) {
     static_assert(BLUR_RH % 8 == 0, "four row pairs per unrolled round");
+    SLIDEO_ORB_PRIO();
     const int f = blockIdx.y;
     // strip_mask (frame path): one byte per (frame, tile, wave) strip, set by blur_mark_kernel iff some keypoint's BRIEF
     // samples can fall into the strip; the other strips of the blurred pyramid are never read, so they are not computed.
@@ -1102,6 +1127,7 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
                                                                const uint64_t* __restrict__ items, uint32_t qtot,
                                                                const uint2* __restrict__ ic_tab, int ic_shift, int ic_entries,
                                                                slideo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc, int atan_fma) {
+    SLIDEO_ORB_PRIO();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the keypoint, its level and frame stay on the SALU)
     const uint32_t gi = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;

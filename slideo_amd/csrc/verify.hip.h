@@ -1034,6 +1034,9 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
                                                            const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
                                                            int fw, int fh, FrameCands* __restrict__ fcs,
                                                            const PairDesc* __restrict__ pair_list, const uint32_t* __restrict__ pair_count) {
+#ifdef VERIFY_PRIO       /* compile-time experiment hook (tools/ab_matrix.sh): the re-projection's waves at instruction priority VERIFY_PRIO */
+    __builtin_amdgcn_s_setprio(VERIFY_PRIO);
+#endif
     __shared__ unsigned long long red[4];
     __shared__ uint32_t vt[VT_PX + 8];                                // + slack: a padding tap (weight 0) may read past the last pixel
     __shared__ int2 s_col[2][32 * VT_CG];                             // (adelta, bdelta) per source column of a tile, double buffered
