@@ -260,7 +260,8 @@ def main():
     ap.add_argument("--verdict-rule", type=int, default=0, choices=[0, 1],
                     help="0 = the reference's verdict (best re-projection similarity wins, mo/lib.rs:370-389); 1 = the opt-in departure "
                          "slideo_config.verdict_rule: rating order, similarity only accepts")
-    ap.add_argument("--pool", type=int, default=0, help="distinct resident frames per GPU a step's units cycle through (default: the workload's batch)")
+    ap.add_argument("--pool", type=int, default=0, help="distinct resident frames per GPU the stream of frames cycles through (default: the workload's batch)")
+    ap.add_argument("--unit", type=int, default=0, help="frames per submitted unit (default: the pool, i.e. one unit per step in weak mode)")
     ap.add_argument("--matcher", default="exact", choices=["exact", "lsh"],
                     help="descriptor index: exact brute force (default; north_star) or the LSH candidate rule of the reference's FLANN index "
                          "(slideo_config.matcher 1: 6 tables, 12-bit keys, multi-probe 1 — recall < 1, and on these descriptors SLOWER than the exact "
@@ -334,8 +335,14 @@ def main():
     # A step's B frames go through the library in UNITS of at most `pool` frames, drawn from a pool of `pool` distinct frames per
     # GPU that is resident in HBM before the timed region (weak mode and the small strong-mode jobs: pool = B, one unit per step,
     # as before; configs[3]: 10 800 frames per step at N = 1 cycle through 256 resident ones — every unit runs the whole hot path).
+    # The frames of the timed region form ONE stream, frame g = resident frame g mod `pool` (pool distinct frames per GPU, in HBM
+    # before the timed region), cut into UNITS of U frames that go through the library's slots; a step is the B frames [sB, (s+1)B) of
+    # that stream, whatever units they travel in, and its verdict records are gathered once all of them are in.  Weak mode by default:
+    # pool = B = U, one unit per step.  configs[3]: 10 800 frames per step at N = 1 cycle through 256 resident ones, 43 units per step.
+    # --unit U: another unit size over the same stream (measured r05: 176 / 192 / 200 / 256-frame units give the same rate within 0.5 %).
     pool = min(B, args.pool or wl["batch"])
-    units = [(o, min(pool, B - o)) for o in range(0, B, pool)]              # (offset in the step, frames): each reads pool[0:n]
+    U = max(1, min(args.unit or wl.get("unit", 0) or pool, pool))
+    units_per_step = B / U
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(64, ncpu // max(world, 1)))
 
@@ -350,7 +357,7 @@ def main():
         frames, truth, _ = synth.frames_persp(pages, pool, fw, fh, persp=persp, first=rank * pool, threads=gen_threads)
     else:
         frames, truth, _ = synth.frames(pages, pool, fw, fh, first=rank * pool, threads=gen_threads)
-    truth_step = np.concatenate([truth[:n] for _, n in units])             # the truth of a step's B frames
+    truth_of = lambda g0, n: truth[(g0 + np.arange(n)) % pool]            # the truth of stream frames g0 .. g0 + n - 1
     t_gen = time.time() - t0
 
     cfg = _capi.default_config(nfeatures=wl["nfeatures"], verify_model=verify_model, ocv_hdlt=args.hdlt, matcher=1 if args.matcher == "lsh" else 0,
@@ -368,56 +375,71 @@ def main():
     M = m.descriptor_count
     Mu = m.unique_descriptor_count             # what the k-NN stage searches (equal rows collapsed, results unchanged)
 
-    d_frames = torch.from_numpy(frames).cuda()          # inputs resident in HBM before timing
+    # (a unit's frames must be contiguous in memory: when U does not divide the pool, the pool's first U frames are repeated behind it)
+    d_frames = torch.from_numpy(frames if pool % U == 0 else np.concatenate([frames, frames[:U]])).cuda()     # inputs resident in HBM before timing
+    frame_bytes = fh * fw * 3
     stream = torch.cuda.current_stream().cuda_stream
     verdict_words = 4
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    # The library leaves a unit's verdict records in the step's slice of one of NBUF device tensors (rotating), the step's
-    # all-gather reads it on torch's stream, and an event recorded behind the collective guards the tensor's NEXT use, NBUF steps
-    # later — by then it has long completed, so no step ends in a host wait for the collective.
-    NBUF = max(2, args.inflight + 1)
-    d_verdicts = [torch.zeros((B, verdict_words), dtype=torch.int32, device=coll_dev) for _ in range(NBUF)]
-    buf_free = [None] * NBUF
+    # The library leaves a unit's verdict records in a RING of R records in device memory, at the unit's place in the stream (R a
+    # multiple of U and of B: neither a unit nor a step wraps); the step's all-gather reads its B records on torch's stream, and an
+    # event recorded behind the collective guards the region's NEXT use, R / B steps later — by then it has long completed, so no
+    # step ends in a host wait for the collective.
+    lcm = U * B // int(np.gcd(U, B))
+    R = lcm * max(1, -(-((args.inflight + 3) * max(U, B)) // lcm))
+    ring = torch.zeros((R, verdict_words), dtype=torch.int32, device=coll_dev)
+    ring_host = np.zeros(R, _capi.VERDICT_DTYPE)
+    step_done_ev = [None] * (R // B)
     d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device=coll_dev) if use_dist else None
     on_dev = use_dist and coll_dev == "cuda"          # the library leaves the records on the device
-    step_no = [0]
-    v_step = [np.zeros(B, _capi.VERDICT_DTYPE), np.zeros(B, _capi.VERDICT_DTYPE)]    # host copy of the step being collected / the last complete one
+    st = {"next_step": 0, "last": None}
 
     def collect_unit(item, local):
-        """Collects one unit into its step's slice; behind a step's LAST unit — unless `local` — the step's one collective (RCCL
-        over xGMI) runs on the step's verdict records."""
-        ticket, ofs, n, last = item
+        """Collects one unit into its place in the ring; behind the LAST unit of a step — unless `local` — the step's one collective
+        (RCCL over xGMI) runs on the step's verdict records."""
+        ticket, g0, n = item
         gather = use_dist and not local
-        b = step_no[0] % NBUF
-        if gather and ofs == 0 and buf_free[b] is not None:
-            buf_free[b].synchronize()                # an event NBUF steps old: returns at once
-        v = m.collect(ticket, dev_out=(d_verdicts[b].data_ptr() + ofs * 4 * verdict_words) if (gather and on_dev) else 0)
-        v_step[0][ofs:ofs + n] = v
+        r0 = g0 % R
+        if gather and on_dev:
+            for sl in range(r0 // B, (r0 + n - 1) // B + 1):
+                if step_done_ev[sl] is not None:
+                    step_done_ev[sl].synchronize()   # an event R / B steps old: returns at once
+        v = m.collect(ticket, dev_out=(ring.data_ptr() + r0 * 4 * verdict_words) if (gather and on_dev) else 0)
+        ring_host[r0:r0 + n] = v
         if gather and not on_dev:                    # gloo stand-in: host tensors
-            d_verdicts[b][ofs:ofs + n].copy_(torch.from_numpy(v.view(np.int32).reshape(n, verdict_words)), non_blocking=False)
-        if last:
-            v_step[0], v_step[1] = v_step[1], v_step[0]
+            ring[r0:r0 + n].copy_(torch.from_numpy(v.view(np.int32).reshape(n, verdict_words)), non_blocking=False)
+        while (st["next_step"] + 1) * B <= g0 + n:   # units are collected in order: every frame before g0 + n is in
+            a = (st["next_step"] * B) % R
+            st["last"] = (st["next_step"], ring_host[a:a + B].copy())
             if gather:
-                dist.all_gather_into_tensor(d_all, d_verdicts[b])      # the one collective of the path
-                step_no[0] += 1
+                dist.all_gather_into_tensor(d_all, ring[a:a + B])      # the one collective of the path
                 if on_dev:
-                    buf_free[b] = torch.cuda.Event()
-                    buf_free[b].record()
+                    step_done_ev[a // B] = torch.cuda.Event()
+                    step_done_ev[a // B].record()
+            st["next_step"] += 1
 
-    def run_steps(k, depth=None, local=False, units_of_step=None):
-        """k steps; a step = B frames through the whole hot path, in units of <= `pool` frames.  `depth` units are kept in flight
-        (submit i+depth-1 before collecting i) so that the ORB / verify stages of some units share the GPU with the kNN of others.
-        Returns the verdicts of the last step."""
+    def run_stream(total, depth=None, local=False, first_unit_only=False):
+        """`total` frames of the stream, in units of U frames (the last one may be shorter).  `depth` units are kept in flight (submit
+        i+depth-1 before collecting i) so that the ORB / verify stages of some units share the GPU with the kNN of others.
+        Returns (verdicts of the last complete step or None, that step's first frame's place in the stream)."""
         pending = []
         depth = depth or (1 if args.no_overlap else max(1, args.inflight))
-        for _ in range(k):
-            for ui, (ofs, n) in enumerate(units_of_step or units):
-                if len(pending) == depth:
-                    collect_unit(pending.pop(0), local)
-                pending.append((m.submit_dev(d_frames.data_ptr(), n, fw, fh, stream=stream), ofs, n, ui == len(units_of_step or units) - 1))
+        st["next_step"], st["last"] = 0, None
+        g = 0
+        while g < total:
+            n = min(U, total - g)
+            g_read = 0 if first_unit_only else g        # (profiling the kernels alone: the same first unit every time)
+            if len(pending) == depth:
+                collect_unit(pending.pop(0), local)
+            pending.append((m.submit_dev(d_frames.data_ptr() + (g_read % pool) * frame_bytes, n, fw, fh, stream=stream), g, n))
+            g += n
         while pending:
             collect_unit(pending.pop(0), local)
-        return v_step[1].copy()
+        return (st["last"][1], st["last"][0] * B) if st["last"] else (None, 0)
+
+    def run_steps(k):
+        """k steps = the k * B first frames of the stream"""
+        return run_stream(k * B)
 
     def barrier():
         if use_dist:
@@ -425,11 +447,11 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup:
-        v = run_steps(args.warmup)
+        run_steps(args.warmup)
     m.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    v = run_steps(args.steps)
+    v, g_last = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof, knn_pairs = m.read_profile()
@@ -439,7 +461,7 @@ def main():
     prof_alone = None
     if rank == 0 and not args.no_overlap and args.inflight > 1:
         m.set_profiling(True)
-        run_steps(3, depth=1, local=True, units_of_step=units[:1])      # (three launches of a step's first unit)
+        run_stream(3 * U, depth=1, local=True, first_unit_only=True)      # (three launches of the stream's first unit)
         torch.cuda.synchronize()
         prof_alone, pairs_alone = m.read_profile()
         m.set_profiling(False)
@@ -452,6 +474,7 @@ def main():
         mine = d_all[rank * B:(rank + 1) * B].cpu().numpy().view(_capi.VERDICT_DTYPE).reshape(-1)
         gathered_ok = bool(np.array_equal(mine, v))
 
+    truth_step = truth_of(g_last, B)                # the truth of the last step's frames
     acc = float((v["page_idx"] == truth_step).mean())
     total_frames = args.steps * B * world
     fps = total_frames / dt
@@ -478,8 +501,8 @@ def main():
             tt = D.timeline(tv, times, fidx, 5.0 * S, int(5.0 * S * 30.0))
             lecture = {"sampled_frames_in_the_last_step": S, "timeline_entries": len(tl), "truth_entries": len(tt),
                        "entries_equal_to_truth": len(set(tl) & set(tt)),
-                       "job": "%d frames = %d steps x %d GPU(s) x %d frames; a step's frames per GPU run as %d unit(s) of <= %d frames"
-                              % (total_frames, args.steps, world, B, len(units), pool)}
+                       "job": "%d frames = %d steps x %d GPU(s) x %d frames; a GPU's frames run as units of %d frames (%.2f units per step)"
+                              % (total_frames, args.steps, world, B, U, units_per_step)}
 
     out = {
         "metric": "frames/sec matched (1080p vs 500-page ORB set)" if args.workload == "headline" else "frames/sec matched",
@@ -492,8 +515,8 @@ def main():
                    "verify_model": verify_model, "ocv_hdlt": args.hdlt, "verify": ("8-DOF homography: findHomography(RANSAC) + warpPerspective" if verify_model == 1 else "the reference's 4-DOF similarity: estimateAffinePartial2D + warpAffine"),
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
-                   "inputs": "%d distinct synthetic frames per GPU, resident in HBM before the timed region; a step submits its %d frames per GPU as %d unit(s) of <= %d frames read from that pool, every step again (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % (pool, B, len(units), pool),
-                   "units_per_step": len(units), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
+                   "inputs": "%d distinct synthetic frames per GPU, resident in HBM before the timed region; the timed region's %d frames per GPU are ONE stream (frame g = resident frame g mod %d) submitted in units of %d frames, a step = %d consecutive frames of it; every unit runs the whole hot path (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % (pool, args.steps * B, pool, U, B),
+                   "frames_per_unit": U, "units_per_step": round(units_per_step, 3), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
                    "collective": ({"backend": backend, "all_gather_of_verdicts_checked": gathered_ok} if use_dist else None),
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
                    "accuracy_vs_synthetic_truth": round(acc, 4),
@@ -569,10 +592,10 @@ def main():
                 # launches of overlapped batches run one block per CU — stage_knn.hip share_pad — beside the other stages: a
                 # launch then lasts longer than a step while the job as a whole gets faster; this is the figure that follows the job.)
                 step_s = out["ms_per_step"] * 1e-3
-                per_step = pairs_per_launch * len(units)                      # (one launch per unit)
+                per_step = pairs_per_launch * units_per_step                  # (one launch per unit)
                 out["roofline"]["over_step"] = {"achieved": round(2.0 * 256 * per_step / step_s / 1e12, 2),
                                                 "frac": round(2.0 * 256 * per_step / step_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                "note": "executed flops of a step's launches / ms_per_step (%d launch(es) per step and GPU)" % len(units)}
+                                                "note": "executed flops of a step's launches / ms_per_step (%.2f launches per step and GPU)" % units_per_step}
             if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
                 a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
                 unit_work = (2.0 * 256 if args.knn != "valu" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
@@ -598,7 +621,7 @@ def main():
             # the stage's interval inside the timed region is an occupancy figure too (it runs UNDER the other batches' search
             # kernels, one search block per CU, and lasts about a step): achieved / frac are the stage with the chip to itself
             # when that was measured, the timed region's interval is beside it
-            rate = lambda ms: round(orb_bytes * B / (ms * 1e-3) / 1e9, 2)
+            rate = lambda ms: round(orb_bytes * U / (ms * 1e-3) / 1e9, 2)      # (a stage interval = one unit of U frames)
             alone_ms = prof_alone["orb"][0] / max(prof_alone["orb"][1], 1) if prof_alone and prof_alone["orb"][1] > 0 else 0.0
             ref_ms = alone_ms if alone_ms > 0 else orb_ms
             out["orb_stage"] = {"bound": "hbm", "algorithmic_bytes_per_frame": int(orb_bytes),
@@ -629,7 +652,8 @@ def main():
             cv = db.match_frames(frames[:ns], threads=min(cores, ns))
             t_cpu += time.time() - t0
             reps += 1
-        agree = float((cv["page_idx"] == v["page_idx"][:ns]).mean())
+        # (resident frame j is the step's frame i with (g_last + i) mod pool == j)
+        agree = float((cv["page_idx"] == v["page_idx"][(np.arange(ns) - g_last) % pool]).mean())
         n1 = 4
         t0 = time.time()
         db.match_frames(frames[:n1], threads=1)                      # also on one core
