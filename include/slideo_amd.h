@@ -48,6 +48,7 @@
  *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
  *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)
  *   SLIDEO_ORB_CHAIN=0            ORB stages of consecutive units free-running instead of taking turns
+ *   SLIDEO_RESIZE_GENERIC=1       every pyramid level through resize_kernel (any shrink factor) instead of resize_quad_kernel [per unit]
  *   SLIDEO_HOST_UNIT n            frames per unit of a host-memory batch (32; 0 = the device-path rule)
  *   SLIDEO_WS_GB x                workspace budget of all slots together (48)
  *   SLIDEO_SIFT_WS_MB n           SIFT pyramid budget per pass (98304 on a device with >= 192 GB, else 24576)  [per call]

@@ -34,6 +34,9 @@ struct LevelGeom {
     int32_t xtab_ofs, ytab_ofs;  // resize coefficient tables (entries), valid for level >= 1
     float scale;               // (float)pow(scale_factor, level)
     int32_t xctab_ofs;         // packed x weights (256-c1) | c1 << 16, same indexing as xtab_ofs
+    // resize_quad_kernel's tables (per group of 4 output columns; valid when rq_ok): the first source byte of the group's 8-byte
+    // window, and one v_perm_b32 selector per output (bytes (p, 0, p + 1, 0), p = the output's left tap inside the window)
+    int32_t rq_ok, xs_ofs, xsel_ofs;
 };
 
 struct PyrGeom {
@@ -285,7 +288,30 @@ inline void build_pyr_geom(int w, int h, const slideo_config& c, PyrGeom& g, std
                 uint32_t c1 = lin_tab[i] >> 16;
                 lin_tab.push_back((256u - c1) | (c1 << 16));
             }
+            while (lin_tab.size() % 4) lin_tab.push_back(0);
             L.ytab_ofs = (int32_t)lin_tab.size(); linear_exact_table(g.lv[l - 1].h, L.h, lin_tab, c.ocv.resize);
+            while (lin_tab.size() % 4) lin_tab.push_back(lin_tab.back());     // (resize_quad_kernel reads 4 rows' entries as one uint4)
+            // quad tables: every group of 4 outputs must tap inside 8 consecutive source bytes (shrink factors < ~2.3; a right tap
+            // at byte 8 is allowed when its weight is 0 — the selector then picks a constant byte)
+            const int nxq = (L.w + 3) / 4, sp = g.lv[l - 1].pitch;
+            std::vector<uint32_t> xs(nxq), sel((size_t)nxq * 4);
+            bool ok = sp >= 8;
+            for (int q = 0; q < nxq && ok; ++q) {
+                const uint32_t* xe = &lin_tab[(size_t)L.xtab_ofs + 4 * q];
+                const int x_s = std::min((int)(xe[0] & 0xffff), sp - 8);
+                xs[q] = (uint32_t)x_s;
+                for (int i = 0; i < 4; ++i) {
+                    const int p = (int)(xe[i] & 0xffff) - x_s;
+                    if (p < 0 || p > 7 || (p == 7 && (xe[i] >> 16) != 0)) ok = false;
+                    sel[(size_t)4 * q + i] = (uint32_t)p * 0x00010001u + 0x0c010c00u;
+                }
+            }
+            L.rq_ok = ok ? 1 : 0;
+            if (ok) {
+                L.xs_ofs = (int32_t)lin_tab.size(); lin_tab.insert(lin_tab.end(), xs.begin(), xs.end());
+                while (lin_tab.size() % 4) lin_tab.push_back(0);
+                L.xsel_ofs = (int32_t)lin_tab.size(); lin_tab.insert(lin_tab.end(), sel.begin(), sel.end());
+            }
         }
     }
     g.frame_bytes = ofs; g.fast_tiles = ftile; g.blur_tiles = btile; g.cand_per_frame = cand;

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ f
                                                    int w, int h, int pitch, int aligned4, GrayCoef gc) {
     SLIDEO_ORB_PRIO();
     const uint32_t half = 1u << (gc.shift - 1);
-    auto gray_of = [&](uint32_t b, uint32_t g, uint32_t r) { return (b * gc.cb + g * gc.cg + r * gc.cr + half) >> gc.shift; };
+    // (coefficients < 2^15, pixels < 2^8: 24-bit multiplies — full rate, where v_mul_lo_u32 takes four issue slots)
+    auto gray_of = [&](uint32_t b, uint32_t g, uint32_t r) { return (__umul24(b, gc.cb) + __umul24(g, gc.cg) + __umul24(r, gc.cr) + half) >> gc.shift; };
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -159,6 +160,58 @@ __global__ __launch_bounds__(256) void resize_kernel(uint8_t* __restrict__ pyr, 
     }
 }
 
+// The same arithmetic for levels whose every group of 4 outputs taps inside 8 consecutive source bytes (LevelGeom::rq_ok: all
+// shrink factors below ~2.3, i.e. every ORB pyramid).  resize_kernel spends about 60 VALU instructions per 4 outputs, a third
+// of them on what does not depend on the row: the window start, the tap selectors, the choice between its two tap paths, 64-bit
+// addresses.  Here those come from per-group tables (geom.h: xs, selectors; the packed weights are resize_kernel's), the four
+// rows' y entries are one 16-byte load, addresses are 32-bit offsets from a scalar base, and nothing branches but the store of
+// a row past the level's last one: per output row 8 v_perm, 8 v_dot2, 8 multiplies, 4 adds, 3 perms to pack.
+// grid (ceil(nxq * ceil(dh / 4) / 256), 1, B), the flat thread numbering of resize_kernel.
+__global__ __launch_bounds__(256) void resize_quad_kernel(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
+                                                          LevelGeom src, LevelGeom dst,
+                                                          const uint32_t* __restrict__ lin_tab, int nxq, uint32_t nxq_magic) {
+    SLIDEO_ORB_PRIO();
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t yg = nxq_magic ? __umulhi(t, nxq_magic) : t;
+    const uint32_t y0 = yg * 4u;
+    if ((int)y0 >= dst.h) return;
+    const uint32_t q = t - __umul24(yg, (uint32_t)nxq);
+    const uint8_t* __restrict__ sbase = pyr + (int64_t)blockIdx.z * pyr_frame_bytes + src.ofs;      // (scalar)
+    uint8_t* __restrict__ dbase = pyr + (int64_t)blockIdx.z * pyr_frame_bytes + dst.ofs;
+    const uint4 sel4 = reinterpret_cast<const uint4*>(lin_tab + dst.xsel_ofs)[q];
+    const uint4 cp4 = reinterpret_cast<const uint4*>(lin_tab + dst.xctab_ofs)[q];
+    const uint32_t xs = lin_tab[dst.xs_ofs + q];
+    const uint4 ye4 = *reinterpret_cast<const uint4*>(lin_tab + dst.ytab_ofs + y0);     // (padded with copies of the last row's entry)
+    const uint32_t ye[4] = {ye4.x, ye4.y, ye4.z, ye4.w};
+    const uint32_t sel[4] = {sel4.x, sel4.y, sel4.z, sel4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+    uint2 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t yo = ye[r] & 0xffffu;
+        const uint32_t o0 = __umul24(yo, (uint32_t)src.pitch) + xs;
+        const uint32_t o1 = __umul24(min(yo + 1u, (uint32_t)(src.h - 1)), (uint32_t)src.pitch) + xs;
+        __builtin_memcpy(&a[r], sbase + o0, 8);
+        __builtin_memcpy(&b[r], sbase + o1, 8);
+    }
+    const uint32_t dofs = __umul24(y0, (uint32_t)dst.pitch) + 4u * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t cy1 = ye[r] >> 16, cy0 = 256u - cy1;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ta = __builtin_amdgcn_perm(a[r].y, a[r].x, sel[i]);
+            const uint32_t tb = __builtin_amdgcn_perm(b[r].y, b[r].x, sel[i]);
+            v[i] = __umul24(cy0, dot2_u16(ta, cp[i])) + (__umul24(cy1, dot2_u16(tb, cp[i])) + (1u << 15));
+        }
+        const uint32_t outv = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
+                                                    __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
+        // (a whole dword also for the level's last, partial group: the pitch is a multiple of 16, the bytes past column w - 1 are
+        // padding no kernel taps — and they come out the same every time: the tables repeat their last entry)
+        if ((int)(y0 + r) < dst.h) *reinterpret_cast<uint32_t*>(dbase + (dofs + (uint32_t)r * (uint32_t)dst.pitch)) = outv;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // [OCV A.3] FAST-9/16 score + NMS + runByImageBorder, all levels in one launch.
 // grid (fast_tiles, B), block 256.  Candidate entry = score << 24 | y << 12 | x.
@@ -251,7 +304,7 @@ __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTil
         const int i = min((int)threadIdx.x + 256 * k, FAST_NDW * FAST_RH - 1);
         const int ry = i / FAST_NDW, rd = i - ry * FAST_NDW;
         const int gy = min(max(T.y0 - 4 + ry, 0), L.h - 1);
-        __builtin_memcpy(&v[k], img + (int64_t)gy * L.pitch + min(xs + 4 * rd, maxo), 4);
+        __builtin_memcpy(&v[k], img + (__umul24((uint32_t)gy, (uint32_t)L.pitch) + (uint32_t)min(xs + 4 * rd, maxo)), 4);   // (32-bit offset from the level's scalar base)
     }
 }
 

@@ -67,6 +67,9 @@ static void launch_blur(slideo_matcher* m, Slot& S, const PyrGeom& g, int n, con
     check_launch("blur kernel");
 }
 
+// SLIDEO_RESIZE_GENERIC=1: every pyramid level through resize_kernel (the form for any shrink factor) instead of resize_quad_kernel
+static bool resize_generic_forced() { return env_long("SLIDEO_RESIZE_GENERIC", 0) != 0; }      // (read per unit: the tests switch it)
+
 // `with_blur`: also materialise the WHOLE blurred pyramid (only the pyramid tap wants it)
 // the f32 blur of ocv.blur 0 / 1 cannot be evaluated per BRIEF sample in integer arithmetic: those variants always
 // materialise the blurred pyramid (blur_f32_kernel) and describe from it (describe_blurred_kernel)
@@ -109,9 +112,13 @@ void orb_stage1(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, in
         const int nxq = cdiv(g.lv[l].w, 4);
         const uint32_t magic = nxq > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)nxq - 1) / (uint64_t)nxq) : 0u;
         dim3 grid(cdiv(nxq * cdiv(g.lv[l].h, RESIZE_ROWS), 256), 1, n);
-        resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
-                                            nxq, magic);
-        check_launch("resize_kernel");
+        if (g.lv[l].rq_ok && !resize_generic_forced())
+            resize_quad_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
+                                                     nxq, magic);
+        else
+            resize_kernel<<<grid, 256, 0, st>>>(S.d_pyr.as<uint8_t>(), g.frame_bytes, g.lv[l - 1], g.lv[l], ge.lin_tab.as<uint32_t>(),
+                                                nxq, magic);
+        check_launch("resize kernel");
     }
     if (g.fast_tiles > 0) {
         fast_kernel<<<dim3(cdiv(g.fast_tiles, FAST_TPB), n), 256, 0, st>>>(g, S.d_pyr.as<uint8_t>(), S.d_cand.as<uint32_t>(), cand_count, hist, ge.fast_tiles.as<int4>());

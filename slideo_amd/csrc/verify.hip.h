@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
     __shared__ unsigned long long red[4];
     __shared__ uint32_t vt[VT_PX + 8];                                // + slack: a padding tap (weight 0) may read past the last pixel
     __shared__ int2 s_col[2][32 * VT_CG];                             // (adelta, bdelta) per source column of a tile, double buffered
+    __shared__ int2 s_rowt[8 * VT_RI];                                // (X0, Y0) fixed-point row terms per source row of the strip
     __shared__ VtTile s_tile[RP_MAX_TILES];
     const uint32_t npairs = *pair_count;
     constexpr int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, round_delta = AB_SCALE / 2;
@@ -1077,16 +1078,17 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
         const int ny_wave = __builtin_amdgcn_readfirstlane(max(ny, __shfl_xor(ny, 32)));      // (a wave holds two rows of small pixels)
         // this thread's source rows (hw, hw + 8, ...) and their fixed-point row terms; rows past the span repeat its last one
         // (their pixels are fetched and dropped)
-        [[maybe_unused]] int X0r[VT_RI], Y0r[VT_RI];
+        // (kept in LDS, not in registers: ten registers that would be live through the taps of every tile, where the prefetched
+        // pixels, the weights and a row of taps already fill the 128 the launch bounds allow — a spill there puts a scratch
+        // reload, and with it a wait for the whole prefetch, into the tap rows)
+        __syncthreads();                                              // previous pair's readers of s_tile / s_col / s_rowt / vt are done
         if constexpr (!PERSP) {
-#pragma unroll
-            for (int ri = 0; ri < VT_RI; ++ri) {
-                const int y = sy_lo + min(hw + 8 * ri, sph - 1);
-                X0r[ri] = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
-                Y0r[ri] = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+            if ((int)threadIdx.x < 8 * VT_RI) {
+                const int y = sy_lo + min((int)threadIdx.x, sph - 1);
+                s_rowt[threadIdx.x] = make_int2(sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta,
+                                                sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta);
             }
         }
-        __syncthreads();                                              // previous pair's readers of s_tile / s_col / vt are done
         if ((int)threadIdx.x < tiles_x) {
             const int tx = threadIdx.x;
             VtTile T{};
@@ -1140,8 +1142,9 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
                     int X, Y;
                     if constexpr (PERSP) persp_src(M, bw0, T.sx_lo + col, sy_lo + min(hw + 8 * ri, sph - 1), X, Y);
                     else {
-                        X = (int)((uint32_t)X0r[ri] + (uint32_t)ab.x) >> AB_BITS;
-                        Y = (int)((uint32_t)Y0r[ri] + (uint32_t)ab.y) >> AB_BITS;
+                        const int2 rt = s_rowt[hw + 8 * ri];              // (rows past the span hold its last row's terms)
+                        X = (int)((uint32_t)rt.x + (uint32_t)ab.x) >> AB_BITS;
+                        Y = (int)((uint32_t)rt.y + (uint32_t)ab.y) >> AB_BITS;
                         // (saturate_cast<short> of imgwarp.cpp cannot change the in-frame test for frames < 32768 px)
                     }
                     int o = (int)__mul24(Y, stride) + 3 * X;
@@ -1194,25 +1197,41 @@ __global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const Ar
             __syncthreads();                                          // B: vt is complete, tile tx + 1's column table has been read
             if constexpr (!PERSP) col_table(tx + 2, tx & 1);
             if (live) {
-                const uint32_t* row = vt + (x_first + ry0 * spw);
-                float s0 = 0, s1 = 0, s2 = 0;
+                // One instance per tap count of the class (max_xtaps; a pixel with fewer taps has weight 0 on the rest, as before):
+                // a row's reads are issued together and its arithmetic is one straight run.  Testing `k >= xtaps_max` after every
+                // tap cost a scalar branch and a wait for that tap's own LDS read per tap (and scalar-register spills).
+                auto area_rows = [&](auto xb_tag) {
+                    constexpr int XB = decltype(xb_tag)::value;
+                    const uint32_t* row = vt + (x_first + ry0 * spw);
+                    float s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-                for (int j = 0; j < YB; ++j) {
-                    if (j >= ny_wave) break;                            // (uniform)
-                    uint32_t px[XBM];
+                    for (int j = 0; j < YB; ++j) {
+                        if (j >= ny_wave) break;                            // (uniform)
+                        uint32_t px[XB];
 #pragma unroll
-                    for (int k = 0; k < XBM; ++k) px[k] = row[k];
-                    float b0 = 0, b1 = 0, b2 = 0;
+                        for (int k = 0; k < XB; ++k) px[k] = row[k];
+                        // (weights and pixels are >= +0, so every product is: 0 + x = x bit for bit, and the first tap / the first row
+                        // start the sums without the addition)
+                        float b0 = (float)(px[0] & 255u) * al[0], b1 = (float)((px[0] >> 8) & 255u) * al[0], b2 = (float)((px[0] >> 16) & 255u) * al[0];
 #pragma unroll
-                    for (int k = 0; k < XBM; ++k) {
-                        if (k >= xtaps_max) break;                      // (uniform: the class has no output with more taps)
-                        b0 = b0 + (float)(px[k] & 255u) * al[k]; b1 = b1 + (float)((px[k] >> 8) & 255u) * al[k]; b2 = b2 + (float)((px[k] >> 16) & 255u) * al[k];
+                        for (int k = 1; k < XB; ++k) {
+                            if (PERSP && k >= xtaps_max) break;             // (PERSP: one instance, the uniform test per tap — see below)
+                            b0 = b0 + (float)(px[k] & 255u) * al[k]; b1 = b1 + (float)((px[k] >> 8) & 255u) * al[k]; b2 = b2 + (float)((px[k] >> 16) & 255u) * al[k];
+                        }
+                        if (j == 0) { s0 = be[0] * b0; s1 = be[0] * b1; s2 = be[0] * b2; }
+                        else { s0 += be[j] * b0; s1 += be[j] * b1; s2 += be[j] * b2; }
+                        row += j + 1 < ny ? spw : 0;
                     }
-                    s0 += be[j] * b0; s1 += be[j] * b1; s2 += be[j] * b2;      // (0 + x = x exactly: the first row needs no case of its own)
-                    row += j + 1 < ny ? spw : 0;
-                }
-                const int d0 = (int)sat_u8_f(s0) - (int)(refpx & 255u), d1 = (int)sat_u8_f(s1) - (int)((refpx >> 8) & 255u), d2 = (int)sat_u8_f(s2) - (int)((refpx >> 16) & 255u);
-                acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+                    const int d0 = (int)sat_u8_f(s0) - (int)(refpx & 255u), d1 = (int)sat_u8_f(s1) - (int)((refpx >> 8) & 255u), d2 = (int)sat_u8_f(s2) - (int)((refpx >> 16) & 255u);
+                    acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+                };
+                // (the projective kernel keeps the one generic instance: its eighteen registers of matrix push the specialised rows
+                // into scratch)
+                if (PERSP) area_rows(std::integral_constant<int, XBM>{});
+                else if (xtaps_max <= 4) area_rows(std::integral_constant<int, 4>{});
+                else if (xtaps_max == 5) area_rows(std::integral_constant<int, 5>{});
+                else if (xtaps_max == 6) area_rows(std::integral_constant<int, 6>{});
+                else area_rows(std::integral_constant<int, XBM>{});
             }
         }
 #pragma unroll

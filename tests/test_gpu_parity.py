@@ -157,6 +157,26 @@ def test_pyramid_and_blur_bit_exact(capi, oracle, m500, cfg0_data, which):
             assert np.array_equal(g, o), "level %d blurred %d: %d px differ" % (level, blurred, (g != o).sum())
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
+def test_pyramid_through_both_resize_kernels(capi, oracle, m500, mdef, synth, monkeypatch, generic):
+    """resize_quad_kernel (per-group tables; every ORB pyramid) and resize_kernel (any shrink factor; SLIDEO_RESIZE_GENERIC=1)
+    against the restatement: odd widths (partial last group), a width below one group, 1080p."""
+    monkeypatch.setenv("SLIDEO_RESIZE_GENERIC", generic)
+    rng = np.random.default_rng(7)
+    oc = small_cfg(oracle)
+    for (h, w) in ((203, 317), (131, 135), (360, 641)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for level in range(1, 8):
+            g = m500.pyramid_level(img, level, 0)
+            o = oracle.pyramid_level(img, oc, level, 0)
+            assert g.shape == o.shape and np.array_equal(g, o), "%dx%d level %d: %d px differ" % (w, h, level, (g != o).sum())
+    pages = synth.pages(1)
+    frames, _, _ = synth.frames(pages, 1, first=3)
+    od = oracle.default_config()
+    for level in (1, 4, 7):
+        assert np.array_equal(mdef.pyramid_level(frames[0], level, 0), oracle.pyramid_level(frames[0], od, level, 0))
+
+
 def _cmp_orb(capi, oracle, matcher, ocfg, img):
     gk, gd = matcher.orb(img)
     ok, od = oracle.orb(img, ocfg)
