@@ -259,7 +259,7 @@ __device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsi
 constexpr int FAST_TPB = FAST_TPB_V;
 constexpr int FAST_STAGE_CAP = 128;                                    // survivors staged per block before one list append (a tile keeps ~10; LDS: 8 blocks per CU)
 constexpr int FAST_NDW = FAST_RW / 4;                                  // dwords per raw row
-constexpr int FAST_NLD = (FAST_NDW * FAST_RH + 255) / 256;             // raw dwords per thread and tile
+constexpr int FAST_NLD = (FAST_RH + 6) / 7;                            // raw dwords per loading thread and tile (fast_issue_loads)
 
 struct FastTile { int l, x0, y0; };
 
@@ -294,21 +294,48 @@ __device__ __forceinline__ FastTile fast_tile_geo(const PyrGeom& g, int tile_id)
 // raw tile: rows y0-4 .. y0+TH+3, columns from x0 - 1 - FAST_XO: UNALIGNED dword loads (x0 >= edge_threshold >= 5, so the first
 // byte is inside the row), the byte offset clamped to the row's pitch — a clamped dword holds shifted pixels, all of them right
 // of the level's last column but 3, which no needed position taps (those lie edge_threshold inside).  Rows clamped to the level.
+// Who loads what: thread t < FAST_LT = 7 * FAST_NDW owns dword column t % FAST_NDW of raw rows t / FAST_NDW + 7 k, k = 0 .. FAST_NLD - 1
+// (rows past FAST_RH - 1 repeat the last one and are dropped; the last few threads of the block idle here).  The k-th dword then
+// sits 7 k rows below the first — one register (`rel0`, the first dword's offset inside the tile; it changes with the level's pitch
+// only) and a scalar stride instead of an offset per dword — and lands in LDS at dword t + FAST_LT k.  A tile whose raw
+// rectangle lies inside the level's rows and pitch — every tile but those of a level's last tile column — costs ONE addition
+// per load; the others clamp as described above.
+constexpr int FAST_LT = 7 * FAST_NDW;
+static_assert(FAST_LT <= 256 && 7 * FAST_NLD >= FAST_RH, "fast_kernel's loader covers the raw tile");
+
 __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTile& T, const uint8_t* __restrict__ frame_pyr,
-                                                 uint32_t (&v)[FAST_NLD]) {
+                                                 uint32_t (&v)[FAST_NLD], uint32_t& rel0, int& rel_level) {
     const LevelGeom& L = g.lv[T.l];
     const uint8_t* img = frame_pyr + L.ofs;
     const int xs = T.x0 - 1 - FAST_XO, maxo = L.pitch - 4;
+    int tid = min((int)threadIdx.x, FAST_LT - 1);
+    if (T.l != rel_level) {                                                  // (wave-uniform)
+        asm volatile("" : "+v"(tid));            // (opaque: the row / column split is redone here, not kept in registers for the whole kernel)
+        const int rg = tid / FAST_NDW, c = tid - rg * FAST_NDW;
+        rel0 = __umul24((uint32_t)rg, (uint32_t)L.pitch) + 4u * (uint32_t)c;
+        rel_level = T.l;
+    }
+    if (T.y0 >= 4 && T.y0 - 4 + 7 * FAST_NLD <= L.h && xs + FAST_RW <= L.pitch) {      // (wave-uniform; rows up to 7 FAST_NLD - 1 are read)
+        const uint32_t base = __umul24((uint32_t)(T.y0 - 4), (uint32_t)L.pitch) + (uint32_t)xs, step = 7u * (uint32_t)L.pitch;
+#pragma unroll
+        for (int k = 0; k < FAST_NLD; ++k) __builtin_memcpy(&v[k], img + (rel0 + (base + step * (uint32_t)k)), 4);
+        return;
+    }
+    asm volatile("" : "+v"(tid));
+    const int rg = tid / FAST_NDW, c = tid - rg * FAST_NDW;
 #pragma unroll
     for (int k = 0; k < FAST_NLD; ++k) {
-        const int i = min((int)threadIdx.x + 256 * k, FAST_NDW * FAST_RH - 1);
-        const int ry = i / FAST_NDW, rd = i - ry * FAST_NDW;
-        const int gy = min(max(T.y0 - 4 + ry, 0), L.h - 1);
-        __builtin_memcpy(&v[k], img + (__umul24((uint32_t)gy, (uint32_t)L.pitch) + (uint32_t)min(xs + 4 * rd, maxo)), 4);   // (32-bit offset from the level's scalar base)
+        const int gy = min(max(T.y0 - 4 + min(rg + 7 * k, FAST_RH - 1), 0), L.h - 1);
+        __builtin_memcpy(&v[k], img + (__umul24((uint32_t)gy, (uint32_t)L.pitch) + (uint32_t)min(xs + 4 * c, maxo)), 4);   // (32-bit offset from the level's scalar base)
     }
 }
 
-__global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+#ifdef FAST_WAVES_EU      /* compile-time experiment hook: a register cap (6 waves per SIMD = 80 registers spills the tile offsets) */
+#define FAST_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FAST_WAVES_EU)))
+#else
+#define FAST_KERNEL_ATTR
+#endif
+__global__ FAST_KERNEL_ATTR __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ hist, const int4* __restrict__ tile_tab) {
     SLIDEO_ORB_PRIO();
@@ -317,6 +344,7 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     // a wave's private share of the queue: its score rows (sy % 4 == wave), back to back
     constexpr int FAST_QR0 = (FAST_SH + 3) / 4, FAST_QR1 = (FAST_SH + 2) / 4, FAST_QR2 = (FAST_SH + 1) / 4;
     __shared__ uint16_t queue[FAST_SH * FAST_SW];
+    __shared__ uint16_t gqueue[(FAST_QR0 + FAST_QR0 + FAST_QR0 + FAST_QR0) * 32];    // groups of 4 positions that failed the cheap reject (row * 32 + group), a quarter per wave
     __shared__ uint32_t qcnt[4];
     // survivors of the block's tiles are staged in LDS and appended to the level's candidate list with ONE returning
     // global atomic per flush (a flush per tile kept every tile waiting for its own round trip); same for the histogram
@@ -327,8 +355,9 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row loops and queue bases are wave-uniform)
     const int first = blockIdx.x * FAST_TPB;
     FastTile T = fast_tile_geo(tile_tab, first);
-    uint32_t pre[FAST_NLD];
-    fast_issue_loads(g, T, frame_pyr, pre);
+    uint32_t pre[FAST_NLD], rel0 = 0;
+    int rel_level = -1;
+    fast_issue_loads(g, T, frame_pyr, pre, rel0, rel_level);
     shist[threadIdx.x] = 0;
     if (threadIdx.x == 0) { nstage = 0; stage_end = 0xFFFFFFFFu; }
     int stage_level = T.l;
@@ -355,39 +384,29 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         if (T.l != stage_level || nstage > (uint32_t)FAST_STAGE_CAP / 2) flush(stage_level);
         stage_level = T.l;
     }
+    if ((int)threadIdx.x < FAST_LT) {
 #pragma unroll
-    for (int k = 0; k < FAST_NLD; ++k) {
-        const int i = (int)threadIdx.x + 256 * k;
-        if (i < FAST_NDW * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = pre[k];
+        for (int k = 0; k < FAST_NLD; ++k) {
+            const int i = (int)threadIdx.x + FAST_LT * k;
+            if (i < FAST_NDW * FAST_RH) reinterpret_cast<uint32_t*>(&raw[0][0])[i] = pre[k];
+        }
     }
     for (int i = threadIdx.x; i < FAST_SW * FAST_SH / 16; i += 256) reinterpret_cast<uint4*>(&sc[0][0])[i] = make_uint4(0, 0, 0, 0);
     // next tile's pixels (always issued — past the end the last tile is re-read and dropped — so that `pre` stays a
     // plain register array)
     const FastTile Tn = fast_tile_geo(tile_tab, min(first + it + 1, g.fast_tiles - 1));
-    fast_issue_loads(g, Tn, frame_pyr, pre);
+    fast_issue_loads(g, Tn, frame_pyr, pre, rel0, rel_level);
     const int l = T.l;
     const LevelGeom& L = g.lv[l];
     const int x0 = T.x0, y0 = T.y0;
     constexpr int xoff = FAST_XO - 3;
     __syncthreads();
-    // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...,
-    // lane covers sx = lane and lane + 64 (no divisions, constant LDS offsets).  Every arc of 9 contains one pixel of
-    // each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out; the four
-    // pairs tested (vertical first — a flat row segment leaves the whole wave there —, horizontal, then the diagonals)
-    // leave only corner-like pixels, which are queued for the full test.
-    // Positions past the keep-region's 1-px halo are not needed (score 0); needed ones are >= 3 px inside the level.
-    // A lane tests positions sx = lane and lane + 64 together, as the two halves of packed-u16 registers:
-    // |a - v| = sat(a - v) | sat(v - a), "either pixel of a pair differs" = max of the two, "every pair" = min over the
-    // pairs, "> t" = a saturating subtract of t that leaves a non-zero half.  No short-circuit operators: a stage's
-    // LDS reads are issued together.
-    // A1 — the vertical pair on every position, FOUR positions per lane: lanes 0..31 take positions 4j .. 4j + 3 of score row
-    // sy, lanes 32..63 those of row sy + 4; centre, top (-3 rows) and bottom (+3 rows) pixels are one aligned ds_read_b32 each.
-    // First a sufficient wave-level reject: the sum of a lane's four |top - centre| (v_sad_u8), and of its four
-    // |bottom - centre|, both <= t means every one of them is — a flat stretch leaves the whole wave after 3 + 3 instructions.
-    // Otherwise the exact test on the even and the odd bytes as packed u16: max(|top - v|, |bottom - v|) =
-    // max(sat(max(top, bottom) - v), sat(v - min(top, bottom))), "> t" = a saturating subtract of t that leaves a non-zero half.
-    // Survivors (5 - 10 % of the positions of a text frame) are queued; every wave appends to its own quarter of the queue
-    // with a wave-uniform count: no atomics, no waits.
+    // Phase A — quick reject over every score position (x0-1+sx, y0-1+sy); wave w takes score rows w, w+4, ...  Every arc of 9
+    // contains one pixel of each antipodal pair, so a pair whose two pixels are both within t of the centre rules the pixel out;
+    // the four pairs tested (A1: a cheap sufficient form of the vertical one, on everything; A2: all four exactly, on what is
+    // left) leave only corner-like pixels, which are queued for the full test.  Positions past the keep-region's 1-px halo are
+    // not needed (score 0); needed ones are >= 3 px inside the level.  Every wave appends to its own quarters of the two queues
+    // with wave-uniform counts: no atomics, no waits.
 #if defined(FAST_ABL) && FAST_ABL == 0      /* timing experiments only (results invalid): 0 = load + commit only, 1 = + A1, 2 = + A2, 3 = + B */
     T = Tn; continue;
 #endif
@@ -401,68 +420,80 @@ __global__ __launch_bounds__(256) void fast_kernel(PyrGeom g, const uint8_t* __r
         if (cond) myq[myn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)val;
         myn += (uint32_t)__popcll(mk);
     };
+    // A1 — only the sufficient reject, FOUR positions per lane (lanes 0..31: positions 4j .. 4j + 3 of score row sy, lanes 32..63:
+    // of row sy + 4): centre, top (-3 rows) and bottom (+3 rows) pixels are one aligned ds_read_b32 each, and
+    // max(sum |top - centre|, sum |bottom - centre|) <= t (two v_sad_u8) means no position of the group passes the vertical pair.
+    // A group that fails it is queued AS A GROUP (one wave-uniform append per row pair instead of the exact vertical test on the
+    // whole wave and four appends: on a text frame a quarter of the waves hold a flagged lane, a tenth of the lanes are flagged).
+    uint32_t myg = 0;
+    uint16_t* const mygq = gqueue + (wave == 0 ? 0 : wave == 1 ? FAST_QR0 : wave == 2 ? FAST_QR0 + FAST_QR1 : FAST_QR0 + FAST_QR1 + FAST_QR2) * 32;
+    const uint32_t* const rawdw = reinterpret_cast<const uint32_t*>(&raw[0][0]) + (FAST_XO >> 2);
     {
-        const int half = lane >> 5, j4 = (lane & 31) * 4;
-        // positions of this lane inside the keep-region's halo: x0 - 1 + j4 + k <= L.rx1
-        const int nin = min(max(L.rx1 - (x0 - 1) - j4 + 1, 0), 4);
-        const uint32_t vmask = nin >= 4 ? 0xFu : ((1u << nin) - 1u);
-        const uint32_t* const raw32 = reinterpret_cast<const uint32_t*>(&raw[0][0]) + ((j4 + FAST_XO) >> 2);
-        auto ev = [](uint32_t x) { return __builtin_bit_cast(fast_us2, __builtin_amdgcn_perm(0u, x, 0x0c020c00u)); };   // bytes (b0, 0, b2, 0)
-        auto od = [](uint32_t x) { return __builtin_bit_cast(fast_us2, __builtin_amdgcn_perm(0u, x, 0x0c030c01u)); };   // bytes (b1, 0, b3, 0)
+        const int half = lane >> 5, j = lane & 31;
+        const bool colok = L.rx1 - (x0 - 1) - 4 * j + 1 > 0;              // the group's first position is inside the keep-region's halo
         for (int sy = wave; sy < FAST_SH; sy += 8) {
             if (y0 - 1 + sy > L.ry1) break;
             const int syl = min(sy + 4 * half, FAST_SH - 1);                // (a clamped second row repeats work, never queues)
             const bool rowok = sy + 4 * half < FAST_SH && y0 - 1 + syl <= L.ry1;
-            const uint32_t* const c32 = raw32 + (syl + 3) * FAST_NDW;
+            const uint32_t* const c32 = rawdw + (syl + 3) * FAST_NDW + j;
             const uint32_t vc = c32[0], vt = c32[-3 * FAST_NDW], vb = c32[3 * FAST_NDW];
             const uint32_t sad = max(__builtin_amdgcn_sad_u8(vt, vc, 0u), __builtin_amdgcn_sad_u8(vb, vc, 0u));
-            if (__builtin_amdgcn_ballot_w64(rowok && sad > (uint32_t)t) == 0ull) continue;
-            uint32_t fl = 0;
-            {
-                const fast_us2 ce = ev(vc), te = ev(vt), be = ev(vb), co = od(vc), to = od(vt), bo = od(vb);
-                const fast_us2 de = __builtin_elementwise_max(__builtin_elementwise_sub_sat(__builtin_elementwise_max(te, be), ce),
-                                                              __builtin_elementwise_sub_sat(ce, __builtin_elementwise_min(te, be)));
-                const fast_us2 dd = __builtin_elementwise_max(__builtin_elementwise_sub_sat(__builtin_elementwise_max(to, bo), co),
-                                                              __builtin_elementwise_sub_sat(co, __builtin_elementwise_min(to, bo)));
-                const uint32_t re = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(de, tt));
-                const uint32_t ro = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(dd, tt));
-                fl = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
-                fl = rowok ? (fl & vmask) : 0u;
-            }
-            if (__builtin_amdgcn_ballot_w64(fl != 0u) == 0ull) continue;
-            const uint32_t p0 = (uint32_t)(syl * FAST_SW + j4);
-            push1((fl & 1u) != 0u, p0);
-            push1((fl & 2u) != 0u, p0 + 1);
-            push1((fl & 4u) != 0u, p0 + 2);
-            push1((fl & 8u) != 0u, p0 + 3);
+            const bool flag = rowok && colok && sad > (uint32_t)t;
+            const uint64_t mk = __builtin_amdgcn_ballot_w64(flag);
+            if (mk == 0ull) continue;
+            if (flag) mygq[myg + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(syl * 32 + j);
+            myg += (uint32_t)__popcll(mk);
         }
     }
-#if defined(FAST_ABL) && FAST_ABL == 1
-    if (myn == 0xFFFFFFFFu) sc[0][0] = 1;
-    T = Tn; continue;
-#endif
-    // A2 — the horizontal pair and the two diagonals, one survivor per lane, by the wave that queued it (score rows are dealt
-    // to the waves modulo 4, so the shares are balanced): its quarter of the queue is compacted in place — a chunk's 64 reads
-    // precede its writes, and the write position never passes the read position.  No barrier between A1 and A2.
-    uint32_t mym = 0;
-    for (uint32_t k0 = 0; k0 < myn; k0 += 64) {
+    // A2 — all four antipodal pairs on the queued groups, a group per lane, by the wave that queued it, four positions at once as
+    // packed u16 (even and odd bytes): with lo = sat(v - t), hi = v + t a pair differs iff min(a, b) < lo or max(a, b) > hi, i.e.
+    // max(sat(lo - min), sat(max - hi)) != 0; a position stays iff that holds for every pair (the minimum over the pairs).  The
+    // pixels of a pair for the four positions are bytes of the aligned dwords left of, at and right of the group in rows 0, +-2,
+    // +-3: eleven ds_read_b32, one v_perm_b32 per (pixel, parity).  Survivors are appended one by one to the wave's quarter of
+    // the position queue.  No barrier between A1 and A2 (a wave reads what it wrote itself).
+    for (uint32_t k0 = 0; k0 < myg; k0 += 64) {
         const uint32_t kq = k0 + lane;
-        bool pass = false;
-        uint32_t i = 0;
-        if (kq < myn) {
-            i = myq[kq];
-            const uint8_t* c = &raw[(i >> 7) + 3][(i & 127u) + 3 + xoff];
-            const int v = c[0];
-            const int p0 = c[3], p1 = c[-3], p2 = c[2 * FAST_RW + 2], p3 = c[-2 * FAST_RW - 2], p4 = c[-2 * FAST_RW + 2], p5 = c[2 * FAST_RW - 2];
-            // (ints, not bools: no short-circuit, the six LDS reads above are issued together)
-            const int d0 = fast_differs(p0, v, t), d1 = fast_differs(p1, v, t), d2 = fast_differs(p2, v, t), d3 = fast_differs(p3, v, t),
-                      d4 = fast_differs(p4, v, t), d5 = fast_differs(p5, v, t);
-            pass = ((d0 | d1) & (d2 | d3) & (d4 | d5)) != 0;
+        const bool act = kq < myg;
+        const uint32_t e = mygq[min(kq, myg - 1u)];
+        const int syl = (int)(e >> 5), j = (int)(e & 31u);
+        const uint32_t* const c32 = rawdw + (syl + 3) * FAST_NDW + j;
+        const uint32_t c = c32[0], pv = c32[-1], nx = c32[1], vt = c32[-3 * FAST_NDW], vb = c32[3 * FAST_NDW];
+        const uint32_t pc = c32[2 * FAST_NDW], pp = c32[2 * FAST_NDW - 1], pn = c32[2 * FAST_NDW + 1];
+        const uint32_t mc = c32[-2 * FAST_NDW], mp = c32[-2 * FAST_NDW - 1], mn = c32[-2 * FAST_NDW + 1];
+        auto pk = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(fast_us2, __builtin_amdgcn_perm(hi, lo, sel)); };
+        auto zero_or = [&](fast_us2 v, fast_us2 a, fast_us2 b, fast_us2 lo, fast_us2 hi) {      // != 0 in a half iff a or b is outside [lo, hi] there
+            return __builtin_elementwise_max(__builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(a, b)),
+                                             __builtin_elementwise_sub_sat(__builtin_elementwise_max(a, b), hi));
+        };
+        uint32_t keep[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                                  // positions 0, 2 (even bytes) / 1, 3 (odd bytes) of the group
+            // byte of position k (k = par, par + 2) in a (hi : lo) dword pair at index k + d: selector bytes (k0 + d, 0, k0 + 2 + d, 0)
+            const uint32_t s0 = par ? 0x0c030c01u : 0x0c020c00u;            // d = 0:  the position itself (within `c`, `vt`, `vb`)
+            const uint32_t s1 = par ? 0x0c040c02u : 0x0c030c01u;            // d = 1
+            const uint32_t s2 = par ? 0x0c050c03u : 0x0c040c02u;            // d = 2
+            const uint32_t s3 = par ? 0x0c060c04u : 0x0c050c03u;            // d = 3
+            const fast_us2 v = pk(0u, c, s0);
+            const fast_us2 lo = __builtin_elementwise_sub_sat(v, tt), hi = v + tt;
+            fast_us2 d = zero_or(v, pk(0u, vt, s0), pk(0u, vb, s0), lo, hi);                                   // (0, -3) / (0, +3)
+            d = __builtin_elementwise_min(d, zero_or(v, pk(nx, c, s3), pk(c, pv, s1), lo, hi));                // (+3, 0) / (-3, 0): bytes k + 3 of (nx : c), k + 1 of (c : pv)
+            d = __builtin_elementwise_min(d, zero_or(v, pk(pn, pc, s2), pk(mc, mp, s2), lo, hi));              // (+2, +2) / (-2, -2)
+            d = __builtin_elementwise_min(d, zero_or(v, pk(mn, mc, s2), pk(pc, pp, s2), lo, hi));              // (+2, -2) / (-2, +2)
+            keep[par] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, (fast_us2){1, 1}));          // 0 / 1 per half
         }
-        const uint64_t mk = __builtin_amdgcn_ballot_w64(pass);
-        if (pass) myq[mym + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)i;
-        mym += (uint32_t)__popcll(mk);
+        // fl bit k = position k stays: keep[0] = (k0 | k2 << 16), keep[1] = (k1 | k3 << 16)
+        const uint32_t m = keep[0] | (keep[1] << 1);
+        uint32_t fl = (m | (m >> 14)) & 0xFu;
+        const int nin = min(max(L.rx1 - (x0 - 1) - 4 * j + 1, 0), 4);       // positions of the group inside the keep-region's halo
+        fl = act ? (fl & (nin >= 4 ? 0xFu : ((1u << nin) - 1u))) : 0u;
+        if (__builtin_amdgcn_ballot_w64(fl != 0u) == 0ull) continue;
+        const uint32_t p0 = (uint32_t)(syl * FAST_SW + 4 * j);
+        push1((fl & 1u) != 0u, p0);
+        push1((fl & 2u) != 0u, p0 + 1);
+        push1((fl & 4u) != 0u, p0 + 2);
+        push1((fl & 8u) != 0u, p0 + 3);
     }
+    const uint32_t mym = myn;
 #if defined(FAST_ABL) && FAST_ABL == 2
     if (mym == 0xFFFFFFFFu) sc[0][0] = 1;
     T = Tn; continue;
