@@ -190,8 +190,18 @@ __global__ __launch_bounds__(256) void resize_quad_kernel(uint8_t* __restrict__ 
         const uint32_t yo = ye[r] & 0xffffu;
         const uint32_t o0 = __umul24(yo, (uint32_t)src.pitch) + xs;
         const uint32_t o1 = __umul24(min(yo + 1u, (uint32_t)(src.h - 1)), (uint32_t)src.pitch) + xs;
-        __builtin_memcpy(&a[r], sbase + o0, 8);
-        __builtin_memcpy(&b[r], sbase + o1, 8);
+        // Three ALIGNED dwords per source row and a funnel shift, not one unaligned 8-byte load: the texture path splits every
+        // unaligned dwordx2 of a lane, and it — not HBM, not the VALU — was what bound the kernel (level 1 of 256 1080p frames:
+        // 337 -> 232 us).  The twelve bytes may end 4 bytes past the row's pitch (the next row, the next level, or the slack
+        // after the last frame's pyramid: orb_stage1 reserves it); the 8 bytes from xs on that are used lie inside the pitch.
+        {
+            const uint32_t sh = (xs & 3u) * 8u;
+            uint32_t w0[3], w1[3];
+            __builtin_memcpy(w0, sbase + (o0 & ~3u), 12);
+            __builtin_memcpy(w1, sbase + (o1 & ~3u), 12);
+            a[r] = make_uint2(__builtin_amdgcn_alignbit(w0[1], w0[0], sh), __builtin_amdgcn_alignbit(w0[2], w0[1], sh));
+            b[r] = make_uint2(__builtin_amdgcn_alignbit(w1[1], w1[0], sh), __builtin_amdgcn_alignbit(w1[2], w1[1], sh));
+        }
     }
     const uint32_t dofs = __umul24(y0, (uint32_t)dst.pitch) + 4u * q;
 #pragma unroll
@@ -1236,13 +1246,13 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
         uint32_t accU = 0, accS = 0;
         constexpr int ICB = 8;                                       // loads in flight per lane
         for (int e0 = lane; e0 < ic_entries; e0 += 64 * ICB) {
-            uint32_t d[ICB]; uint2 wgt[ICB]; int rows[ICB];
+            uint32_t d[ICB]; uint2 wgt[ICB];
 #pragma unroll
             for (int u = 0; u < ICB; ++u) {
                 const int e = min(e0 + 64 * u, ic_entries - 1);      // (table entries past the disc carry weight 0; the clamp keeps `d` a plain array)
-                rows[u] = e >> ic_shift;
+                const int row = e >> ic_shift;
                 // rows past the disc (zero-weight pad entries) re-read the disc's last row instead of running off it
-                __builtin_memcpy(&d[u], ic0 + (int64_t)min(rows[u], 2 * half) * L.pitch + 4 * (e & ncm), 4);
+                __builtin_memcpy(&d[u], ic0 + (__umul24((uint32_t)min(row, 2 * half), (uint32_t)L.pitch) + 4u * (uint32_t)(e & ncm)), 4);
                 wgt[u] = ic_tab[e];
                 if (e0 + 64 * u >= ic_entries) wgt[u] = make_uint2(0u, 0u);
             }
@@ -1251,7 +1261,8 @@ __global__ __launch_bounds__(256) void describe_blurred_kernel(PyrGeom g, const 
                 const uint32_t srow = __builtin_amdgcn_udot4(d[u], wgt[u].y, 0u, false);
                 accU = __builtin_amdgcn_udot4(d[u], wgt[u].x, accU, false);
                 accS += srow;
-                m01 += (rows[u] - half) * (int)srow;
+                const int row = min(e0 + 64 * u, ic_entries - 1) >> ic_shift;      // (recomputed: eight registers less than keeping it from the loads)
+                m01 += __mul24(row - half, (int)srow);
             }
         }
         m10 = (int)accU - half * (int)accS;
