@@ -353,9 +353,10 @@ __global__ FAST_KERNEL_ATTR __launch_bounds__(256) void fast_kernel(PyrGeom g, c
     __shared__ __attribute__((aligned(16))) uint8_t sc[FAST_SH][FAST_SW];
     // a wave's private share of the queue: its score rows (sy % 4 == wave), back to back
     constexpr int FAST_QR0 = (FAST_SH + 3) / 4, FAST_QR1 = (FAST_SH + 2) / 4, FAST_QR2 = (FAST_SH + 1) / 4;
-    __shared__ uint16_t queue[FAST_SH * FAST_SW];
+    constexpr int FAST_PQ_TOTAL = 4 * 64 * (((FAST_SH * 32 + 255) / 256) + 3 * ((FAST_SH * 32 - 64 + 255) / 256));   // (>= FAST_SH * FAST_SW; see the shares below)
+    __shared__ uint16_t queue[FAST_PQ_TOTAL];
     __shared__ uint16_t gqueue[(FAST_QR0 + FAST_QR0 + FAST_QR0 + FAST_QR0) * 32];    // groups of 4 positions that failed the cheap reject (row * 32 + group), a quarter per wave
-    __shared__ uint32_t qcnt[4];
+    __shared__ uint32_t qcnt[4], gcnt[4];
     // survivors of the block's tiles are staged in LDS and appended to the level's candidate list with ONE returning
     // global atomic per flush (a flush per tile kept every tile waiting for its own round trip); same for the histogram
     __shared__ uint32_t stage[FAST_STAGE_CAP], shist[256], nstage, stage_end, stage_base;
@@ -422,7 +423,12 @@ __global__ FAST_KERNEL_ATTR __launch_bounds__(256) void fast_kernel(PyrGeom g, c
 #endif
     const fast_us2 tt = {(unsigned short)t, (unsigned short)t};
     uint32_t myn = 0;
-    const int qbase = (wave == 0 ? 0 : wave == 1 ? FAST_QR0 : wave == 2 ? FAST_QR0 + FAST_QR1 : FAST_QR0 + FAST_QR1 + FAST_QR2) * FAST_SW;
+    // the position queue's share of a wave = what it can append in phase A2: four positions per group of the pool it walks
+    // (groups 64 w + 256 i + lane of at most FAST_SH * 32): 5 rounds for wave 0, 4 for the others — together every position
+    constexpr int FAST_PQ0 = 4 * 64 * ((FAST_SH * 32 + 255) / 256), FAST_PQ1 = 4 * 64 * ((FAST_SH * 32 - 64 + 255) / 256),
+                  FAST_PQ2 = 4 * 64 * ((FAST_SH * 32 - 128 + 255) / 256), FAST_PQ3 = 4 * 64 * ((FAST_SH * 32 - 192 + 255) / 256);
+    static_assert(FAST_PQ0 + FAST_PQ1 + FAST_PQ2 + FAST_PQ3 <= FAST_PQ_TOTAL, "position queue");
+    const int qbase = wave == 0 ? 0 : wave == 1 ? FAST_PQ0 : wave == 2 ? FAST_PQ0 + FAST_PQ1 : FAST_PQ0 + FAST_PQ1 + FAST_PQ2;
     uint16_t* const myq = queue + qbase;
     auto push1 = [&](bool cond, uint32_t val) {
         const uint64_t mk = __builtin_amdgcn_ballot_w64(cond);
@@ -459,12 +465,19 @@ __global__ FAST_KERNEL_ATTR __launch_bounds__(256) void fast_kernel(PyrGeom g, c
     // packed u16 (even and odd bytes): with lo = sat(v - t), hi = v + t a pair differs iff min(a, b) < lo or max(a, b) > hi, i.e.
     // max(sat(lo - min), sat(max - hi)) != 0; a position stays iff that holds for every pair (the minimum over the pairs).  The
     // pixels of a pair for the four positions are bytes of the aligned dwords left of, at and right of the group in rows 0, +-2,
-    // +-3: eleven ds_read_b32, one v_perm_b32 per (pixel, parity).  Survivors are appended one by one to the wave's quarter of
-    // the position queue.  No barrier between A1 and A2 (a wave reads what it wrote itself).
-    for (uint32_t k0 = 0; k0 < myg; k0 += 64) {
-        const uint32_t kq = k0 + lane;
-        const bool act = kq < myg;
-        const uint32_t e = mygq[min(kq, myg - 1u)];
+    // +-3: eleven ds_read_b32, one v_perm_b32 per (pixel, parity).  Survivors are appended one by one to the share of the position
+    // queue of the wave that tested them.
+    // The groups of the four waves are pooled (one barrier): a tile of a text frame queues ~110 groups, 27 per wave — four rounds
+    // of this loop at 43 % of the lanes when every wave walks its own share, two when the block walks the pool.
+    if (lane == 0) gcnt[wave] = myg;
+    __syncthreads();
+    const uint32_t gc1 = gcnt[0], gc2 = gc1 + gcnt[1], gc3 = gc2 + gcnt[2], ng = gc3 + gcnt[3];
+    for (uint32_t k0 = 64u * (uint32_t)wave; k0 < ng; k0 += 256) {
+        const uint32_t kq = min(k0 + lane, ng - 1u);
+        const bool act = k0 + lane < ng;
+        const uint32_t r = (kq >= gc1) + (kq >= gc2) + (kq >= gc3);
+        const uint32_t e = gqueue[(r == 0 ? 0u : r == 1 ? (uint32_t)FAST_QR0 * 32 - gc1 : r == 2 ? (uint32_t)(FAST_QR0 + FAST_QR1) * 32 - gc2
+                                                                                           : (uint32_t)(FAST_QR0 + FAST_QR1 + FAST_QR2) * 32 - gc3) + kq];
         const int syl = (int)(e >> 5), j = (int)(e & 31u);
         const uint32_t* const c32 = rawdw + (syl + 3) * FAST_NDW + j;
         const uint32_t c = c32[0], pv = c32[-1], nx = c32[1], vt = c32[-3 * FAST_NDW], vb = c32[3 * FAST_NDW];
@@ -514,8 +527,8 @@ __global__ FAST_KERNEL_ATTR __launch_bounds__(256) void fast_kernel(PyrGeom g, c
     const uint32_t qc1 = qcnt[0], qc2 = qc1 + qcnt[1], qc3 = qc2 + qcnt[2];
     auto qat = [&](uint32_t kq) -> int {
         const uint32_t r = (kq >= qc1) + (kq >= qc2) + (kq >= qc3);
-        return queue[(r == 0 ? 0u : r == 1 ? (uint32_t)FAST_QR0 * FAST_SW - qc1 : r == 2 ? (uint32_t)(FAST_QR0 + FAST_QR1) * FAST_SW - qc2
-                                                                                            : (uint32_t)(FAST_QR0 + FAST_QR1 + FAST_QR2) * FAST_SW - qc3) + kq];
+        return queue[(r == 0 ? 0u : r == 1 ? (uint32_t)FAST_PQ0 - qc1 : r == 2 ? (uint32_t)(FAST_PQ0 + FAST_PQ1) - qc2
+                                                                            : (uint32_t)(FAST_PQ0 + FAST_PQ1 + FAST_PQ2) - qc3) + kq];
     };
     // Phase B — segment test + cornerScore<16> on the queued positions only
     const uint32_t nqueued = qc3 + qcnt[3];

@@ -69,7 +69,7 @@ __device__ __forceinline__ int sift_reflect101(int p, int n) {
 // (reading the BGR frame directly cost 27 byte loads per thread: bound by the texture path at 30 us per 1080p frame).
 // The interpolation is resize(INTER_LINEAR)'s: per output coordinate (i0, i1, a0, a1) from the same expression as the oracle
 // (borders clamp to weight 1 / 0), t = g0 a0 + g1 a1 per row, then t0 b0 + t1 b1: unfused multiplies and adds.
-// grid (ceil(w / 512), ceil(h / SIFT_BASE_ROWS), n); the gray rows must be readable 2 bytes past column w - 1 (pitch >= w + 2 or a following row).
+// grid (ceil(w / 512), ceil(h / SIFT_BASE_ROWS), n); the gray rows must be readable 6 bytes past column w - 1 (a following row, or the slack stage_sift reserves).
 constexpr int SIFT_BASE_ROWS = 4;          // source rows per thread (a thread per source pixel: 8.8 M waves of 30 instructions, 2.1 TB/s)
 // One thread = source columns (i, i + 1), i even, x SIFT_BASE_ROWS source rows: one unaligned dword per gray row holds columns
 // i - 1 .. i + 2, the outputs of a doubled row leave as one 16-byte store.
@@ -87,8 +87,11 @@ __global__ __launch_bounds__(256) void sift_base_kernel(const uint8_t* __restric
 #pragma unroll
         for (int q = 0; q < SIFT_BASE_ROWS + 2; ++q) {
             const int row = min(max(j0 - 1 + q, 0), h - 1);
-            uint32_t v;
-            __builtin_memcpy(&v, img + (int64_t)row * gp + xs, 4);
+            // (an aligned pair of dwords and a funnel shift: xs is odd for every thread but the first of a row, and the texture path
+            // splits unaligned loads — resize_quad_kernel, orb.hip.h; up to 6 bytes past column w - 1 are read: stage_sift's slack)
+            uint32_t w2[2];
+            __builtin_memcpy(w2, img + (int64_t)row * gp + (xs & ~3), 8);
+            const uint32_t v = __builtin_amdgcn_alignbit(w2[1], w2[0], (uint32_t)(xs & 3) * 8u);
             const float b0 = (float)(v & 255u), b1 = (float)((v >> 8) & 255u), b2 = (float)((v >> 16) & 255u), b3 = (float)(v >> 24);
             const float c0 = i >= 1 ? b1 : b0;                                            // column i
             const float c1 = i >= 1 ? b2 : b1;                                            // column i + 1 (if it exists)
