@@ -71,6 +71,17 @@ __device__ unsigned int kt_wave[64][8][4];            // per block (the first 64
 #define KT_T0(v)
 #define KT_T1(i, v)
 #endif
+// min(x of lane l, x of lane l ^ 32) in every lane, on the VALU: v_permlane32_swap exchanges the upper half of one register with the
+// lower half of another, and the minimum of the two results is symmetric.  (__shfl_xor goes through the LDS crossbar: a round trip
+// behind the operand reads of every wave of the CU, on the slow path of every pushed row.)
+__device__ __forceinline__ float kt_min_halves(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ int kt_min_halves(int x) {
+    const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)x, false, false);
+    return min((int)r[0], (int)r[1]);
+}
 template <int NT> constexpr int knn_qpb() { return KT_WAVES * 32 * NT; }                         // queries per block
 template <int NT> constexpr size_t knn_pend_words_per_wave() { return (size_t)NT * KT_PEND_CAP * 64; }
 
@@ -408,25 +419,28 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                                      : M::raw(acc[15])) > thri;
             if (__builtin_amdgcn_ballot_w64(gate) == 0ull) continue;
             // the norms of the triple's rows: three LDS reads in flight, one wait (row by row every test paid its own round trip)
-            uint32_t nrm3[3];
+            // ... and their original row numbers with them (six reads in flight, one wait): a gate that opens nearly always ends in a
+            // push, and the row number fetched only then was one more LDS round trip — behind the operand reads of every wave of the
+            // CU — on the path every record-breaking row takes
+            uint32_t nrm3[3], row3[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int r = min(3 * k + u, 15);
                 nrm3[u] = sd[tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                if constexpr (M::hamming) row3[u] = sd[KT_ST_ROWS + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];      // (the L2 engine is at its register limit: it reads the row when it pushes)
             }
 #pragma unroll
             for (int r = 3 * k; r < 3 * k + 3 && r < 16; ++r) {
-                const int ro = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;           // row within the super-tile
                 if constexpr (M::hamming) {
                     const float nrm = __uint_as_float(nrm3[r - 3 * k]);
                     const float v = acc[r];
                     const bool hit = __builtin_fmaf(nrm, -0.5f, v) > hh;              // exact: halves of small integers
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
                         bool take = hit;
-                        if constexpr (M::filtered) { if (hit) take = M::accept(ctx, sd[KT_ST_ROWS + ro], min(qbase + 32 * qt + ql, nq - 1)); }
+                        if constexpr (M::filtered) { if (hit) take = M::accept(ctx, row3[r - 3 * k], min(qbase + 32 * qt + ql, nq - 1)); }
                         if (take) {
                             const float d = nq_i + nrm - 2.f * v;
-                            P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | sd[KT_ST_ROWS + ro];
+                            P[c * 64 + lane] = ((uint32_t)(int)d << KNN_KEY_SHIFT) | row3[r - 3 * k];
                             ++c;
                             dbest = fminf(dbest, d);
                         }
@@ -436,7 +450,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                     const bool hit = sc >= hh;
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
                         if (hit) {
-                            P[c * 64 + lane] = ((Key)(uint32_t)(nq_i - sc) << 32) | (Key)sd[KT_ST_ROWS + ro];
+                            P[c * 64 + lane] = ((Key)(uint32_t)(nq_i - sc) << 32) | (Key)sd[KT_ST_ROWS + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
                             ++c;
                             dbest = fminf(dbest, (float)(nq_i - sc));      // (d^2 < 2^24: exact)
                         }
@@ -448,7 +462,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
         if constexpr (!M::hamming) {
             if (prune_tol > 0.f) {                                       // (the same, for the L2 engine: knl_prune_bound)
                 int bn = dbest < 1.0e9f ? knl_prune_bound((int)dbest, prune_tol) : 0x3FFFFFFF;
-                bn = min(bn, __shfl_xor(bn, 32));
+                bn = kt_min_halves(bn);
                 if (bn < 0x3FFFFFFF) hh = max(hh, (Thr)(nq_i - bn));
             }
         }
@@ -458,7 +472,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
                 // query's final best from above, so the acceptance bound of the best row this lane just pushed is already
                 // valid, and so is the one its partner lane (the other 16 rows of the same query) derived.
                 float bn = ceilf(dbest * prune_tol) - 1.f;
-                bn = fminf(bn, __shfl_xor(bn, 32));
+                bn = kt_min_halves(bn);
                 hh = fmaxf(hh, (nq_i - bn - 1.f) * 0.5f);
             }
         }
