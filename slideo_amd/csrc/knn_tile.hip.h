@@ -512,17 +512,24 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
         // One tile (tt = its index in the super-tile, compile time): (c*) = F(t) are live on entry, (n*) = F(t + 1) on exit;
         // group A (accumulators 0 .. G-1) already holds tile t.  Lc / Ln: this lane's fragment pointers into the slot of the
         // current / the next tile's super-tile; sdc: side array of the current slot.
+#ifdef KT_N23_EARLY      /* experiment: all four fragments of the next tile requested at the tile's start */
+#define KT_EARLY_N23(x) x
+#define KT_LATE_N23(x)
+#else
+#define KT_EARLY_N23(x)
+#define KT_LATE_N23(x) x
+#endif
 #define KT_TILE(tt, c0, c1, c2, c3, n0, n1, n2, n3)                                                                    \
         {                                                                                                             \
             const uint4* Lx_ = (tt) == KT_TPS - 1 ? Ln : Lc + ((tt) + 1) * 256;                                       \
-            n0 = Lx_[0]; n1 = Lx_[64];                                                                                \
+            n0 = Lx_[0]; n1 = Lx_[64]; KT_EARLY_N23(n2 = Lx_[128]; n3 = Lx_[192];)                                   \
             const uint32_t nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                  \
             {                                                                                                         \
                 KT_MFMAS(G, c0, c1, c2, c3)                                                                            \
                 KT_TREES(0, nmh_)                                                                                     \
                 KT_INTERLEAVE                                                                                         \
                 _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) asm volatile("" : "+v"(a[G + g_]));   /* keeps the MFMAs above the branch below */ \
-                n2 = Lx_[128]; n3 = Lx_[192];                                                                         \
+                KT_LATE_N23(n2 = Lx_[128]; n3 = Lx_[192];)                                                            \
                 KT_TEST(0, sdc, tt)                                                                                   \
             }                                                                                                         \
             {                                                                                                         \
@@ -578,6 +585,8 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             }
         }
 #undef KT_TILE
+#undef KT_EARLY_N23
+#undef KT_LATE_N23
 #undef KT_TEST
 #undef KT_TREES
 #undef KT_INTERLEAVE

@@ -217,6 +217,20 @@ def test_orb_edge_cases(capi, oracle, m500):
     _cmp_orb(capi, oracle, m500, oc, odd)
 
 
+def test_orb_every_position_passes_the_quick_reject(capi, oracle, m500, mdef):
+    """Worst case of fast_kernel's queues: gray = 64 ((x + 2 y) mod 4) makes BOTH pixels of every antipodal pair differ from the
+    centre by >= 64 at every position, so every group of four is queued by the cheap reject and every position by the exact pair
+    test (the position queue's per-wave shares are sized for exactly this); also with noise on top (real corners among them)."""
+    yy, xx = np.mgrid[0:420, 0:700]
+    g = (64 * ((xx + 2 * yy) % 4)).astype(np.uint8)
+    img = np.repeat(g[:, :, None], 3, axis=2)
+    _cmp_orb(capi, oracle, m500, small_cfg(oracle), img)
+    rng = np.random.default_rng(5)
+    noisy = np.clip(img.astype(np.int32) + rng.integers(-60, 61, img.shape[:2])[:, :, None], 0, 255).astype(np.uint8)
+    assert _cmp_orb(capi, oracle, m500, small_cfg(oracle), noisy) > 100
+    _cmp_orb(capi, oracle, mdef, oracle.default_config(), noisy)
+
+
 def test_orb_many_ties_kept(capi, oracle, m500):
     # identical corners everywhere -> every score ties; retainBest keeps all of them (count > quota)
     img = np.full((300, 400, 3), 255, np.uint8)
