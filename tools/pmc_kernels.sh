@@ -11,9 +11,9 @@ rocprofv3 --kernel-trace --pmc $B -d $out/b -o t -- python bench.py --steps 2 --
   echo "# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap   (3 dispatches of the 256-frame kernels;"
   echo "# the ORB kernels also run for the page ingest).  VALU share of a kernel = SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * duration * clock)."
   echo "## set A: $A"
-  for k in fast_kernel blur_f32_kernel describe_blurred_kernel resize_quad_kernel gray_kernel reproject knn_tile; do python profiles/summarize_pmc.py $out/a/t_results.db $k; done
+  for k in fast_kernel blur_f32_kernel describe_blurred_kernel resize_quad_kernel gray_kernel reproject ransac_kernel vote_kernel knn_expand_dups sort_kernel compact_kernel knn_tile; do python profiles/summarize_pmc.py $out/a/t_results.db $k; done
   echo "## set B: $B"
-  for k in fast_kernel blur_f32_kernel describe_blurred_kernel resize_quad_kernel gray_kernel reproject knn_tile; do python profiles/summarize_pmc.py $out/b/t_results.db $k; done
+  for k in fast_kernel blur_f32_kernel describe_blurred_kernel resize_quad_kernel gray_kernel reproject ransac_kernel vote_kernel knn_expand_dups sort_kernel compact_kernel knn_tile; do python profiles/summarize_pmc.py $out/b/t_results.db $k; done
 } > gpurun_out/pmc_kernels.txt
 rm -rf $out
 tail -5 gpurun_out/pmc_kernels.txt
