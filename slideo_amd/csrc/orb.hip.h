@@ -7,7 +7,8 @@
 // so that one launch covers >> 256 workgroups.
 //
 //   gray_kernel        BGR8 -> level 0                      (HBM: 3wh in, wh out)
-//   resize_kernel      level l-1 -> l, INTER_LINEAR_EXACT   (7 dependent launches)
+//   resize_quad_kernel level l-1 -> l, INTER_LINEAR_EXACT   (7 dependent launches; per-group tables, shrink factors < ~2.3;
+//                      resize_kernel is the same arithmetic for any factor)
 //   fast_kernel        FAST-9/16 score + 3x3 NMS + border filter -> candidate
 //                      list + per-(frame,level) score histogram   (all levels, one launch)
 //   blur_kernel        7x7 sigma-2 fixed-point Gaussian     (all levels, one launch)
@@ -248,17 +249,15 @@ __device__ __forceinline__ int level_of_tile(const PyrGeom& g, int tile, bool bl
 // positions 4j .. 4j + 3 of a row, and the pixels three rows above and below them, are each ONE aligned LDS dword.
 constexpr int FAST_SW = FAST_TW + 2, FAST_SH = FAST_TH + 2;   // score tile (halo 1)
 constexpr int FAST_XO = 4;                                    // raw column of score position 0
-// raw tile: columns 0 .. FAST_SW - 1 + FAST_XO + 3 are needed (135); the row pitch is 35 dwords — ODD, so that the per-position
-// byte reads of phases A2 / B, whose lanes often sit in one column on consecutive rows (a vertical edge), spread over the banks
-// (34 dwords: LDS bank-conflict cycles x 5)
+// raw tile: columns 0 .. FAST_SW - 1 + FAST_XO + 3 are needed (135); the row pitch is 35 dwords — ODD, so that the gathers of
+// phases A2 (dwords around a group) and B (bytes around a position), whose lanes often sit in one column on consecutive rows (a
+// vertical edge), spread over the banks (34 dwords: LDS bank-conflict cycles x 5)
 constexpr int FAST_RW = FAST_TW + 14, FAST_RH = FAST_TH + 8;
 static_assert(FAST_SW == 128 && FAST_RW % 4 == 0 && (FAST_RW / 4) % 2 == 1 && FAST_RW >= FAST_SW + FAST_XO + 3, "fast_kernel maps one score row onto two wave-widths");
 
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short fast_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fast_s2 fast_swap(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
-
-__device__ __forceinline__ bool fast_differs(int a, int v, int t) { return (unsigned)(a - v + t) > (unsigned)(2 * t); }   // |a - v| > t
 
 // A block walks FAST_TPB consecutive tiles.  The raw pixels of tile i+1 are fetched into registers right after
 // tile i's have been committed to LDS, so the global-load latency (the longest single wait of a tile: about 10 k of
