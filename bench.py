@@ -593,9 +593,14 @@ def main():
                 # launch then lasts longer than a step while the job as a whole gets faster; this is the figure that follows the job.)
                 step_s = out["ms_per_step"] * 1e-3
                 per_step = pairs_per_launch * units_per_step                  # (one launch per unit)
+                alg_step = 2.0 * 256 * (q_per_launch * M) * units_per_step / step_s / 1e12
                 out["roofline"]["over_step"] = {"achieved": round(2.0 * 256 * per_step / step_s / 1e12, 2),
                                                 "frac": round(2.0 * 256 * per_step / step_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                "note": "executed flops of a step's launches / ms_per_step (%.2f launches per step and GPU)" % units_per_step}
+                                                "algorithmic_achieved": round(alg_step, 2), "algorithmic_frac": round(alg_step / MFMA_FP4_PEAK_TFLOPS, 4),
+                                                "note": "executed flops of a step's launches / ms_per_step (%.2f launches per step and GPU); algorithmic_* by "
+                                                        "SURVEY 8(d)'s K x M pair count.  Consecutive launches overlap each other a fifth to a third of the time "
+                                                        "since round 5 (profiles/r05_timeline_overlap.txt): a launch lasts longer than a step, so the per-launch "
+                                                        "`frac` above FALLS when the job gets faster — this is the figure that follows the job" % units_per_step}
             if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
                 a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
                 unit_work = (2.0 * 256 if args.knn != "valu" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
