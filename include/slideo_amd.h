@@ -44,6 +44,7 @@
  * that the tests hold bit-identical, or size workspaces; everything else that used to be switchable this way was removed):
  *   SLIDEO_KNN_ENGINE 0..3        initial value of slideo_matcher_set_knn_engine
  *   SLIDEO_KNN_SHARE=0 / 1        exact Hamming search: always two / always one block per CU (default: one while other units are in flight)
+ *                      =3 / 4    measurement: the 12-wave block (three search waves per SIMD, one block per CU) while other units are in flight / always
  *   SLIDEO_KNN_DEDUP=0            search all M train rows instead of the distinct ones (slideo_matcher_unique_descriptor_count)
  *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
  *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)

@@ -424,7 +424,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     mm->cfg = *cfg; mm->device = device;
     // environment switches of a matcher (include/slideo_amd.h, "Environment"); none changes a result
     { const long v = env_long("SLIDEO_KNN_ENGINE", 0); if (v >= 0 && v <= 3) mm->knn_engine = (int)v; }
-    { const long v = env_long("SLIDEO_KNN_SHARE", -1); if (v >= -1 && v <= 1) mm->knn_share = (int)v; }
+    { const long v = env_long("SLIDEO_KNN_SHARE", -1); if ((v >= -1 && v <= 1) || v == 3 || v == 4) mm->knn_share = (int)v; }
     mm->async_submit = env_long("SLIDEO_ASYNC_SUBMIT", 1) != 0;
     mm->knn_dedup = env_long("SLIDEO_KNN_DEDUP", 1) != 0;
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";

@@ -40,7 +40,8 @@ namespace slideo {
 typedef int knn_v8i __attribute__((ext_vector_type(8)));
 typedef float knn_v16f __attribute__((ext_vector_type(16)));
 
-constexpr int KT_WAVES = 8;                    // waves per block
+constexpr int KT_WAVES = 8;                    // waves per block (and the waves of a block that stage the ring, whatever its size)
+constexpr int KT_WAVES12 = 12;                 // the three-waves-per-SIMD block (knn_tile2w12_kernel)
 constexpr int KT_THREADS = KT_WAVES * 64;
 constexpr int KT_ST_ROWS = 128;                // rows per super-tile (the unit of LDS staging)
 #ifndef KT_RING_V
@@ -82,7 +83,7 @@ __device__ __forceinline__ int kt_min_halves(int x) {
     const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)x, false, false);
     return min((int)r[0], (int)r[1]);
 }
-template <int NT> constexpr int knn_qpb() { return KT_WAVES * 32 * NT; }                         // queries per block
+template <int NT, int W = KT_WAVES> constexpr int knn_qpb() { return W * 32 * NT; }                         // queries per block
 template <int NT> constexpr size_t knn_pend_words_per_wave() { return (size_t)NT * KT_PEND_CAP * 64; }
 
 // 8 bits -> 8 FP4 nibbles: bit b -> 0x2 (+1.0) if set, 0x0 (0.0) if clear; bit i -> nibble i.
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void knn_tile_expand_kernel(const uint32_t* __
 // nminh: [n_st] float4 = half the smallest norm of each of the super-tile's 4 tiles.
 // prune_tol: 0 = exact k-NN lists; > 0 = lists are exact only for the neighbours with d < best * prune_tol (the vote's rule).
 // Grid (ceil(nq / knn_qpb<NT>()), nseg), block 512.  Segment s covers super-tiles [s * st_per_seg, ...).  out: [seg][nq][32] keys.
-template <int NT, typename M>
+template <int NT, typename M, int W = KT_WAVES>
 __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
                                               const uint32_t* __restrict__ side, const uint4* __restrict__ nminh, int nt_pad,
                                               int st_per_seg, typename M::Key* __restrict__ out, typename M::Key* __restrict__ pend_ws,
@@ -218,7 +219,8 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     // nq_dev != null: the grid was sized by CAPACITY and the query count lives on the device (the host did not wait for the
     // ORB stage's counts); blocks past the last query leave at once — before any barrier, the test is block-uniform
     if (nq_dev) nq = (int)*nq_dev;
-    if ((int)blockIdx.x * knn_qpb<NT>() >= nq) return;
+    static_assert(W % 4 == 0 && W >= KT_WAVES, "waves w, w + 4, ... share a SIMD; waves 0 .. KT_WAVES - 1 stage the ring");
+    if ((int)blockIdx.x * knn_qpb<NT, W>() >= nq) return;
 #ifdef KT_PROBE
     unsigned long long kt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     KT_T0(kt_all);
@@ -228,15 +230,15 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     __shared__ uint4 lds[KT_RING][KT_ST_U4];
     __shared__ __attribute__((aligned(16))) uint32_t lds_side[KT_RING][KT_SIDE_U32];
     __shared__ uint32_t s_filled[KT_RING], s_done[KT_RING];           // waves that wrote / finished reading each slot (monotonic)
-    __shared__ Thr s_nq[KT_WAVES][NT][32];                            // |q| (Hamming) / |q'|^2 (L2) of every query of the block (read in the slow path and the flush only)
+    __shared__ Thr s_nq[W][NT][32];                            // |q| (Hamming) / |q'|^2 (L2) of every query of the block (read in the slow path and the flush only)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, ql = lane & 31;
-    const int qbase = blockIdx.x * knn_qpb<NT>() + wave * 32 * NT;
+    const int qbase = blockIdx.x * knn_qpb<NT, W>() + wave * 32 * NT;
     const int seg = blockIdx.y;
     const int n_st = nt_pad / KT_ST_ROWS;
     const int st0 = seg * st_per_seg, st1 = min(n_st, st0 + st_per_seg);
     const int nst = st1 - st0;
-    Key* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KT_WAVES + wave) * knn_pend_words_per_wave<NT>();      // (in keys)
+    Key* const P0 = pend_ws + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * knn_pend_words_per_wave<NT>();      // (in keys)
     auto pend = [&](int i) -> Key* { return P0 + (size_t)i * KT_PEND_CAP * 64; };
 
     // B operands: lane l holds, of query (l & 31) of each tile, the 32 bits of packed dword 2s + (l >> 5) for k-step s
@@ -366,23 +368,26 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     };
     if (tid < KT_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
-    for (int j = 0; j < KT_AHEAD && j < nst; ++j) stage(j, j);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int j = 0; j < KT_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    const bool stager = W == KT_WAVES || wave < KT_WAVES;             // (wave-uniform) a block of more than KT_WAVES waves: the others only read the ring
+    if (stager) {
+        for (int j = 0; j < KT_AHEAD && j < nst; ++j) stage(j, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = 0; j < KT_AHEAD && j < nst; ++j) signal(&s_filled[j]);
+    }
     // e_done / e_filled: the two counters as read one tile EARLIER (counters only grow, so an early value that already meets the
     // target is as good as a fresh one; a wave that tests a fresh read pays the LDS round trip — behind the operand reads of
     // every wave of the CU — twice per super-tile with its matrix pipe idle: a quarter of a wave's time at 2 waves per SIMD)
     auto acquire = [&](int j, uint32_t e_done, uint32_t e_filled) {    // group A is about to read super-tile j
         const int jp = j - 1 + KT_AHEAD, jn = j + KT_AHEAD;
-        if (j > 0 && jp < nst) {                                       // publish this wave's share staged at acquire(j - 1)
+        if (stager && j > 0 && jp < nst) {                             // publish this wave's share staged at acquire(j - 1)
             KT_T0(t_a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             KT_T1(1, t_a);
             signal(&s_filled[jp % KT_RING]);
         }
-        if (jn < nst) {                                                // the slot was last read for super-tile jn - KT_RING
+        if (stager && jn < nst) {                                      // the slot was last read for super-tile jn - KT_RING (by all W waves)
             KT_T0(t_b);
-            const uint32_t tgt = (uint32_t)KT_WAVES * (uint32_t)(jn / KT_RING);
+            const uint32_t tgt = (uint32_t)W * (uint32_t)(jn / KT_RING);
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)e_done) < tgt) wait_ge(&s_done[jn % KT_RING], tgt);
             KT_T1(2, t_b);
             stage(jn, jn % KT_RING);
@@ -544,7 +549,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
         // priorities the arbiter favours the older wave (0 .. 3): it runs ahead until the ring stops it (15 % of its time
         // waiting for a slot, against 5 % for waves 4 .. 7 — per-wave s_memtime sums, profiles/r04_experiments.txt) and the
         // SIMD then runs ONE wave's instruction stream; taking turns keeps both within a super-tile of each other.
-        static_assert(KT_WAVES == 8, "waves w and w + 4 share a SIMD");
+        static_assert(KT_WAVES == 8, "waves w and w + 4 (and w + 8) share a SIMD");
         acquire(0, 0u, 0u);
         const uint4* Lc = lds[0] + lane;
         uint4 x0 = Lc[0], x1 = Lc[64], x2 = Lc[128], x3 = Lc[192];                                 // F(t)
@@ -553,7 +558,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
 #pragma unroll 1
         for (int j = 0; j < nst; ++j) {
             const int slot = j % KT_RING;
-            if ((j ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+            if (W == KT_WAVES ? (((j ^ (wave >> 2)) & 1) != 0) : ((j + (wave >> 2)) % (W / 4) == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
             Lc = lds[slot] + lane;
             const uint32_t* sdc = lds_side[slot];
             const uint4 nm4 = nminh[st0 + j];                          // (wave-uniform address: scalar loads; float / int bit patterns)
@@ -597,7 +602,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     KT_T1(0, kt_all);
     kt_acc[6] = 1; kt_acc[7] = wall_clock64() - kt_wall;
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&kt_probe[i], kt_acc[i]);
-    if (lane == 0 && blockIdx.x >= 100 && blockIdx.x < 164 && blockIdx.y == 0) { unsigned int* w = kt_wave[blockIdx.x - 100][wave]; w[0] = (unsigned)(kt_acc[0] >> 10); w[1] = (unsigned)(kt_acc[4] >> 10); w[2] = (unsigned)(kt_acc[2] >> 10); w[3] = (unsigned)(kt_acc[3] >> 10); }
+    if (lane == 0 && wave < 8 && blockIdx.x >= 100 && blockIdx.x < 164 && blockIdx.y == 0) { unsigned int* w = kt_wave[blockIdx.x - 100][wave]; w[0] = (unsigned)(kt_acc[0] >> 10); w[1] = (unsigned)(kt_acc[4] >> 10); w[2] = (unsigned)(kt_acc[2] >> 10); w[3] = (unsigned)(kt_acc[3] >> 10); }
 #endif
 }
 
@@ -628,6 +633,15 @@ void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __res
 #endif
     knn_tile_body<2, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
                                 prune_tol, nq_dev);
+}
+// Three waves per SIMD: a block of 12 waves (768 queries), ONE per CU by its registers (3 x 128 per SIMD lane; the other 128 and
+// 87 KB of LDS stay free for the other units' kernels).  Waves 0 .. 7 stage the ring as in the 8-wave block, all twelve read it.
+__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(KT_WAVES12 * 64)
+void knn_tile2w12_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
+                         const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
+                         uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+    knn_tile_body<2, KtHamming, KT_WAVES12>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
+                                            prune_tol, nq_dev);
 }
 // the same engine over the LSH candidates only (KtHammingLsh)
 __global__ __launch_bounds__(KT_THREADS, 4)

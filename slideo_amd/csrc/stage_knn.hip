@@ -123,6 +123,9 @@ void knn_probe_report() {
 }
 #endif
 static unsigned share_pad(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 1 || (m->knn_share < 0 && S.u_shared)) ? KT_SHARE_PAD : 0u; }
+// SLIDEO_KNN_SHARE=3 (measurement): while other units are in flight, the 12-wave block — three search waves per SIMD, one block per
+// CU by its registers — instead of the 8-wave block with the LDS pad
+static bool use_w12(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 3 && S.u_shared) || m->knn_share == 4; }      // (4: always — the tests)
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // Engine 0 ("mfma") = the 2-tile wave shape (knn_tile2_kernel: 4 waves/SIMD, two 512-query blocks per CU) at every size: since the
 // {0,1} operand alphabet it runs the headline launch in 10.0 ms alone against 11.3 for the 4-tile shape and the step is 2 %
@@ -134,7 +137,7 @@ static int knn_engine_for(const slideo_matcher* m, int nq) {
 }
 // nq: the query count the plan is made for (the real one, or its estimate when only the device knows it); nq_grid >= nq:
 // what the grid and the buffers are sized for (blocks past the device-side count leave at once)
-static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0) {
+static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0, bool w12 = false) {
     KnnPlan p{};
     nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
     nq_grid = std::max(nq_grid, nq);
@@ -148,17 +151,18 @@ static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0
         p.nseg = cdiv(n_st, p.per_seg);
         p.qblocks = cdiv(nq_grid, knn_qpb<4>());
     } else if (p.engine == 3 && nt > 0) {
-        p.qblocks = cdiv(nq, knn_qpb<2>());
+        const int qpb = w12 ? knn_qpb<2, KT_WAVES12>() : knn_qpb<2>();
+        p.qblocks = cdiv(nq, qpb);
         const int n_st = knn_pad_rows(nt) / KT_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
         // segment pays its own list warm-up and the merge); fewer query blocks split the train set so that the blocks
         // fill the chip in ONE round (floor, not ceil: 1.4 rounds of smaller blocks lose more to the tail than the
         // empty slots do).  Measured (r01): 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
         // 3 segments 23.5 ms; 239 query blocks x 517 k rows (128 1080p frames): 2 segments 6.24 ms, 3 segments 6.65 ms
-        int nseg = p.qblocks >= 384 ? 1 : std::min(std::max(512 / std::max(p.qblocks, 1), 1), n_st);
+        int nseg = p.qblocks >= (w12 ? 192 : 384) ? 1 : std::min(std::max((w12 ? 256 : 512) / std::max(p.qblocks, 1), 1), n_st);
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
-        p.qblocks = cdiv(nq_grid, knn_qpb<2>());
+        p.qblocks = cdiv(nq_grid, qpb);
     } else {
         p.engine = 1;
         p.qblocks = cdiv(nq, KNN_BLOCK);
@@ -172,10 +176,10 @@ static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0
 }
 
 static void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt, int nq_grid = 0) {
-    const KnnPlan p = knn_plan(m, nq, nt, nq_grid);
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, use_w12(m, S));
     S.d_keys.reserve((size_t)p.nseg * std::max(std::max(nq, nq_grid), 1) * KLIST * 4);
     if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<4>() * 4);
-    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<2>() * 4);
+    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * (use_w12(m, S) ? KT_WAVES12 : KT_WAVES) * knn_pend_words_per_wave<2>() * 4);
 }
 
 // prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (matrix-core engine; the VALU
@@ -194,12 +198,15 @@ static void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, c
     if (nq <= 0 && !nq_dev) return;
     hipStream_t st = st_arg ? st_arg : S.st;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
-    const KnnPlan p = knn_plan(m, nq, nt, nq_grid);
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, use_w12(m, S));
     knn_reserve(m, S, nq, nt, nq_grid);
     const int nq_all = std::max(std::max(nq, nq_grid), 1);
     if ((p.engine == 2 || p.engine == 3) && nt > 0) {
         if (p.engine == 2)
             knn_tile4_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
+        else if (use_w12(m, S))
+            knn_tile2w12_kernel<<<dim3(p.qblocks, p.nseg), KT_WAVES12 * 64, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
         else
             knn_tile2_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, share_pad(m, S), st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
