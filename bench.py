@@ -221,6 +221,17 @@ def bench_cfg2(args, wl, rank, world, local_rank, use_dist, barrier_fn):
     m.close()
 
 
+def knn_kernel_label(args):
+    """The search kernel(s) a run launches (stage_knn.hip knn_shape / SLIDEO_KNN_SHARE; --knn mfma4 = the 4-tile A/B shape)."""
+    if args.knn == "mfma4":
+        return "knn_tile4_kernel"
+    share = os.environ.get("SLIDEO_KNN_SHARE", "auto")
+    t1 = "knn_tile1w12_kernel (12 waves x 1 query tile, 80 registers: three waves per SIMD beside the other stages)"
+    t2 = "knn_tile2_kernel (8 waves x 2 query tiles)"
+    return {"auto": t1, "-1": t1, "5": t1 + " while units share the chip, else " + t2, "6": t1, "0": t2 + ", two blocks per CU",
+            "1": t2 + ", one block per CU", "3": "knn_tile2w12_kernel while units share the chip, else " + t2, "4": "knn_tile2w12_kernel"}.get(share, t2)
+
+
 def self_launch(n):
     """Re-executes this command line under torch.distributed.run with n ranks on this node; returns its exit code."""
     import socket
@@ -271,7 +282,13 @@ def main():
                          "matches between pages of one template, accuracy 1.00 on the synthetic decks), or Lowe's ratio test on the two nearest "
                          "rows (the north_star's wording; drops exactly those matches: accuracy 0.71)")
     ap.add_argument("--persp", type=float, default=-1.0, help="projective component of the synthetic frames (0 = similarity frames; default: the workload's)")
+    ap.add_argument("--backend", default="", choices=["", "nccl", "gloo"],
+                    help="collective backend (default: SLIDEO_BENCH_BACKEND or nccl = RCCL). gloo: the verdict all-gather goes through host "
+                         "memory — a control-flow dry run of the N-rank job on a box with fewer GPUs than ranks (with --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="gloo only: ranks may share devices (rank r uses device r mod the visible GPUs). Never a measurement of scaling.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive host-frames record (3 calls after the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
 
@@ -281,7 +298,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SLIDEO_BENCH_FORCE_LAUNCH") == "1"):
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
         # hand their output through — the same command line the driver's torch.distributed.run form runs
         sys.exit(self_launch(args.gpus))
@@ -291,8 +308,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback) [rank %d of %d]" % (rank, world))
     # SLIDEO_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks (ranks then
     # share devices and the verdict all-gather goes through host memory); the driver's runs use nccl = RCCL.
-    backend = os.environ.get("SLIDEO_BENCH_BACKEND", "nccl")
+    backend = args.backend or os.environ.get("SLIDEO_BENCH_BACKEND", "nccl")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if args.share_device and backend == "nccl":
+        raise SystemExit("bench.py: --share-device needs --backend gloo (RCCL needs one GPU per rank)")
     if backend == "nccl" and torch.cuda.device_count() < local_world:
         # RCCL needs one device per rank; two ranks on one device do not fail, they hang in the first collective
         raise SystemExit("bench.py: %d ranks on this node but %d GPU(s) visible — the nccl (= RCCL) backend needs one GPU per rank "
@@ -455,6 +474,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, knn_pairs = m.read_profile()
+    clk_mhz, clk_n = m.read_shader_clock()          # (the search blocks of the timed region; cleared by the read)
     m.set_profiling(False)
     # outside the timed region: the same launches with one batch in flight, i.e. each kernel alone on the GPU
     # (under overlap the kNN shares the CUs with the other batch's ORB / verify kernels and its launches stretch)
@@ -555,52 +575,50 @@ def main():
                 except (OSError, KeyError, ValueError):
                     traffic = None
             # `traffic` = HBM bytes per launch (a number, or null where it was not measured); the passes behind it in traffic_detail
-            common = {"traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic, "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n),
-                      "pairs_per_launch": int(pairs_per_launch), "pairs_per_s": round(pairs_per_launch / avg_s, 1),
-                      "interval": "knn kernel + its list-merge kernel, HIP events on the launch stream",
-                      "launch_overlap_note": "with several batches in flight a launch shares the CUs with the ORB / verification kernels of the other "
-                                             "batches AND, a step being shorter than two launches, with the next batch's kNN launch whose blocks "
-                                             "runs beside it (overlapped batches search with ONE block per CU and leave the other half of every CU to the other stages: stage_knn.hip share_pad): "
-                                             "avg_launch_ms in the timed region is an occupancy figure (it exceeds ms_per_step); "
-                                             "the kernel's own rate is one_batch_in_flight (DESIGN.md section 3)",
+            # ---- the roofline record.  TOP LEVEL = anchored on the driver's clock: the matrix-pipe flops a step's
+            # launches EXECUTE over ms_per_step, so that  frac x peak x ms_per_step == flops_per_step  by construction and the kernel's
+            # time per step cannot exceed the step.  The per-launch figure (a launch's flops over its own HIP-event duration inside the
+            # timed region) is an OCCUPANCY statement since round 4 — overlapped units launch the search one block per CU beside the
+            # other stages and consecutive launches overlap each other, so a launch lasts longer than a step and its rate falls when
+            # the job gets faster: it lives in `per_launch`.  The kernel with the chip to itself is `one_batch_in_flight`.
+            step_s = out["ms_per_step"] * 1e-3
+            launches_per_step = knn_n / max(args.steps, 1)
+            common = {"traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                      "launches_per_step": round(launches_per_step, 3), "pairs_per_launch": int(pairs_per_launch),
+                      "interval": "ms_per_step (barrier + synchronize on both sides of the timed steps): what a step's launches execute / the step",
+                      "shader_clock_mhz": (round(clk_mhz, 1) if clk_n else None),
+                      "shader_clock_note": "s_memtime / s_memrealtime deltas summed over the search blocks of the timed region (every 8th block records; %d samples): the clock the search waves ran at" % clk_n,
                       "hbm_view": hbm_view}
+            per_launch_note = ("a launch's own duration (search kernel + its list merge, HIP events on the launch stream) inside the timed region. With several "
+                               "units in flight a launch shares every CU with the ORB / verify kernels of the other units and overlaps the next unit's "
+                               "launch: an occupancy figure (launches_per_step x avg_launch_ms may exceed ms_per_step), not the kernel's rate")
             if args.knn != "valu":
-                # Hamming = (256 - <+-1,+-1>)/2 as an FP4 contraction: 2*256 flops per pair
-                flops = 2.0 * 256 * pairs_per_launch
-                achieved = flops / avg_s / 1e12
-                # `achieved` / `frac` = the flops the matrix pipe EXECUTES per launch (K x Mu pairs: the distinct train rows; equal rows
-                # are collapsed at finalize and restored in the lists by knn_expand_dups_kernel, inside the timed interval) over the
-                # launch's duration — what ran, never above the peak.  SURVEY 8(d)'s brute-force definition counts K x M pairs over
-                # ALL train rows: that algorithmic-equivalent rate is `algorithmic` (M / Mu times higher on a deck with repeated rows).
-                alg = 2.0 * 256 * (q_per_launch * M) / avg_s / 1e12
+                # Hamming = |q| + |t| - 2 <q, t> on {0,1} FP4 operands: 2 * 256 flops per pair.  Executed pairs = query
+                # descriptors x DISTINCT train rows (K x Mu; equal rows are collapsed at finalize and restored in the lists by
+                # knn_expand_dups_kernel); SURVEY 8(d)'s K x M count over ALL rows is `algorithmic` (effective, not executed).
+                flops_launch = 2.0 * 256 * pairs_per_launch
+                flops_step = flops_launch * launches_per_step
+                achieved = flops_step / step_s / 1e12
+                alg_step = 2.0 * 256 * (q_per_launch * M) * launches_per_step / step_s / 1e12
                 assert achieved <= MFMA_FP4_PEAK_TFLOPS, "executed matrix-core rate above the peak: the pair count or the timing is wrong"
-                out["roofline"] = dict({"kernel": "knn_tile2_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4; --knn mfma4 selects knn_tile4_kernel)", "bound": "mfma",
+                out["roofline"] = dict({"kernel": "%s (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4)" % knn_kernel_label(args), "bound": "mfma",
                                         "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512,
+                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512, "flops_per_step": flops_step,
                                         "counts": "executed pairs: query descriptors x DISTINCT train rows (K x Mu)",
-                                        "algorithmic": {"pairs_per_launch": int(q_per_launch * M), "achieved": round(alg, 2), "frac": round(alg / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                        "note": "SURVEY 8(d)'s definition, K x M pairs over ALL train rows x 512 flops: the rate a search without the "
-                                                                "train-set de-duplication would need for the same launch time (effective, not executed)"}}, **common)
+                                        "algorithmic": {"pairs_per_launch": int(q_per_launch * M), "achieved": round(alg_step, 2), "frac": round(alg_step / MFMA_FP4_PEAK_TFLOPS, 4),
+                                                        "note": "SURVEY 8(d)'s definition, K x M pairs over ALL train rows x 512 flops over the same step: the rate a search "
+                                                                "without the train-set de-duplication would need (effective, not executed)"},
+                                        "per_launch": {"avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n), "achieved": round(flops_launch / avg_s / 1e12, 2),
+                                                       "frac": round(flops_launch / avg_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4), "note": per_launch_note}}, **common)
             else:
-                laneops = LANEOPS_PER_PAIR * pairs_per_launch
-                achieved = laneops / avg_s / 1e12
+                laneops_launch = LANEOPS_PER_PAIR * pairs_per_launch
+                achieved = laneops_launch * launches_per_step / step_s / 1e12
                 out["roofline"] = dict({"kernel": "knn_hamming_kernel<32> (v_xor_b32 + v_bcnt_u32_b32)", "bound": "valu",
                                         "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
-                                        "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR}, **common)
-            if "roofline" in out and out.get("ms_per_step", 0) > 0 and args.knn != "valu":
-                # the same launch's flops over the STEP it is one stage of: what the whole job sustains on the matrix pipe.  (The
-                # launches of overlapped batches run one block per CU — stage_knn.hip share_pad — beside the other stages: a
-                # launch then lasts longer than a step while the job as a whole gets faster; this is the figure that follows the job.)
-                step_s = out["ms_per_step"] * 1e-3
-                per_step = pairs_per_launch * units_per_step                  # (one launch per unit)
-                alg_step = 2.0 * 256 * (q_per_launch * M) * units_per_step / step_s / 1e12
-                out["roofline"]["over_step"] = {"achieved": round(2.0 * 256 * per_step / step_s / 1e12, 2),
-                                                "frac": round(2.0 * 256 * per_step / step_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                "algorithmic_achieved": round(alg_step, 2), "algorithmic_frac": round(alg_step / MFMA_FP4_PEAK_TFLOPS, 4),
-                                                "note": "executed flops of a step's launches / ms_per_step (%.2f launches per step and GPU); algorithmic_* by "
-                                                        "SURVEY 8(d)'s K x M pair count.  Consecutive launches overlap each other a fifth to a third of the time "
-                                                        "since round 5 (profiles/r05_timeline_overlap.txt): a launch lasts longer than a step, so the per-launch "
-                                                        "`frac` above FALLS when the job gets faster — this is the figure that follows the job" % units_per_step}
+                                        "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR,
+                                        "flops_per_step": laneops_launch * launches_per_step,
+                                        "per_launch": {"avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n), "achieved": round(laneops_launch / avg_s / 1e12, 3),
+                                                       "frac": round(laneops_launch / avg_s / 1e12 / VALU_PEAK_TLANEOPS, 4), "note": per_launch_note}}, **common)
             if prof_alone and prof_alone["knn"][1] > 0 and "roofline" in out:
                 a_s = prof_alone["knn"][0] / prof_alone["knn"][1] * 1e-3
                 unit_work = (2.0 * 256 if args.knn != "valu" else LANEOPS_PER_PAIR) * (pairs_alone / prof_alone["knn"][1]) / 1e12
@@ -633,6 +651,23 @@ def main():
                                 "achieved": rate(ref_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rate(ref_ms) / HBM_PEAK_GBS, 4),
                                 "interval": "one batch in flight" if alone_ms > 0 else "timed region",
                                 "in_timed_region": {"ms": round(orb_ms, 3), "achieved": rate(orb_ms), "frac": round(rate(orb_ms) / HBM_PEAK_GBS, 4)}}
+
+    # ---- the drop-in path's rate: HOST frames in (what crates/matching-hip and every host mirror hand over), PCIe-inclusive —
+    # never `value` (inputs are resident in HBM when the timed region starts); 1 warm-up + 3 calls on pinned memory, outside the
+    # timed region (rank 0, N=1)
+    if rank == 0 and world == 1 and not args.no_host_frames:
+        hf = torch.from_numpy(frames).pin_memory().numpy()
+        hv = m.match_frames(hf)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            hv = m.match_frames(hf)
+        dth = (time.perf_counter() - t0) / 3
+        out["host_frames"] = {"value": round(len(hf) / dth, 1), "unit": "frames/s", "ms_per_call": round(dth * 1e3, 3), "frames_per_call": int(len(hf)),
+                              "h2d_inclusive_GBps": round(hf.nbytes / dth / 1e9, 2), "memory": "pinned host memory",
+                              "verdicts_equal_to_resident_run": bool(np.array_equal(hv["page_idx"][(np.arange(B) + g_last) % pool], v["page_idx"])) if B == pool == len(hf) else None,
+                              "note": "slideo_match_frames_bgr8 on host frames: the H2D copy (one ordered copy stream, 32-frame units) is the bound; "
+                                      "reported beside `value`, never as it"}
+        del hf
 
     # ---- CPU baseline: the CPU restatement on the host cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,10 +1,10 @@
-//! Hand-written declarations of include/slideo_amd.h (ABI 6) — what bindgen would emit for the entry points this crate
+//! Hand-written declarations of include/slideo_amd.h (ABI 7) — what bindgen would emit for the entry points this crate
 //! uses.  Field order and types mirror the C structs exactly; tests/test_capi_load.py pins the C side's layout
 //! (sizeof(slideo_config) == 168) and `assert_abi()` below pins the version at run time.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_char;
 
-pub const SLIDEO_ABI_VERSION: u32 = 6;
+pub const SLIDEO_ABI_VERSION: u32 = 7;
 
 /// slideo_ocv_variants: which restatement of each OpenCV primitive runs.  slideo_config_default fills it; the
 /// application never touches it.

@@ -70,7 +70,7 @@
 extern "C" {
 #endif
 
-#define SLIDEO_ABI_VERSION 6
+#define SLIDEO_ABI_VERSION 7
 
 enum {
     SLIDEO_OK = 0,
@@ -223,7 +223,8 @@ typedef struct slideo_config {
      * re-projects its shared template as well as the true page and wins by a few thousandths of similarity on ~13 % of the
      * synthetic headline frames, while the true page has the most inliers (DESIGN.md section 5 has the measured effect). */
     int32_t verdict_rule;         /* 0 */
-    /* which restatement of each OpenCV primitive to run (all 0 / 4164903690 by default) */
+    /* which restatement of each OpenCV primitive to run.  Defaults: all 0 EXCEPT hdlt = 1 (ABI 6), rng_mul 4164903690 — obtain
+     * them from slideo_config_default: a zero-initialised ocv selects hdlt 0, a different (60x slower) form than the default */
     slideo_ocv_variants ocv;
 } slideo_config;
 
@@ -392,6 +393,12 @@ int32_t     slideo_matcher_set_knn_exact_lists(slideo_matcher* m, int32_t on);
 int32_t     slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable);
 int32_t     slideo_matcher_read_profile(slideo_matcher* m, double* ms_out /*[4]*/,
                                         int64_t* launches_out /*[4]*/, int64_t* knn_pairs_out);
+/* ABI 7.  The shader clock (MHz) the search kernel's waves ran at since profiling was switched on or this was last read:
+ * wave 0 of every 8th search block sums its s_memtime (shader cycles) and s_memrealtime (100 MHz) deltas in device memory
+ * (csrc/knn_tile.hip.h KtClock); *samples_out = the blocks that recorded (0: no search ran while profiling; *mhz_out is 0
+ * then).  Measurement only (bench.py roofline.shader_clock_mhz): the chip clocks to its power budget, 2.1 - 2.3 of 2.4 GHz
+ * under this load.  The matcher must be idle. */
+int32_t     slideo_matcher_read_shader_clock(slideo_matcher* m, double* mhz_out, int64_t* samples_out);
 
 /* ---- debug taps used by the parity tests ------------------------------ */
 

@@ -69,7 +69,7 @@ EXPORTS = [
     "slideo_match_frames_bgr8", "slideo_match_frames_bgr8_dev", "slideo_changed_mask_bgr8",
     "slideo_matcher_set_progress", "slideo_orb_bgr8", "slideo_pyramid_level_bgr8",
     "slideo_knn_hamming", "slideo_knn_l2_u8", "slideo_small_image_bgr8", "slideo_last_frame_candidates",
-    "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
+    "slideo_matcher_set_profiling", "slideo_matcher_read_profile", "slideo_matcher_read_shader_clock", "slideo_matcher_set_knn_engine", "slideo_matcher_set_knn_exact_lists",
     "slideo_match_frames_submit_dev", "slideo_match_frames_collect", "slideo_match_frames_collect_dev",
     "slideo_matcher_add_page_features", "slideo_matcher_get_page_small", "slideo_l2_set_train", "slideo_l2_knn_dev",
     "slideo_matcher_unique_descriptor_count", "slideo_match_kept_frames", "slideo_host_register", "slideo_host_unregister",
@@ -362,6 +362,12 @@ class Matcher:
         names = ["orb", "knn", "verify", "total"]
         return {names[i]: (ms[i], n[i]) for i in range(4)}, pairs.value
 
+    def read_shader_clock(self):
+        """-> (MHz the search kernel's waves ran at while profiling, blocks that recorded); clears the sums (ABI 7)."""
+        mhz = C.c_double(); n = C.c_int64()
+        self._check(lib().slideo_matcher_read_shader_clock(self._h, C.byref(mhz), C.byref(n)))
+        return mhz.value, n.value
+
     # ---- debug taps -----------------------------------------------------------------
     def orb(self, bgr, cap=None):
         bgr = _img3(bgr)
@@ -437,13 +443,13 @@ class Matcher:
 class Group:
     """slideo_group (include/slideo_amd.h, "N-device group"): one matcher per device behind one handle — page DB replicated,
     a call's pages and frames sharded contiguously over the devices, verdicts gathered into one host array.  Results equal
-    a single Matcher's bit for bit.  `devices`: HIP ordinals (may repeat); None = every gfx950 device of the node."""
+    a single Matcher's bit for bit.  `devices`: HIP ordinals (may repeat); None or empty = every gfx950 device of the node."""
 
     def __init__(self, cfg=None, devices=None):
         self.cfg = cfg if cfg is not None else default_config()
         self._h = C.c_void_p()
         self._cb = None
-        if devices is None:
+        if devices is None or len(devices) == 0:     # (an empty list = n_devices 0 = the same request: never a stale empty self.devices)
             # every gfx950 device of the node: the library enumerates them by their own HIP ordinals (n_devices 0)
             rc = lib().slideo_group_create(C.byref(self.cfg), 0, None, C.byref(self._h))
             self.devices = device_list() if rc == OK else []

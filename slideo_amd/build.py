@@ -23,7 +23,7 @@ SYNTH_LIB = os.path.join(LIBDIR, "libslideo_synth.so")
 HIP_SOURCES = ["capi_runtime.hip", "capi_group.hip", "capi_taps.hip", "stage_orb.hip", "stage_knn.hip", "stage_verify.hip", "stage_sift.hip"]
 # the kernel headers each unit includes (beyond runtime.hpp and the plain headers, which every unit depends on)
 HIP_UNIT_HEADERS = {"stage_orb.hip": ["orb.hip.h", "cv_math.hip.h"],
-                    "stage_knn.hip": ["knn.hip.h", "knn_tile.hip.h", "knn_l2.hip.h", "knn_lsh.hip.h"],
+                    "stage_knn.hip": ["knn.hip.h", "knn_tile.hip.h", "knn_tile1.hip.h", "knn_l2.hip.h", "knn_lsh.hip.h"],
                     "stage_verify.hip": ["verify.hip.h", "homography.hip.h"],
                     "stage_sift.hip": ["sift.hip.h", "cv_math.hip.h"]}
 HIP_COMMON_HEADERS = ["runtime.hpp", "common.h", "geom.h", "types.h"]

@@ -424,7 +424,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     mm->cfg = *cfg; mm->device = device;
     // environment switches of a matcher (include/slideo_amd.h, "Environment"); none changes a result
     { const long v = env_long("SLIDEO_KNN_ENGINE", 0); if (v >= 0 && v <= 3) mm->knn_engine = (int)v; }
-    { const long v = env_long("SLIDEO_KNN_SHARE", -1); if ((v >= -1 && v <= 1) || v == 3 || v == 4) mm->knn_share = (int)v; }
+    { const long v = env_long("SLIDEO_KNN_SHARE", -1); if ((v >= -1 && v <= 1) || (v >= 3 && v <= 6)) mm->knn_share = (int)v; }
     mm->async_submit = env_long("SLIDEO_ASYNC_SUBMIT", 1) != 0;
     mm->knn_dedup = env_long("SLIDEO_KNN_DEDUP", 1) != 0;
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";
@@ -452,6 +452,9 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     }
     for (Slot& S : mm->slots) {
         if (mm->cu_split) {
+            // (hipExtStreamCreateWithCUMask has no flags argument: these are BLOCKING streams — they synchronise implicitly with the
+            // legacy NULL stream, unlike the hipStreamNonBlocking streams of the normal path; a caller with default-stream work of its
+            // own distorts what the switch measures)
             if (cu_split_others) HIP_CHECK(hipExtStreamCreateWithCUMask(&S.st, 8, mask_rest));
             else HIP_CHECK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
             HIP_CHECK(hipExtStreamCreateWithCUMask(&S.st_knn, 8, mask_knn));
@@ -525,6 +528,24 @@ int32_t slideo_matcher_set_profiling(slideo_matcher* m, int32_t enable) {
     m->profiling = enable != 0;
     for (int i = 0; i < SLIDEO_N_STAGES; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
     m->prof_pairs = 0;
+    m->d_clk.reserve(64);
+    HIP_CHECK(hipMemset(m->d_clk.p, 0, 64));
+    API_CATCH(m)
+}
+
+int32_t slideo_matcher_read_shader_clock(slideo_matcher* m, double* mhz_out, int64_t* samples_out) {
+    if (!m || !mhz_out) return SLIDEO_ERR_INVALID_ARG;
+    API_TRY
+    *mhz_out = 0.0;
+    if (samples_out) *samples_out = 0;
+    if (!m->d_clk.p) return SLIDEO_OK;                       // profiling was never on
+    HIP_CHECK(hipSetDevice(m->device));
+    require_idle(m);
+    unsigned long long v[3] = {0, 0, 0};
+    HIP_CHECK(hipMemcpy(v, m->d_clk.p, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(m->d_clk.p, 0, 64));
+    if (v[1] > 0) *mhz_out = 100.0 * (double)v[0] / (double)v[1];      // s_memrealtime counts 100 MHz
+    if (samples_out) *samples_out = (int64_t)v[2];
     API_CATCH(m)
 }
 

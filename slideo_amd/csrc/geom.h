@@ -210,7 +210,7 @@ inline bool config_supported(const slideo_config& c, const char** why) {
     if (o.hdlt < 0 || o.hdlt > 2) { *why = "ocv.hdlt must be 0, 1 or 2"; return false; }
     if (c.verify_model < 0 || c.verify_model > 1) { *why = "verify_model must be 0 (similarity) or 1 (homography)"; return false; }
     if (c.matcher < 0 || c.matcher > 1) { *why = "matcher must be 0 (exact) or 1 (LSH-compatible)"; return false; }
-    if (c.verdict_rule < 0 || c.verdict_rule > 1) { *why = "verdict_rule must be 0 (best similarity, the reference) or 1 (most inliers among the accepted)"; return false; }
+    if (c.verdict_rule < 0 || c.verdict_rule > 1) { *why = "verdict_rule must be 0 (best similarity, the reference) or 1 (rating order, the similarity only accepts)"; return false; }
     if (c.matcher == 1 && (c.lsh_tables < 1 || c.lsh_tables > 8 || c.lsh_key_bits < 1 || c.lsh_key_bits > 16 || c.lsh_multi_probe < 0 || c.lsh_multi_probe > 2)) {
         *why = "lsh_tables must be 1..8, lsh_key_bits 1..16, lsh_multi_probe 0..2"; return false;
     }

@@ -83,6 +83,45 @@ __device__ __forceinline__ int kt_min_halves(int x) {
     const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)x, false, false);
     return min((int)r[0], (int)r[1]);
 }
+// The shader clock the search waves run at, measured where they run (slideo_matcher_read_shader_clock; bench.py roofline.shader_clock_mhz):
+// wave 0 of every 8th block adds its s_memtime (shader cycles) and s_memrealtime (100 MHz) deltas over the block's life to clk[0], clk[1]
+// and counts itself in clk[2].  clk == null (not profiling): nothing.  Stateless — the start values are SUBTRACTED in memory, nothing
+// lives in registers through the kernel (the 2-tile shape has none to spare).
+__device__ __forceinline__ void kt_clock(unsigned long long* __restrict__ clk, bool stop) {
+    if (clk != nullptr && (blockIdx.x & 7u) == 0u && threadIdx.x == 0) {
+        const unsigned long long c = __builtin_readcyclecounter(), w = wall_clock64();
+        atomicAdd(clk, stop ? c : 0ull - c);
+        atomicAdd(clk + 1, stop ? w : 0ull - w);
+        if (stop) atomicAdd(clk + 2, 1ull);
+    }
+}
+// ---- the ring's counters, in inline assembly --------------------------------------------------------------------------------
+// The compiler orders EVERY LDS access it emits behind all pending LDS-DMA of the wave (`s_waitcnt vmcnt(0)` in front of the first
+// ds instruction after a global_load_lds that it cannot prove disjoint): with the counters read and bumped through builtins every
+// staging wave waited, twice per super-tile, for the share it had JUST issued — the landing deadline of a fetch was half a
+// super-tile instead of the look-ahead the ring was built for (found round 6 in the ISA: the waits sat in front of the early
+// peek and of the signal's ds_add).  Issued from inline assembly the counter accesses carry no such wait; what they need — the
+// wave's own LDS reads done before a `done` signal, a peeked value landed before it is tested — is waited for explicitly.
+__device__ __forceinline__ uint32_t kt_lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }      // (low half of a flat LDS address = the LDS offset)
+__device__ __forceinline__ uint32_t kt_ring_peek(const uint32_t* p) {                                 // issued, NOT waited for: kt_ring_landed() before the value is used
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(kt_lds_addr(p)) : "memory");
+    return r;
+}
+__device__ __forceinline__ void kt_ring_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t kt_ring_read(const uint32_t* p) {
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(kt_lds_addr(p)) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+__device__ __forceinline__ void kt_ring_signal(uint32_t* p, int lane) {     // after everything this wave read from / wrote to the LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(kt_lds_addr(p)), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void kt_ring_wait_ge(const uint32_t* p, uint32_t target) {
+    while (kt_ring_read(p) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 template <int NT, int W = KT_WAVES> constexpr int knn_qpb() { return W * 32 * NT; }                         // queries per block
 template <int NT> constexpr size_t knn_pend_words_per_wave() { return (size_t)NT * KT_PEND_CAP * 64; }
 
@@ -210,7 +249,8 @@ template <int NT, typename M, int W = KT_WAVES>
 __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int nq, const uint4* __restrict__ tx,
                                               const uint32_t* __restrict__ side, const uint4* __restrict__ nminh, int nt_pad,
                                               int st_per_seg, typename M::Key* __restrict__ out, typename M::Key* __restrict__ pend_ws,
-                                              float prune_tol, const uint32_t* __restrict__ nq_dev, typename M::Ctx ctx = typename M::Ctx()) {
+                                              float prune_tol, const uint32_t* __restrict__ nq_dev, typename M::Ctx ctx = typename M::Ctx(),
+                                              unsigned long long* __restrict__ clk = nullptr) {
     typedef typename M::Acc Acc;
     typedef typename M::Key Key;
     typedef typename M::Thr Thr;
@@ -221,6 +261,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     if (nq_dev) nq = (int)*nq_dev;
     static_assert(W % 4 == 0 && W >= KT_WAVES, "waves w, w + 4, ... share a SIMD; waves 0 .. KT_WAVES - 1 stage the ring");
     if ((int)blockIdx.x * knn_qpb<NT, W>() >= nq) return;
+    kt_clock(clk, false);
 #ifdef KT_PROBE
     unsigned long long kt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     KT_T0(kt_all);
@@ -357,6 +398,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(side + (size_t)(st0 + jj) * KT_SIDE_U32 + wave * 64 + lane),
                                              (__attribute__((address_space(3))) void*)&lds_side[sl][wave * 64], 4, 0, 0);
     };
+#ifdef KT_RING_BUILTIN       /* A/B: the counters through compiler builtins (rounds 1 - 5; see kt_ring_peek) */
     auto signal = [&](uint32_t* f) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -366,6 +408,10 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
+#else
+    auto signal = [&](uint32_t* f) { kt_ring_signal(f, lane); };
+    auto wait_ge = [&](uint32_t* f, uint32_t target) { kt_ring_wait_ge(f, target); };
+#endif
     if (tid < KT_RING) { s_filled[tid] = 0; s_done[tid] = 0; }
     __syncthreads();
     const bool stager = W == KT_WAVES || wave < KT_WAVES;             // (wave-uniform) a block of more than KT_WAVES waves: the others only read the ring
@@ -379,6 +425,9 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     // every wave of the CU — twice per super-tile with its matrix pipe idle: a quarter of a wave's time at 2 waves per SIMD)
     auto acquire = [&](int j, uint32_t e_done, uint32_t e_filled) {    // group A is about to read super-tile j
         const int jp = j - 1 + KT_AHEAD, jn = j + KT_AHEAD;
+#ifndef KT_RING_BUILTIN
+        kt_ring_landed();                                              // (the early peeks, issued a tile ago)
+#endif
         if (stager && j > 0 && jp < nst) {                             // publish this wave's share staged at acquire(j - 1)
             KT_T0(t_a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -398,7 +447,11 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
         asm volatile("" ::: "memory");
         KT_T1(3, t_c);
     };
+#ifdef KT_RING_BUILTIN
     auto peek = [&](const uint32_t* f) -> uint32_t { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#else
+    auto peek = [&](const uint32_t* f) -> uint32_t { return kt_ring_peek(f); };
+#endif
     auto mfma = [&](Acc acc, const uint4& f, const typename M::Bop& b) { return M::mfma(acc, f, b); };
     // maxima of the raw bit patterns: triples {3k, 3k+1, 3k+2}, k = 0..4, register 15 apart
     // (only the overall maximum is kept: the slow path recomputes the triple maxima it gates on — ten registers per skew group
@@ -598,6 +651,7 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
 #undef KT_MFMAS
     }
     flush();
+    kt_clock(clk, true);
 #ifdef KT_PROBE
     KT_T1(0, kt_all);
     kt_acc[6] = 1; kt_acc[7] = wall_clock64() - kt_wall;
@@ -627,21 +681,21 @@ __global__ __launch_bounds__(KT_THREADS, 4)
 #endif
 void knn_tile2_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                       const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
-                      uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+                      uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev, unsigned long long* __restrict__ clk) {
 #ifdef KT2_CLOBBER      /* experiment: the register allocation of a larger wave shape without its code */
     asm volatile("" ::: KT2_CLOBBER);
 #endif
     knn_tile_body<2, KtHamming>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
-                                prune_tol, nq_dev);
+                                prune_tol, nq_dev, KtNoCtx(), clk);
 }
 // Three waves per SIMD: a block of 12 waves (768 queries), ONE per CU by its registers (3 x 128 per SIMD lane; the other 128 and
 // 87 KB of LDS stay free for the other units' kernels).  Waves 0 .. 7 stage the ring as in the 8-wave block, all twelve read it.
 __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(KT_WAVES12 * 64)
 void knn_tile2w12_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                          const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
-                         uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev) {
+                         uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev, unsigned long long* __restrict__ clk) {
     knn_tile_body<2, KtHamming, KT_WAVES12>(reinterpret_cast<const uint8_t*>(q), nq, tx, side, reinterpret_cast<const uint4*>(nminh), nt_pad, st_per_seg, out, pend_ws,
-                                            prune_tol, nq_dev);
+                                            prune_tol, nq_dev, KtNoCtx(), clk);
 }
 // the same engine over the LSH candidates only (KtHammingLsh)
 __global__ __launch_bounds__(KT_THREADS, 4)

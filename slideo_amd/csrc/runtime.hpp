@@ -182,6 +182,7 @@ struct slideo_matcher {
     double prof_ms[SLIDEO_N_STAGES] = {0, 0, 0, 0};
     int64_t prof_n[SLIDEO_N_STAGES] = {0, 0, 0, 0};
     int64_t prof_pairs = 0;
+    slideo::DevBuf d_clk;           // {shader cycles, 100 MHz ticks, samples} summed by the search blocks while profiling (knn_tile.hip.h KtClock)
 
     // trace of the last match call
     std::vector<slideo::FrameCands> last_fcs;

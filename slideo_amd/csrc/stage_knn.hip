@@ -2,6 +2,7 @@
 #include "runtime.hpp"
 #include "knn.hip.h"
 #include "knn_tile.hip.h"
+#include "knn_tile1.hip.h"
 #include "knn_l2.hip.h"
 #include "knn_lsh.hip.h"
 
@@ -122,10 +123,22 @@ void knn_probe_report() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(slideo::kt_probe), z, sizeof(z));
 }
 #endif
-static unsigned share_pad(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 1 || (m->knn_share < 0 && S.u_shared)) ? KT_SHARE_PAD : 0u; }
-// SLIDEO_KNN_SHARE=3 (measurement): while other units are in flight, the 12-wave block — three search waves per SIMD, one block per
-// CU by its registers — instead of the 8-wave block with the LDS pad
-static bool use_w12(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 3 && S.u_shared) || m->knn_share == 4; }      // (4: always — the tests)
+static unsigned share_pad(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 1 || ((m->knn_share < 0 || m->knn_share >= 5) && S.u_shared)) ? KT_SHARE_PAD : 0u; }
+// The block shape of the exact Hamming search (engine 3).  SHAPE_T2: knn_tile2_kernel, 8 waves x 2 query tiles, two blocks per CU or
+// — with the LDS pad — one.  SHAPE_T2W12 (SLIDEO_KNN_SHARE=3 / 4, measurement): the same wave shape, 12 waves, one block per CU by
+// its registers.  SHAPE_T1W12 (knn_tile1.hip.h; SLIDEO_KNN_SHARE=5: while other units are in flight, 6: always): 12 waves x 1 query
+// tile at 80 registers — three waves per SIMD in the registers two 2-tile waves take; one block per CU by the LDS pad while units
+// share the chip, two otherwise.  Only the exact search (matcher 0): the LSH-filtered stream has its own kernel and plan.
+enum KnnShape { SHAPE_T2 = 0, SHAPE_T2W12 = 1, SHAPE_T1W12 = 2 };
+static KnnShape knn_shape(const slideo_matcher* m, const Slot& S) {
+    if (m->cfg.matcher != 0) return SHAPE_T2;
+    if ((m->knn_share == 3 && S.u_shared) || m->knn_share == 4) return SHAPE_T2W12;
+    if ((m->knn_share == 5 && S.u_shared) || m->knn_share == 6) return SHAPE_T1W12;
+    return SHAPE_T2;
+}
+static int shape_qpb(KnnShape sh) { return sh == SHAPE_T1W12 ? KT1_QPB : sh == SHAPE_T2W12 ? knn_qpb<2, KT_WAVES12>() : knn_qpb<2>(); }
+static int shape_waves(KnnShape sh) { return sh == SHAPE_T1W12 ? KT1_WAVES : sh == SHAPE_T2W12 ? KT_WAVES12 : KT_WAVES; }
+static size_t shape_pend_words(KnnShape sh) { return sh == SHAPE_T1W12 ? KT1_PEND_WORDS_PER_WAVE : knn_pend_words_per_wave<2>(); }
 struct KnnPlan { int engine, qblocks, nseg, per_seg; };
 // Engine 0 ("mfma") = the 2-tile wave shape (knn_tile2_kernel: 4 waves/SIMD, two 512-query blocks per CU) at every size: since the
 // {0,1} operand alphabet it runs the headline launch in 10.0 ms alone against 11.3 for the 4-tile shape and the step is 2 %
@@ -137,7 +150,7 @@ static int knn_engine_for(const slideo_matcher* m, int nq) {
 }
 // nq: the query count the plan is made for (the real one, or its estimate when only the device knows it); nq_grid >= nq:
 // what the grid and the buffers are sized for (blocks past the device-side count leave at once)
-static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0, bool w12 = false) {
+static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0, KnnShape sh = SHAPE_T2) {
     KnnPlan p{};
     nq = std::max(nq, 1);            // a unit may hold no keypoint at all (e.g. one flat frame)
     nq_grid = std::max(nq_grid, nq);
@@ -151,7 +164,8 @@ static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0
         p.nseg = cdiv(n_st, p.per_seg);
         p.qblocks = cdiv(nq_grid, knn_qpb<4>());
     } else if (p.engine == 3 && nt > 0) {
-        const int qpb = w12 ? knn_qpb<2, KT_WAVES12>() : knn_qpb<2>();
+        const int qpb = shape_qpb(sh);
+        const bool w12 = sh == SHAPE_T2W12;                              // (one block per CU whatever else runs: 256 slots)
         p.qblocks = cdiv(nq, qpb);
         const int n_st = knn_pad_rows(nt) / KT_ST_ROWS;
         // the chip holds 512 blocks (two per CU).  From 3/4 of that on, one pass over the train set is best (every
@@ -176,10 +190,12 @@ static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0
 }
 
 static void knn_reserve(slideo_matcher* m, Slot& S, int nq, int nt, int nq_grid = 0) {
-    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, use_w12(m, S));
+    // (always for the plan that is launched: knn_shape is SHAPE_T2 for the LSH-filtered stream, whose launch plans without a shape)
+    const KnnShape sh = knn_shape(m, S);
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, sh);
     S.d_keys.reserve((size_t)p.nseg * std::max(std::max(nq, nq_grid), 1) * KLIST * 4);
     if (p.engine == 2) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * KT_WAVES * knn_pend_words_per_wave<4>() * 4);
-    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * (use_w12(m, S) ? KT_WAVES12 : KT_WAVES) * knn_pend_words_per_wave<2>() * 4);
+    if (p.engine == 3) S.d_knn_pend.reserve((size_t)p.qblocks * p.nseg * shape_waves(sh) * shape_pend_words(sh) * 4);
 }
 
 // prune_tol > 0: only neighbours that can pass the vote's `d < best * tol` need to be exact (matrix-core engine; the VALU
@@ -198,19 +214,24 @@ static void run_knn(slideo_matcher* m, Slot& S, const uint32_t* q_dev, int nq, c
     if (nq <= 0 && !nq_dev) return;
     hipStream_t st = st_arg ? st_arg : S.st;
     if ((int64_t)nt >= ((int64_t)1 << KNN_KEY_SHIFT)) fail(SLIDEO_ERR_UNSUPPORTED, "train set of %d rows exceeds %d", nt, 1 << KNN_KEY_SHIFT);
-    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, use_w12(m, S));
+    const KnnShape sh = knn_shape(m, S);
+    const KnnPlan p = knn_plan(m, nq, nt, nq_grid, sh);
     knn_reserve(m, S, nq, nt, nq_grid);
     const int nq_all = std::max(std::max(nq, nq_grid), 1);
+    unsigned long long* const clk = m->profiling ? m->d_clk.as<unsigned long long>() : nullptr;      // (slideo_matcher_read_shader_clock)
     if ((p.engine == 2 || p.engine == 3) && nt > 0) {
         if (p.engine == 2)
             knn_tile4_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
                                                                              S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
-        else if (use_w12(m, S))
+        else if (sh == SHAPE_T1W12)
+            knn_tile1w12_kernel<<<dim3(p.qblocks, p.nseg), KT1_WAVES * 64, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev, clk);
+        else if (sh == SHAPE_T2W12)
             knn_tile2w12_kernel<<<dim3(p.qblocks, p.nseg), KT_WAVES12 * 64, 0, st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
-                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev, clk);
         else
             knn_tile2_kernel<<<dim3(p.qblocks, p.nseg), KT_THREADS, share_pad(m, S), st>>>(q_dev, nq, T.txb, T.side, T.nminh, knn_pad_rows(nt), p.per_seg,
-                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev);
+                                                                             S.d_keys.as<uint32_t>(), S.d_knn_pend.as<uint32_t>(), prune_tol, nq_dev, clk);
         check_launch("knn_tile_kernel");
         if (p.nseg > 1) {
             knn_merge_kernel<KLIST><<<cdiv(nq_all, KNN_BLOCK), KNN_BLOCK, 0, st>>>(S.d_keys.as<uint32_t>(), nq, p.nseg, nq_dev);

@@ -33,6 +33,16 @@ def test_single_gpu_line():
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] <= 1        # the EXECUTED rate (K x Mu pairs)
     assert rf["algorithmic"]["frac"] >= rf["frac"]                                            # SURVEY 8(d)'s K x M count, reported beside it
+    # the line's own cross-check: the top-level figure is anchored on the driver's clock —
+    # frac x peak x ms_per_step == the flops a step's launches execute (so the kernel's time per step cannot exceed the step)
+    flops = rf["frac"] * rf["peak"] * 1e12 * j["ms_per_step"] * 1e-3
+    assert abs(flops - rf["flops_per_step"]) <= 0.02 * rf["flops_per_step"], (flops, rf["flops_per_step"])
+    assert abs(rf["flops_per_step"] - 512.0 * rf["pairs_per_launch"] * rf["launches_per_step"]) <= 1e-6 * rf["flops_per_step"]
+    pl = rf["per_launch"]                                                                      # the occupancy figure lives in a sub-record
+    assert pl["avg_launch_ms"] > 0 and pl["launches"] >= 3 and 0 < pl["frac"] <= 1
+    assert rf["shader_clock_mhz"] is None or 500 < rf["shader_clock_mhz"] < 2600              # measured by the search blocks themselves (ABI 7)
+    hf = j["host_frames"]                                                                      # the PCIe-inclusive rate of the drop-in path, beside `value`
+    assert hf["value"] > 0 and hf["h2d_inclusive_GBps"] > 0 and hf["verdicts_equal_to_resident_run"] is True
     assert rf["traffic"] is None or isinstance(rf["traffic"], (int, float))      # HBM bytes per launch; measured for the headline only
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["verdict_agreement_with_gpu"] == 1.0
@@ -136,7 +146,38 @@ def test_cfg3_lecture_two_ranks_over_gloo():
     lec = c["lecture"]
     assert lec["sampled_frames_in_the_last_step"] == 96 and lec["timeline_entries"] >= 2
     assert c["accuracy_vs_synthetic_truth"] >= 0.9 and lec["entries_equal_to_truth"] >= 0.8 * lec["truth_entries"]
-    assert j["value"] > 0 and j["roofline"]["over_step"]["frac"] > 0
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["launches_per_step"] == 3
+
+
+def test_cfg3_eight_ranks_dry_run_and_one_rank_under_the_launcher():
+    """Dry run of the driver's 8-GPU form of configs[3] on whatever this box has: `bench.py --gpus 8 --workload cfg3
+    --backend gloo --share-device` starts its own eight ranks (they share the device; the verdict all-gather goes through host memory),
+    the job is FIXED (strong scaling), every rank's gathered slice equals its own verdicts.  And the N = 1 line under the launcher
+    (the RCCL path at world size 1) measures what the plain command measures: same job, same per-step work, rates within 10 %
+    (a 3 % bound holds on the full-size job — profiles/ — but not on one this small)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SLIDEO_BENCH_BACKEND"):
+        env.pop(k, None)
+    common = ["--workload", "cfg3", "--pages", "20", "--pool", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-frames"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-device", "--total-frames", "512"] + common,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and c["frames_per_step_per_gpu"] == 32 and c["units_per_step"] == 2
+    assert c["collective"] == {"backend": "gloo", "all_gather_of_verdicts_checked": True}
+    assert c["lecture"]["sampled_frames_in_the_last_step"] == 256 and j["value"] > 0
+    # N = 1: plain command against the same line under torch.distributed.run with the process group forced (nccl at world size 1)
+    one = ["--gpus", "1", "--total-frames", "1536"] + common[:-6] + ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-host-frames"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + one, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    env2 = dict(env, SLIDEO_BENCH_FORCE_DIST="1", SLIDEO_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + one, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env2)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    a, b = _json_line(r1.stdout), _json_line(r2.stdout)
+    assert a["scaling"] == b["scaling"] == "strong" and a["config"]["frames_per_step_per_gpu"] == b["config"]["frames_per_step_per_gpu"] == 256
+    assert a["config"]["collective"] is None and b["config"]["collective"] == {"backend": "nccl", "all_gather_of_verdicts_checked": True}
+    assert abs(a["value"] - b["value"]) <= 0.10 * a["value"], (a["value"], b["value"])
 
 
 def test_nccl_with_fewer_gpus_than_ranks_fails_fast():

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(capi.EXPORTS) == names
-    assert L.slideo_abi_version() == 6        # ABI 6: + slideo_config.verdict_rule, slideo_device_list, n_devices 0 at group create; ocv.hdlt defaults to 1
+    assert L.slideo_abi_version() == 7        # ABI 7: + slideo_matcher_read_shader_clock (6: verdict_rule, slideo_device_list, n_devices 0; ocv.hdlt defaults to 1)
 
 
 def test_config_struct_matches_oracle_layout(capi, oracle):

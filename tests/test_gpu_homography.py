@@ -227,17 +227,18 @@ def test_verdict_rule_1_equals_oracle(capi, oracle, synth, model):
     frames have several accepted survivors (template-sharing sibling pages)."""
     pages = synth.pages(24, 800, 450)
     frames, truth, _ = synth.frames(pages, 24, 640, 360)
-    kw = dict(nfeatures=500, min_rating=6.0, min_rating_ratio=0.02, min_similarity=0.05, verify_model=model, verdict_rule=1)
+    min_sim = 0.05
+    kw = dict(nfeatures=500, min_rating=6.0, min_rating_ratio=0.02, min_similarity=min_sim, verify_model=model, verdict_rule=1)
     m, db = _build_both(capi, oracle, capi.default_config(**kw), oracle.default_config(**kw), pages)
     v = m.match_frames(frames)
     _compare_traces(m, db, frames, v, skip_ill_conditioned=True)
     several = 0
     for i in range(len(frames)):
         c = m.last_candidates(i)
-        ok = c[(c["survived"] == 1) & (c["similarity"] > 0.5)]
+        ok = c[(c["survived"] == 1) & (c["similarity"] > min_sim)]       # rule 1: the similarity only ACCEPTS (the configured bound) ...
         several += len(ok) > 1
         if len(ok):
-            assert v["page_idx"][i] == ok[np.argmax(ok["inliers"])]["page_idx"]
+            assert v["page_idx"][i] == ok[np.argmax(ok["inliers"])]["page_idx"]      # ... and the first in rating (= inlier) order wins
     assert several >= 1, "no frame exercised the rule"
     m.close()
     with pytest.raises(capi.SlideoError):

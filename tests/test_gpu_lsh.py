@@ -42,7 +42,12 @@ def test_knn_lsh_many_ties_at_the_kth_distance(capi, oracle):
     m.close()
 
 
-def test_lsh_mode_traces(capi, oracle, synth, cfg0_data):
+@pytest.mark.parametrize("share", [None, "4", "6"])
+def test_lsh_mode_traces(capi, oracle, synth, cfg0_data, monkeypatch, share):
+    """(share: SLIDEO_KNN_SHARE forcing the 12-wave block shapes of the EXACT search — the LSH-filtered stream keeps its own 8-wave
+    kernel and plan, and its buffers must be reserved for that plan: ADVICE r05, stage_knn.hip knn_shape)"""
+    if share is not None:
+        monkeypatch.setenv("SLIDEO_KNN_SHARE", share)
     pages, frames, truth, _ = cfg0_data
     m, db = _build_both(capi, oracle, small_cfg(capi, matcher=1), small_cfg(oracle, matcher=1), pages)
     v = m.match_frames(frames)
