@@ -102,6 +102,7 @@ __device__ __forceinline__ void kt_clock(unsigned long long* __restrict__ clk, b
 // super-tile instead of the look-ahead the ring was built for (found round 6 in the ISA: the waits sat in front of the early
 // peek and of the signal's ds_add).  Issued from inline assembly the counter accesses carry no such wait; what they need — the
 // wave's own LDS reads done before a `done` signal, a peeked value landed before it is tested — is waited for explicitly.
+__device__ __forceinline__ uint32_t kt_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }      // (a value the optimiser cannot trace: what is computed from it stays where it is written)
 __device__ __forceinline__ uint32_t kt_lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }      // (low half of a flat LDS address = the LDS offset)
 __device__ __forceinline__ uint32_t kt_ring_peek(const uint32_t* p) {                                 // issued, NOT waited for: kt_ring_landed() before the value is used
     uint32_t r;
@@ -389,14 +390,19 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
     auto stage = [&](int jj, int sl) {
         constexpr int PER_WAVE = KT_ST_U4 / KT_WAVES;                  // uint4 per wave and super-tile
         static_assert(PER_WAVE % 64 == 0, "whole wave-instructions");
-        const uint4* src = tx + (size_t)(st0 + jj) * KT_ST_U4 + wave * PER_WAVE + lane;
+        // a wave-uniform base (scalar registers) + a 32-bit lane offset the optimiser cannot trace back to the lane number: a
+        // per-lane 64-bit source pointer hoisted out of the main loop is two vector registers the wave shapes do not have
+        const uint32_t lo = kt_opaque((uint32_t)lane);
+        const char* sb = reinterpret_cast<const char*>(tx + (size_t)(st0 + jj) * KT_ST_U4 + wave * PER_WAVE);
 #pragma unroll
         for (int i = 0; i < PER_WAVE / 64; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (lo * 16u + 1024u * i)),
                                              (__attribute__((address_space(3))) void*)&lds[sl][wave * PER_WAVE + 64 * i], 16, 0, 0);
-        if (wave < KT_SIDE_U32 / 64)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(side + (size_t)(st0 + jj) * KT_SIDE_U32 + wave * 64 + lane),
+        if (wave < KT_SIDE_U32 / 64) {
+            const char* ss = reinterpret_cast<const char*>(side + (size_t)(st0 + jj) * KT_SIDE_U32 + wave * 64);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ss + lo * 4u),
                                              (__attribute__((address_space(3))) void*)&lds_side[sl][wave * 64], 4, 0, 0);
+        }
     };
 #ifdef KT_RING_BUILTIN       /* A/B: the counters through compiler builtins (rounds 1 - 5; see kt_ring_peek) */
     auto signal = [&](uint32_t* f) {
@@ -608,13 +614,18 @@ __device__ __forceinline__ void knn_tile_body(const uint8_t* __restrict__ q, int
         uint4 x0 = Lc[0], x1 = Lc[64], x2 = Lc[128], x3 = Lc[192];                                 // F(t)
         uint4 y0, y1, y2, y3;                                                                      // F(t + 1)
         KT_MFMAS(0, x0, x1, x2, x3)
+        // the super-tile's four half norms (wave-uniform address: a scalar load; float / int bit patterns) are fetched one super-tile
+        // AHEAD: asked for where they are used, the load sat two MFMAs in front of its `s_waitcnt lgkmcnt(0)` — a scalar-cache round
+        // trip in the first chain of every super-tile
+        uint4 nm4n = nminh[st0];
 #pragma unroll 1
         for (int j = 0; j < nst; ++j) {
             const int slot = j % KT_RING;
             if (W == KT_WAVES ? (((j ^ (wave >> 2)) & 1) != 0) : ((j + (wave >> 2)) % (W / 4) == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
             Lc = lds[slot] + lane;
             const uint32_t* sdc = lds_side[slot];
-            const uint4 nm4 = nminh[st0 + j];                          // (wave-uniform address: scalar loads; float / int bit patterns)
+            const uint4 nm4 = nm4n;
+            nm4n = nminh[st0 + min(j + 1, nst - 1)];
             // the tile after the segment's last is the last one again: recomputed into group A, never tested
             const uint4* Ln = j + 1 < nst ? lds[(j + 1) % KT_RING] + lane : Lc + (KT_TPS - 1) * 256;
             KT_TILE(0, x0, x1, x2, x3, y0, y1, y2, y3)

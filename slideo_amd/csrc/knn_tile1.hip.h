@@ -78,7 +78,7 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
 
     // `opaque(lane)`: a copy of the lane number the optimiser cannot trace — what is computed from it stays where it is written
     // instead of being hoisted out of the main loop into registers that live through it (a per-lane 64-bit global address is two)
-    auto opaque = [](uint32_t v) -> uint32_t { asm volatile("" : "+v"(v)); return v; };
+    auto opaque = [](uint32_t v) -> uint32_t { return kt_opaque(v); };
     M::Bop bq[4];
     auto load_queries = [&]() {
         const uint32_t lo = opaque((uint32_t)lane) & 31u;
@@ -249,13 +249,18 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
         Acc a;
         // One tile: its four MFMAs, each k-step's fragment registers re-loaded for the NEXT tile (Lx_) behind the MFMA that read
         // them; then the tile's max tree and test.
+#ifdef KT1_FENCED      /* experiment: every fragment re-load pinned right behind the MFMA that read its registers */
+#define KT1_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define KT1_FENCE
+#endif
 #define KT1_TILE(tt)                                                                                                   \
         {                                                                                                             \
             const uint4* Lx_ = (tt) == KT_TPS - 1 ? Ln : Lc + ((tt) + 1) * 256;                                       \
-            a = M::mfma(zero, f0, bq[0]); f0 = Lx_[0];                                                                \
-            a = M::mfma(a, f1, bq[1]); f1 = Lx_[64];                                                                  \
-            a = M::mfma(a, f2, bq[2]); f2 = Lx_[128];                                                                 \
-            a = M::mfma(a, f3, bq[3]); f3 = Lx_[192];                                                                 \
+            KT1_FENCE a = M::mfma(zero, f0, bq[0]); KT1_FENCE f0 = Lx_[0];                                            \
+            KT1_FENCE a = M::mfma(a, f1, bq[1]); KT1_FENCE f1 = Lx_[64];                                              \
+            KT1_FENCE a = M::mfma(a, f2, bq[2]); KT1_FENCE f2 = Lx_[128];                                             \
+            KT1_FENCE a = M::mfma(a, f3, bq[3]); KT1_FENCE f3 = Lx_[192]; KT1_FENCE                                   \
             const uint32_t nmh_ = (tt) == 0 ? nm4.x : (tt) == 1 ? nm4.y : (tt) == 2 ? nm4.z : nm4.w;                  \
             const int mx_ = tree(a), ti_ = M::tile_thr(h, nmh_);                                                      \
             if (__builtin_amdgcn_ballot_w64(mx_ > ti_) != 0ull) { KT_T0(t_s); candidates(a, ti_, sdc, tt); KT_T1(4, t_s); }      \
@@ -263,6 +268,7 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
         acquire(0, 0u, 0u);
         const uint4* Lc = lds[0] + lane;
         uint4 f0 = Lc[0], f1 = Lc[64], f2 = Lc[128], f3 = Lc[192];
+        uint4 nm4n = nminh[st0];                                       // (fetched one super-tile ahead: knn_tile_body)
 #pragma unroll 1
         for (int j = 0; j < nst; ++j) {
             const int slot = j % RING;
@@ -270,7 +276,8 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
             if ((j + (wave >> 2)) % (W / 4) == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
             Lc = lds[slot] + lane;
             const uint32_t* sdc = lds_side[slot];
-            const uint4 nm4 = nminh[st0 + j];
+            const uint4 nm4 = nm4n;
+            nm4n = nminh[st0 + min(j + 1, nst - 1)];
             const uint4* Ln = j + 1 < nst ? lds[(j + 1) % RING] + lane : Lc + (KT_TPS - 1) * 256;
             KT1_TILE(0)
             KT1_TILE(1)
@@ -292,6 +299,7 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
             }
         }
 #undef KT1_TILE
+#undef KT1_FENCE
     }
     flush();
     kt_clock(clk, true);

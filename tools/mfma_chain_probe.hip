@@ -3,6 +3,8 @@
 //   skew   two accumulators: the chain of one while the tree of the other is issued (knn_tile_body<2>, G = 1)
 //   pair   four accumulators: two interleaved chains while the trees of the other two are issued (knn_tile_body<4>, G = 2)
 //   flat2  two accumulators: two interleaved chains on the same fragments, then both trees (nothing overlapped inside the wave)
+//   split  two accumulators, the two chains offset by HALF a chain and interleaved (r06): A.k2 [tree B] B.k0 A.k3 B.k1 | B.k2 [tree A] A'.k0 B.k3 A'.k1 —
+//          consecutive MFMAs of one chain are two issue slots apart (a dependent MFMA issues ~80 cycles after its predecessor, a slot is 32)
 // A operands re-read from LDS for every chain ({0,1} nibbles), B operands in registers.  Grid = 256 blocks of W x 4 waves.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_chain_probe mfma_chain_probe.hip && ./mfma_chain_probe
 #include <hip/hip_runtime.h>
@@ -45,6 +47,20 @@ __global__ __launch_bounds__(1024) void probe(int iters, int* out) {
             const int m1 = tree(c[1]);
             c[0] = MF(zero, f3, b[0][0]); c[0] = MF(c[0], f2, b[0][1]); c[0] = MF(c[0], f1, b[0][2]); c[0] = MF(c[0], f0, b[0][3]);
             if (__builtin_amdgcn_ballot_w64(m1 > thr)) ++hits;
+        } else if (MODE == 4) {
+            // c[0] = chain A with k-steps 0, 1 of this tile done; c[1] = chain B of the previous tile, complete
+            c[0] = MF(c[0], f2, b[0][2]);
+            const int mB = tree(c[1]);
+            if (__builtin_amdgcn_ballot_w64(mB > thr)) ++hits;
+            c[1] = MF(zero, f0, b[1][0]);
+            c[0] = MF(c[0], f3, b[0][3]);
+            c[1] = MF(c[1], f1, b[1][1]);
+            c[1] = MF(c[1], f2, b[1][2]);
+            const int mA = tree(c[0]);
+            if (__builtin_amdgcn_ballot_w64(mA > thr)) ++hits;
+            c[0] = MF(zero, f1, b[0][0]);
+            c[1] = MF(c[1], f3, b[1][3]);
+            c[0] = MF(c[0], f0, b[0][1]);
         } else if (MODE == 3) {
             // two interleaved chains on the SAME fragments, then both trees: no overlap inside the wave (the SIMD's other waves cover)
             c[0] = MF(zero, f0, b[0][0]); c[1] = MF(zero, f0, b[1][0]); c[0] = MF(c[0], f1, b[0][1]); c[1] = MF(c[1], f1, b[1][1]);
@@ -110,7 +126,7 @@ static void run16(int wps, int* d) {
 }
 
 template <int MODE> static void run(const char* name, int wps, int* d) {
-    const int iters = MODE == 0 ? 40000 : (MODE == 1 || MODE == 3) ? 20000 : 10000;        // 160 k MFMAs per wave in every mode
+    const int iters = MODE == 0 ? 40000 : (MODE == 1 || MODE == 3 || MODE == 4) ? 20000 : 10000;        // 160 k MFMAs per wave in every mode
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     probe<MODE><<<256, 256 * wps>>>(100, d);
     hipEventRecord(e0); probe<MODE><<<256, 256 * wps>>>(iters, d); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -120,6 +136,6 @@ template <int MODE> static void run(const char* name, int wps, int* d) {
 }
 int main() {
     int* d; hipMalloc(&d, 4096 * 4);
-    for (int wps = 1; wps <= 4; ++wps) { run<0>("dep", wps, d); run<1>("skew", wps, d); run<2>("pair", wps, d); run<3>("flat2", wps, d); run16(wps, d); }
+    for (int wps = 1; wps <= 4; ++wps) { run<0>("dep", wps, d); run<1>("skew", wps, d); run<2>("pair", wps, d); run<3>("flat2", wps, d); run<4>("split", wps, d); run16(wps, d); }
     return 0;
 }
