@@ -292,6 +292,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
 
+    # Hardware queues.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.
+    # The library's four slot streams each get one of their own in a plain process — but an initialised RCCL communicator has created
+    # streams before them, two slot streams then SHARE a queue (their kernels serialise) and the same job is 10 % slower:
+    # 12.0 against 10.8 ms per step at world size 1, with the process group merely initialised, no collective issued
+    # (profiles/r06_experiments.txt 6).  Eight queues give every stream its own again (10.85 with or without RCCL).  Must be in the
+    # environment before the HIP runtime starts, i.e. before torch is imported.
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SLIDEO_BENCH_FORCE_DIST") == "1") and "RANK" in os.environ:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -412,18 +420,23 @@ def main():
     d_all = torch.zeros((world * B, verdict_words), dtype=torch.int32, device=coll_dev) if use_dist else None
     on_dev = use_dist and coll_dev == "cuda"          # the library leaves the records on the device
     st = {"next_step": 0, "last": None}
+    host_t = {"event_wait": 0.0, "collect": 0.0, "all_gather": 0.0, "submit": 0.0}     # host seconds of the stream loop's calls (cleared before the timed region)
 
     def collect_unit(item, local):
         """Collects one unit into its place in the ring; behind the LAST unit of a step — unless `local` — the step's one collective
         (RCCL over xGMI) runs on the step's verdict records."""
         ticket, g0, n = item
-        gather = use_dist and not local
+        gather = use_dist and not local and os.environ.get("SLIDEO_BENCH_SKIP_GATHER") != "1"      # (the switch: measurement only — where a collective path's time goes)
         r0 = g0 % R
+        tq0 = time.perf_counter()
         if gather and on_dev:
             for sl in range(r0 // B, (r0 + n - 1) // B + 1):
                 if step_done_ev[sl] is not None:
                     step_done_ev[sl].synchronize()   # an event R / B steps old: returns at once
+        tq1 = time.perf_counter()
         v = m.collect(ticket, dev_out=(ring.data_ptr() + r0 * 4 * verdict_words) if (gather and on_dev) else 0)
+        tq2 = time.perf_counter()
+        host_t["event_wait"] += tq1 - tq0; host_t["collect"] += tq2 - tq1
         ring_host[r0:r0 + n] = v
         if gather and not on_dev:                    # gloo stand-in: host tensors
             ring[r0:r0 + n].copy_(torch.from_numpy(v.view(np.int32).reshape(n, verdict_words)), non_blocking=False)
@@ -431,10 +444,12 @@ def main():
             a = (st["next_step"] * B) % R
             st["last"] = (st["next_step"], ring_host[a:a + B].copy())
             if gather:
+                tq3 = time.perf_counter()
                 dist.all_gather_into_tensor(d_all, ring[a:a + B])      # the one collective of the path
                 if on_dev:
                     step_done_ev[a // B] = torch.cuda.Event()
                     step_done_ev[a // B].record()
+                host_t["all_gather"] += time.perf_counter() - tq3
             st["next_step"] += 1
 
     def run_stream(total, depth=None, local=False, first_unit_only=False):
@@ -450,7 +465,9 @@ def main():
             g_read = 0 if first_unit_only else g        # (profiling the kernels alone: the same first unit every time)
             if len(pending) == depth:
                 collect_unit(pending.pop(0), local)
+            tq4 = time.perf_counter()
             pending.append((m.submit_dev(d_frames.data_ptr() + (g_read % pool) * frame_bytes, n, fw, fh, stream=stream), g, n))
+            host_t["submit"] += time.perf_counter() - tq4
             g += n
         while pending:
             collect_unit(pending.pop(0), local)
@@ -469,10 +486,12 @@ def main():
         run_steps(args.warmup)
     m.set_profiling(True)
     barrier()
+    for k_ in host_t: host_t[k_] = 0.0
     t0 = time.perf_counter()
     v, g_last = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    host_ms = {k_: round(v_ / max(args.steps, 1) * 1e3, 4) for k_, v_ in host_t.items()}
     prof, knn_pairs = m.read_profile()
     clk_mhz, clk_n = m.read_shader_clock()          # (the search blocks of the timed region; cleared by the read)
     m.set_profiling(False)
@@ -538,6 +557,7 @@ def main():
                    "inputs": "%d distinct synthetic frames per GPU, resident in HBM before the timed region; the timed region's %d frames per GPU are ONE stream (frame g = resident frame g mod %d) submitted in units of %d frames, a step = %d consecutive frames of it; every unit runs the whole hot path (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % (pool, args.steps * B, pool, U, B),
                    "frames_per_unit": U, "units_per_step": round(units_per_step, 3), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
                    "collective": ({"backend": backend, "all_gather_of_verdicts_checked": gathered_ok} if use_dist else None),
+                   "host_ms_per_step": host_ms, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),
                    "accuracy_vs_synthetic_truth": round(acc, 4),
                    "mean_keypoints_per_frame": round(float(v["n_keypoints"].mean()), 1)},
@@ -602,10 +622,10 @@ def main():
                 alg_step = 2.0 * 256 * (q_per_launch * M) * launches_per_step / step_s / 1e12
                 assert achieved <= MFMA_FP4_PEAK_TFLOPS, "executed matrix-core rate above the peak: the pair count or the timing is wrong"
                 out["roofline"] = dict({"kernel": "%s (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4)" % knn_kernel_label(args), "bound": "mfma",
-                                        "achieved": round(achieved, 2), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 4), "flops_per_pair": 512, "flops_per_step": flops_step,
+                                        "achieved": round(achieved, 4), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 7), "flops_per_pair": 512, "flops_per_step": flops_step,
                                         "counts": "executed pairs: query descriptors x DISTINCT train rows (K x Mu)",
-                                        "algorithmic": {"pairs_per_launch": int(q_per_launch * M), "achieved": round(alg_step, 2), "frac": round(alg_step / MFMA_FP4_PEAK_TFLOPS, 4),
+                                        "algorithmic": {"pairs_per_launch": int(q_per_launch * M), "achieved": round(alg_step, 4), "frac": round(alg_step / MFMA_FP4_PEAK_TFLOPS, 7),
                                                         "note": "SURVEY 8(d)'s definition, K x M pairs over ALL train rows x 512 flops over the same step: the rate a search "
                                                                 "without the train-set de-duplication would need (effective, not executed)"},
                                         "per_launch": {"avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n), "achieved": round(flops_launch / avg_s / 1e12, 2),
@@ -614,8 +634,8 @@ def main():
                 laneops_launch = LANEOPS_PER_PAIR * pairs_per_launch
                 achieved = laneops_launch * launches_per_step / step_s / 1e12
                 out["roofline"] = dict({"kernel": "knn_hamming_kernel<32> (v_xor_b32 + v_bcnt_u32_b32)", "bound": "valu",
-                                        "achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
-                                        "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "laneops_per_pair": LANEOPS_PER_PAIR,
+                                        "achieved": round(achieved, 5), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
+                                        "frac": round(achieved / VALU_PEAK_TLANEOPS, 7), "laneops_per_pair": LANEOPS_PER_PAIR,
                                         "flops_per_step": laneops_launch * launches_per_step,
                                         "per_launch": {"avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(knn_n), "achieved": round(laneops_launch / avg_s / 1e12, 3),
                                                        "frac": round(laneops_launch / avg_s / 1e12 / VALU_PEAK_TLANEOPS, 4), "note": per_launch_note}}, **common)

@@ -45,6 +45,8 @@
  *   SLIDEO_KNN_ENGINE 0..3        initial value of slideo_matcher_set_knn_engine
  *   SLIDEO_KNN_SHARE=0 / 1        exact Hamming search: always two / always one block per CU (default: one while other units are in flight)
  *                      =3 / 4    measurement: the 12-wave block (three search waves per SIMD, one block per CU) while other units are in flight / always
+ *                      =5 / 6    measurement: the 12-wave block of ONE query tile per wave (88 registers: three waves per SIMD in the registers of two,
+ *                                csrc/knn_tile1.hip.h) while other units are in flight / always
  *   SLIDEO_KNN_DEDUP=0            search all M train rows instead of the distinct ones (slideo_matcher_unique_descriptor_count)
  *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
  *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)
@@ -58,6 +60,10 @@
  *   SLIDEO_RANSAC_WINDOW=0        ransac_kernel's redraw schedule by the fixed point only                       [per unit]
  *   SLIDEO_RH_TAIL_ROUNDS n       verify_model 1: rounds before a candidate moves to ransac_h_tail_kernel (256; 0 = never) [per unit]
  *   SLIDEO_REFINE_LANE_LM 0|1     verify_model 1: the small candidates' LM in refine_h_kernel<1> / in the eigen kernel's lanes [per unit]
+ *   (not the library's, but it decides how its streams run) GPU_MAX_HW_QUEUES — the HIP runtime maps a process's streams onto this many
+ *       hardware queues (default 4) in creation order; a matcher's four slot streams must not share one (their units' kernels would
+ *       serialise: - 10 %).  A process that has created other streams BEFORE the matcher — an initialised RCCL communicator does — should
+ *       run with GPU_MAX_HW_QUEUES=8, set before the HIP runtime starts (bench.py does for its collective path; profiles/r06_experiments.txt 6)
  *   build time only: SLIDEO_HIP_EXTRA_FLAGS (slideo_amd/build.py), SLIDEO_LIB_PATH / SLIDEO_REBUILD (slideo_amd/_capi.py)
  */
 #ifndef SLIDEO_AMD_H

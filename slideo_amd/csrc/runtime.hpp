@@ -158,7 +158,7 @@ struct slideo_matcher {
     slideo::DevBuf d_kept;
     bool units_pending = false;   // the call being served has more units than the one submitted now
     int cu_split = 0;       // SLIDEO_CU_SPLIT=N: the search on N CUs (two blocks per CU), ORB / verify on the other 256 - N (0 = off: every stream on every CU)
-    int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one; 3 / 4 = the 12-wave block while shared / always (SLIDEO_KNN_SHARE)
+    int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one; 3 / 4 = the 12-wave block while shared / always; 5 / 6 = the 1-tile 12-wave block (knn_tile1.hip.h) while shared / always (SLIDEO_KNN_SHARE)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)
     int knn_exact_lists = 0;  // 1 = the matcher's kNN stage keeps full exact k-NN lists (no fused vote filter)

@@ -5,6 +5,10 @@ rank r takes a contiguous block of the sampled frames, the page DB is replicated
 exchange is ONE all-gather of fixed-size verdict records; rank 0 then runs the reference's
 sort + consecutive-duplicate removal (lib.rs:229-244).  Backend "nccl" is RCCL on ROCm (GPU
 tensors); "gloo" works on CPU tensors and is what the CPU-only tests use.
+
+A process that initialises an RCCL communicator BEFORE it creates its matcher should run with GPU_MAX_HW_QUEUES=8 in its
+environment (set before the HIP runtime starts): with the default four hardware queues RCCL's streams shift the matcher's four
+slot streams onto shared queues and the same job runs 10 % slower (include/slideo_amd.h "Environment", bench.py main).
 """
 import numpy as np
 
