@@ -1,5 +1,7 @@
 // knn_tile1.hip.h — the exact Hamming k-NN engine of knn_tile.hip.h as a block of THREE waves per SIMD that fits the registers
-// of less than two: ONE 32-query tile and ONE accumulator per wave (80 registers), twelve waves, 384 queries per block.
+// of two: ONE 32-query tile and ONE accumulator per wave (88 registers), twelve waves, 384 queries per block.
+// MEASUREMENT MODE (SLIDEO_KNN_SHARE=5 / 6): built, held bit-identical by the tests, measured — and slower than the shipped shape
+// (profiles/r06_experiments.txt 1: 96 against 116 queries per ms and CU); kept because the numbers in DESIGN.md section 8 come from it.
 //
 // Why.  While units share the chip the search runs one block per CU and leaves the other half of every SIMD's registers to the
 // ORB / verify kernels of the other units (stage_knn.hip).  With the 2-tile wave shape that block is two waves per SIMD at 128
@@ -12,10 +14,10 @@
 //   * ONE accumulator, no skew: the max tree of a tile runs when its four MFMAs are through — the other two waves of the SIMD
 //     own the pipe meanwhile (a wave needs ~90 cycles between its last MFMA and its next first one, the others have 256 to issue);
 //   * one fragment set, each k-step's registers re-loaded for the next tile as soon as its MFMA has issued.
-// 3 x 80 = 240 registers per SIMD lane: what two waves of the 2-tile shape take (256), so the co-runners keep their occupancy.
+// 3 x 88 = 264 registers per SIMD lane against the 256 of two 2-tile waves: the co-runners keep their occupancy.
 // The price is LDS traffic — a fragment read feeds one MFMA instead of two: 50 % of the LDS's ds_read_b128 rate at a full pipe —
 // and 4/3 of the L2 -> LDS staging per query (384 instead of 512 queries per streamed matrix).
-// Alone on the chip two blocks fit a CU (6 waves per SIMD).  Same contract, ring, push / flush protocol, thresholds, fused vote
+// One block per CU by its LDS (the ring below: 88 KB).  Same contract, ring, push / flush protocol, thresholds, fused vote
 // filter and result as knn_tile_body<2, KtHamming>; tests/test_gpu_parity.py holds all engines to the same keys.
 #pragma once
 #include "knn_tile.hip.h"
@@ -310,9 +312,9 @@ __device__ __forceinline__ void knn_tile1_body(const uint8_t* __restrict__ q, in
 #endif
 }
 
-// 512 / 6 = 85 -> 80 registers: three waves per SIMD in 240 registers beside the other units' kernels (one block per CU by the launch's
-// LDS pad, stage_knn.hip), six when the launch has the chip to itself (two blocks per CU: 2 x 73 KB of LDS)
-__global__ __launch_bounds__(KT1_WAVES * 64, 6)
+// 88 registers (amdgpu_num_vgpr counts in units of two on gfx90a+): three waves per SIMD in 264 registers beside the other units'
+// kernels; ONE block per CU by its LDS (5 ring slots: 88 KB), whatever else runs
+__global__ __attribute__((amdgpu_num_vgpr(44))) __launch_bounds__(KT1_WAVES * 64, 3)
 void knn_tile1w12_kernel(const uint32_t* __restrict__ q, int nq, const uint4* __restrict__ tx, const uint32_t* __restrict__ side,
                          const float4* __restrict__ nminh, int nt_pad, int st_per_seg, uint32_t* __restrict__ out,
                          uint32_t* __restrict__ pend_ws, float prune_tol, const uint32_t* __restrict__ nq_dev, unsigned long long* __restrict__ clk) {
