@@ -292,14 +292,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames in the CPU baseline sample")
     args = ap.parse_args()
 
-    # Hardware queues.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.
-    # The library's four slot streams each get one of their own in a plain process — but an initialised RCCL communicator has created
-    # streams before them, two slot streams then SHARE a queue (their kernels serialise) and the same job is 10 % slower:
-    # 12.0 against 10.8 ms per step at world size 1, with the process group merely initialised, no collective issued
-    # (profiles/r06_experiments.txt 6).  Eight queues give every stream its own again (10.85 with or without RCCL).  Must be in the
-    # environment before the HIP runtime starts, i.e. before torch is imported.
-    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SLIDEO_BENCH_FORCE_DIST") == "1") and "RANK" in os.environ:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (Hardware queues: an initialised RCCL communicator has created streams before the matcher's; with the HIP runtime's default
+    # of four hardware queues two of the matcher's slot streams used to land on ONE queue and every rank of a multi-GPU run was 10 %
+    # slower than the single-GPU run — profiles/r06_experiments.txt 6.  The library now picks its slot streams by measurement
+    # (slideo_matcher_create, SLIDEO_STREAM_PICK), so nothing is set here; config.gpu_max_hw_queues records what the process ran with.)
     import torch
     import torch.distributed as dist
 

@@ -51,6 +51,7 @@
  *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
  *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)
  *   SLIDEO_ORB_CHAIN=0            ORB stages of consecutive units free-running instead of taking turns
+ *   SLIDEO_STREAM_PICK=0          the slots' streams in plain creation order instead of picked by measurement to sit on hardware queues of their own (below)
  *   SLIDEO_RESIZE_GENERIC=1       every pyramid level through resize_kernel (any shrink factor) instead of resize_quad_kernel [per unit]
  *   SLIDEO_HOST_UNIT n            frames per unit of a host-memory batch (32; 0 = the device-path rule)
  *   SLIDEO_WS_GB x                workspace budget of all slots together (48)
@@ -61,9 +62,10 @@
  *   SLIDEO_RH_TAIL_ROUNDS n       verify_model 1: rounds before a candidate moves to ransac_h_tail_kernel (256; 0 = never) [per unit]
  *   SLIDEO_REFINE_LANE_LM 0|1     verify_model 1: the small candidates' LM in refine_h_kernel<1> / in the eigen kernel's lanes [per unit]
  *   (not the library's, but it decides how its streams run) GPU_MAX_HW_QUEUES — the HIP runtime maps a process's streams onto this many
- *       hardware queues (default 4) in creation order; a matcher's four slot streams must not share one (their units' kernels would
- *       serialise: - 10 %).  A process that has created other streams BEFORE the matcher — an initialised RCCL communicator does — should
- *       run with GPU_MAX_HW_QUEUES=8, set before the HIP runtime starts (bench.py does for its collective path; profiles/r06_experiments.txt 6)
+ *       hardware queues (default 4) in creation order, and a matcher's four slot streams must not share one (their units' kernels would
+ *       serialise: - 10 %, measured behind an initialised RCCL communicator, whose streams come first: profiles/r06_experiments.txt 6).
+ *       slideo_matcher_create therefore PICKS its slot streams by measurement (a candidate is kept iff a kernel on it completes while spin
+ *       kernels keep the streams kept so far busy; a few ms); with fewer hardware queues than slots it takes what there is.
  *   build time only: SLIDEO_HIP_EXTRA_FLAGS (slideo_amd/build.py), SLIDEO_LIB_PATH / SLIDEO_REBUILD (slideo_amd/_capi.py)
  */
 #ifndef SLIDEO_AMD_H

@@ -1,5 +1,6 @@
 // capi_runtime.hip — handles, page database, workspace slots, unit submit / collect and the match entry points of include/slideo_amd.h (no kernel of its own).
 #include "runtime.hpp"
+#include <chrono>
 
 using namespace slideo;
 
@@ -405,6 +406,46 @@ const char* slideo_last_error(const slideo_matcher* m) {
     return copy.c_str();
 }
 
+// ---- the slots' streams: on hardware queues of their own -------------------------------------------------------------------
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams
+// on one queue run their kernels one after the other.  The pipeline needs its NSLOTS slot streams to run BESIDE each other (the
+// search of one unit over the ORB / verify kernels of the others): when the host has created streams before the matcher — an
+// initialised RCCL communicator has — two slot streams would share a queue and the same job runs 10 % slower
+// (profiles/r06_experiments.txt 6).  So the streams are picked by measurement: a candidate is kept iff a kernel on it completes
+// while spin kernels keep every stream kept so far busy.  ~0.5 ms per candidate at create time; SLIDEO_STREAM_PICK=0: plain
+// creation order.  (One 3-line kernel: this unit otherwise holds none.)
+__global__ void slideo_spin_kernel(long long ticks) {           // ticks of the 100 MHz wall clock
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static void pick_independent_streams(hipStream_t* out, int n) {
+    using clk = std::chrono::steady_clock;
+    std::vector<hipStream_t> rejected;
+    int have = 0;
+    for (int attempt = 0; have < n && attempt < 4 * n + 8; ++attempt) {
+        hipStream_t c = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        slideo_spin_kernel<<<1, 64, 0, c>>>(0);                          // (its hardware queue comes into being with its first kernel)
+        HIP_CHECK(hipStreamSynchronize(c));
+        bool ok = true;
+        if (have > 0) {
+            for (int i = 0; i < have; ++i) slideo_spin_kernel<<<1, 64, 0, out[i]>>>(60000);      // 600 us on every stream kept so far
+            const auto t0 = clk::now();
+            slideo_spin_kernel<<<1, 64, 0, c>>>(0);
+            HIP_CHECK(hipStreamSynchronize(c));
+            const double us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+            for (int i = 0; i < have; ++i) HIP_CHECK(hipStreamSynchronize(out[i]));
+            ok = us < 300.0;                                               // behind a spinning stream it would have waited the 600
+        }
+        if (ok) out[have++] = c; else rejected.push_back(c);
+    }
+    for (; have < n; ++have) {                                             // fewer independent queues than slots (GPU_MAX_HW_QUEUES < NSLOTS): whatever comes
+        if (!rejected.empty()) { out[have] = rejected.back(); rejected.pop_back(); }
+        else HIP_CHECK(hipStreamCreateWithFlags(&out[have], hipStreamNonBlocking));
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+}
+
 int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_matcher** out) {
     slideo_matcher* m = nullptr;
     API_TRY
@@ -450,7 +491,19 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
         }
         if (mm->knn_share < 0) mm->knn_share = 0;    // the search has its CUs to itself: two blocks per CU (SLIDEO_KNN_SHARE=1 still forces one)
     }
+    hipStream_t picked[NSLOTS];
+    const bool pick = !mm->cu_split && env_long("SLIDEO_STREAM_PICK", 1) != 0;
+    if (pick) pick_independent_streams(picked, NSLOTS);
+    int slot_i = 0;
     for (Slot& S : mm->slots) {
+        if (pick) {
+            S.st = picked[slot_i++];
+            for (auto& e : S.ev) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&S.ev_orb, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
+            continue;
+        }
         if (mm->cu_split) {
             // (hipExtStreamCreateWithCUMask has no flags argument: these are BLOCKING streams — they synchronise implicitly with the
             // legacy NULL stream, unlike the hipStreamNonBlocking streams of the normal path; a caller with default-stream work of its

@@ -6,9 +6,8 @@ exchange is ONE all-gather of fixed-size verdict records; rank 0 then runs the r
 sort + consecutive-duplicate removal (lib.rs:229-244).  Backend "nccl" is RCCL on ROCm (GPU
 tensors); "gloo" works on CPU tensors and is what the CPU-only tests use.
 
-A process that initialises an RCCL communicator BEFORE it creates its matcher should run with GPU_MAX_HW_QUEUES=8 in its
-environment (set before the HIP runtime starts): with the default four hardware queues RCCL's streams shift the matcher's four
-slot streams onto shared queues and the same job runs 10 % slower (include/slideo_amd.h "Environment", bench.py main).
+(An RCCL communicator initialised BEFORE the matcher used to cost every rank 10 %: its streams shifted the matcher's slot streams
+onto shared hardware queues.  slideo_matcher_create now picks its slot streams by measurement — include/slideo_amd.h "Environment".)
 """
 import numpy as np
 
