@@ -188,3 +188,57 @@ def test_default_group_takes_the_nodes_gfx950_devices_by_ordinal(capi):
     import ctypes as C
     few = (C.c_int32 * 1)(-7)
     assert capi.lib().slideo_device_list(few, 0) == len(devs) and few[0] == -7        # capacity respected
+
+
+@pytest.mark.gpu
+def test_slot_streams_picked_by_measurement(capi, cfg0_data, monkeypatch):
+    """slideo_matcher_create picks its slot streams by measurement (hardware queues of their own whatever streams the host created
+    first — include/slideo_amd.h "Environment"): the same verdicts as plain creation order, also with streams created before the matcher
+    and in a process that only has TWO hardware queues (fewer than slots: it takes what there is)."""
+    import subprocess, sys, os, torch
+    from conftest import small_cfg
+    pages, frames, truth, _ = cfg0_data
+    big = np.concatenate([frames] * 12)                                 # several units in flight
+    out = {}
+    hold = [torch.cuda.Stream() for _ in range(5)]                     # the host's own streams, created (and used) first
+    for s_ in hold:
+        with torch.cuda.stream(s_):
+            torch.zeros(16, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    for pick in ("1", "0"):
+        monkeypatch.setenv("SLIDEO_STREAM_PICK", pick)
+        m = capi.Matcher(small_cfg(capi))
+        m.add_pages(list(pages)); m.finalize()
+        out[pick] = m.match_frames(big).tobytes()
+        m.close()
+    monkeypatch.delenv("SLIDEO_STREAM_PICK")
+    assert out["1"] == out["0"]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from slideo_amd import _capi, synth\n"
+            "pages = synth.pages(4, 800, 450); frames, truth, _ = synth.frames(pages, 8, 640, 360)\n"
+            "m = _capi.Matcher(_capi.default_config(nfeatures=500, min_rating=12.0)); m.add_pages(list(pages)); m.finalize()\n"
+            "v = m.match_frames(np.concatenate([frames] * 10)); assert np.array_equal(v['page_idx'][:8], truth), v['page_idx'][:8]; print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, GPU_MAX_HW_QUEUES="2"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_shader_clock_probe(capi, cfg0_data):
+    """slideo_matcher_read_shader_clock (ABI 7): the search blocks sum their s_memtime / s_memrealtime deltas while profiling is on;
+    the read clears the sums; without profiling nothing is recorded; the verdicts do not depend on it."""
+    pages, frames, truth, _ = cfg0_data
+    m = capi.Matcher(small_cfg(capi))
+    m.add_pages(list(pages)); m.finalize()
+    v0 = m.match_frames(frames)
+    assert m.read_shader_clock() == (0.0, 0)                            # profiling was never on
+    m.set_profiling(True)
+    v1 = m.match_frames(np.concatenate([frames] * 4))
+    mhz, n = m.read_shader_clock()
+    assert n >= 1 and 300.0 < mhz < 2600.0, (mhz, n)
+    assert m.read_shader_clock() == (0.0, 0)                            # cleared by the read
+    m.set_profiling(False)
+    v2 = m.match_frames(frames)
+    assert m.read_shader_clock()[1] == 0
+    assert np.array_equal(v0, v2) and np.array_equal(v1[:len(frames)], v0)
+    m.close()
