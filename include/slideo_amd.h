@@ -44,7 +44,10 @@
  * that the tests hold bit-identical, or size workspaces; everything else that used to be switchable this way was removed):
  *   SLIDEO_KNN_ENGINE 0..3        initial value of slideo_matcher_set_knn_engine
  *   SLIDEO_KNN_SHARE=0 / 1        exact Hamming search: always two / always one block per CU (default: one while other units are in flight)
- *                      =3 / 4    measurement: the 12-wave block (three search waves per SIMD, one block per CU) while other units are in flight / always
+ *                      =3 / 4    the 12-wave block (three search waves per SIMD, one block per CU) while other units are in flight / always
+ *   SLIDEO_KNN_W12_RATIO x        default rule: that 12-wave block while units share the chip when a unit carries >= x (query, train row) pairs per frame
+ *                                 pixel (290: decks of ~750 pages x ORB-1000 and up at 1080p; 0 = never) — the fuller matrix pipe then outweighs the
+ *                                 co-runners' occupancy (configs[3] + 6.8 %, configs[4] + 4.7 %; headline - 2..4 %, hence the rule)
  *                      =5 / 6    measurement: the 12-wave block of ONE query tile per wave (88 registers: three waves per SIMD in the registers of two,
  *                                csrc/knn_tile1.hip.h) while other units are in flight / always
  *   SLIDEO_KNN_DEDUP=0            search all M train rows instead of the distinct ones (slideo_matcher_unique_descriptor_count)

@@ -159,6 +159,8 @@ void unit_submit(slideo_matcher* m, Slot& S, const uint8_t* frames_dev, int n, i
     }
     // all workspace before the timed kNN interval
     S.u_nt = knn_unit_rows(m, (int)qplan);
+    // the search's block shape while units share the chip (stage_knn.hip knn_shape): how much search there is per pixel of ORB work
+    S.u_w12 = m->knn_w12_ratio > 0.0 && (double)qplan * (double)S.u_nt >= m->knn_w12_ratio * (double)n * (double)w * (double)h;
     knn_reserve_unit(m, S, qplan, qtot);
     S.d_votes.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(uint2), 16));
     S.d_gpts.reserve(std::max<size_t>((size_t)qtot * c.knn_k * sizeof(float4), 16));
@@ -466,6 +468,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     // environment switches of a matcher (include/slideo_amd.h, "Environment"); none changes a result
     { const long v = env_long("SLIDEO_KNN_ENGINE", 0); if (v >= 0 && v <= 3) mm->knn_engine = (int)v; }
     { const long v = env_long("SLIDEO_KNN_SHARE", -1); if ((v >= -1 && v <= 1) || (v >= 3 && v <= 6)) mm->knn_share = (int)v; }
+    if (const char* e = std::getenv("SLIDEO_KNN_W12_RATIO")) mm->knn_w12_ratio = std::atof(e);
     mm->async_submit = env_long("SLIDEO_ASYNC_SUBMIT", 1) != 0;
     mm->knn_dedup = env_long("SLIDEO_KNN_DEDUP", 1) != 0;
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";

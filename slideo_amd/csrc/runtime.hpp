@@ -73,7 +73,7 @@ struct Slot {
     hipStream_t st_knn = nullptr;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     // arguments of the unit in flight (re-run through the exact-size path if the capacity-sized one overflowed)
-    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0; bool u_shared = false;
+    const uint8_t* u_frames = nullptr; int u_w = 0, u_h = 0, u_stride = 0; int64_t u_fs = 0; bool u_async = false; int u_nt = 0; bool u_shared = false, u_w12 = false;
     DevBuf d_stage, d_pyr, d_blur, d_cand, d_hist, d_candcount, d_flags, d_thr, d_lvlofs, d_kpcount, d_qofs, d_info;
     DevBuf d_items, d_kp, d_desc, d_keys, d_knn_pend, d_votes, d_gpts, d_gmask, d_fcs, d_verdicts, d_pairs, d_blurmask, d_qkeys, d_tail, d_refine;
     PinBuf h_info, h_out;
@@ -158,6 +158,12 @@ struct slideo_matcher {
     slideo::DevBuf d_kept;
     bool units_pending = false;   // the call being served has more units than the one submitted now
     int cu_split = 0;       // SLIDEO_CU_SPLIT=N: the search on N CUs (two blocks per CU), ORB / verify on the other 256 - N (0 = off: every stream on every CU)
+    // while units share the chip the search runs the 12-wave block (three waves per SIMD, 128 registers each) instead of the 8-wave
+    // block + LDS pad when a unit carries at least this many (query, train row) pairs per frame pixel: the larger the deck, the more of
+    // a step is search, and from ~290 pairs per pixel on the fuller matrix pipe is worth more than the co-runners' occupancy
+    // (profiles/r06_experiments.txt 7: headline 197: - 2..4 %; 700 pages 275: - 1.7 %; 800 pages 314: + 5.5 %; configs[3] 392:
+    // + 6.8 %; configs[4] 352: + 4.7 %).  SLIDEO_KNN_W12_RATIO overrides (0 = never).
+    double knn_w12_ratio = 290.0;
     int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one; 3 / 4 = the 12-wave block while shared / always; 5 / 6 = the 1-tile 12-wave block (knn_tile1.hip.h) while shared / always (SLIDEO_KNN_SHARE)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)

@@ -125,14 +125,15 @@ void knn_probe_report() {
 #endif
 static unsigned share_pad(const slideo_matcher* m, const Slot& S) { return (m->knn_share == 1 || ((m->knn_share < 0 || m->knn_share >= 5) && S.u_shared)) ? KT_SHARE_PAD : 0u; }
 // The block shape of the exact Hamming search (engine 3).  SHAPE_T2: knn_tile2_kernel, 8 waves x 2 query tiles, two blocks per CU or
-// — with the LDS pad — one.  SHAPE_T2W12 (SLIDEO_KNN_SHARE=3 / 4, measurement): the same wave shape, 12 waves, one block per CU by
-// its registers.  SHAPE_T1W12 (knn_tile1.hip.h; SLIDEO_KNN_SHARE=5: while other units are in flight, 6: always): 12 waves x 1 query
+// — with the LDS pad — one.  SHAPE_T2W12 (by default for LARGE decks while units share the chip — knn_w12_ratio —; SLIDEO_KNN_SHARE=3 / 4 force it):
+// the same wave shape, 12 waves, one block per CU by its registers.  SHAPE_T1W12 (knn_tile1.hip.h; SLIDEO_KNN_SHARE=5: while other units are in flight, 6: always): 12 waves x 1 query
 // tile at 80 registers — three waves per SIMD in the registers two 2-tile waves take; one block per CU by the LDS pad while units
 // share the chip, two otherwise.  Only the exact search (matcher 0): the LSH-filtered stream has its own kernel and plan.
 enum KnnShape { SHAPE_T2 = 0, SHAPE_T2W12 = 1, SHAPE_T1W12 = 2 };
 static KnnShape knn_shape(const slideo_matcher* m, const Slot& S) {
     if (m->cfg.matcher != 0) return SHAPE_T2;
     if ((m->knn_share == 3 && S.u_shared) || m->knn_share == 4) return SHAPE_T2W12;
+    if (m->knn_share < 0 && S.u_shared && S.u_w12) return SHAPE_T2W12;       // large decks (runtime.hpp knn_w12_ratio)
     if ((m->knn_share == 5 && S.u_shared) || m->knn_share == 6) return SHAPE_T1W12;
     return SHAPE_T2;
 }

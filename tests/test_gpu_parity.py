@@ -812,15 +812,18 @@ def test_search_blocks_per_cu_modes_agree(capi, oracle, cfg0_data, monkeypatch):
     big = np.concatenate([frames] * 12)                                 # > one 64-frame unit: units in flight together
     out = {}
     # (3 / 4: the 12-wave block of the 2-tile wave shape while units share the chip / always; 5 / 6: the 1-tile 12-wave block, knn_tile1.hip.h)
-    for mode in ("0", "1", "3", "4", "5", "6", None):
-        if mode is not None: monkeypatch.setenv("SLIDEO_KNN_SHARE", mode)
+    # ("ratio1": the default rule for large decks — the 12-wave block while units share the chip from knn_w12_ratio pairs per pixel on — forced on)
+    for mode in ("0", "1", "3", "4", "5", "6", "ratio1", None):
+        if mode == "ratio1": monkeypatch.setenv("SLIDEO_KNN_W12_RATIO", "1")
+        elif mode is not None: monkeypatch.setenv("SLIDEO_KNN_SHARE", mode)
         m, db = _build_both(capi, oracle, small_cfg(capi), small_cfg(oracle), pages)
-        if mode is not None: monkeypatch.delenv("SLIDEO_KNN_SHARE")
+        if mode == "ratio1": monkeypatch.delenv("SLIDEO_KNN_W12_RATIO")
+        elif mode is not None: monkeypatch.delenv("SLIDEO_KNN_SHARE")
         v = m.match_frames(frames)
         _compare_traces(m, db, frames, v)
         out[mode] = (v.tobytes(), m.match_frames(big).tobytes())
         m.close()
-    assert out["0"] == out["1"] == out["3"] == out["4"] == out["5"] == out["6"] == out[None]
+    assert out["0"] == out["1"] == out["3"] == out["4"] == out["5"] == out["6"] == out["ratio1"] == out[None]
     assert out[None][1] == out[None][0] * 12
 
 

@@ -1,3 +1,5 @@
+"""What slideo_matcher_create's stream pick (SLIDEO_STREAM_PICK, include/slideo_amd.h "Environment") costs: create + destroy of a matcher
+with and without it, 10 times each (on the GPU box: python tools/stream_pick_cost.py).  r06: 25 - 42 ms against 19 ms."""
 import time, sys, os
 sys.path.insert(0, '/root/repo')
 from slideo_amd import _capi
