@@ -341,6 +341,8 @@ __device__ __forceinline__ void fast_issue_loads(const PyrGeom& g, const FastTil
 
 #ifdef FAST_WAVES_EU      /* compile-time experiment hook: a register cap (6 waves per SIMD = 80 registers spills the tile offsets) */
 #define FAST_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FAST_WAVES_EU)))
+#elif defined(FAST_VGPRS)  /* experiment hook: a HARD cap (amdgpu_num_vgpr counts in units of two: 32 = 64 registers; what does not fit spills) */
+#define FAST_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(FAST_VGPRS)))
 #else
 #define FAST_KERNEL_ATTR
 #endif
@@ -752,8 +754,13 @@ typedef float blur_f2 __attribute__((ext_vector_type(2)));
 //     k3 A[t] + k4 (M[t] + M[t-1]) + k5 (A[t+1] + A[t-1]) + k6 (M[t+1] + M[t-2])
 // is 7 packed instructions per pixel pair, in OpenCV's order of operations component by component.  The final
 // saturate_cast<uchar>(cvRound(s)) is one v_cvt_pk_u8_f32 per pixel (round to nearest even, saturating: tools/cvt_pk_probe.hip).
+#ifdef BLUR_VGPRS          /* experiment hook: hard register cap (units of two) */
+#define BLUR_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(BLUR_VGPRS)))
+#else
+#define BLUR_KERNEL_ATTR
+#endif
 template <bool FMA>
-__global__ __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
+__global__ BLUR_KERNEL_ATTR __launch_bounds__(256) void blur_f32_kernel(PyrGeom g, const uint8_t* __restrict__ pyr,
                                                        uint8_t* __restrict__ blur, OrbTables const* __restrict__ tab,
                                                        const uint8_t* __restrict__ strip_mask) {
     static_assert(BLUR_RH % 8 == 0, "four row pairs per unrolled round");

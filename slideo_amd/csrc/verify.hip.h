@@ -1027,8 +1027,13 @@ struct VtTile { int sx_lo, spw, all_in; };
 #ifndef VT_WAVES_EU
 #define VT_WAVES_EU 4      /* 128 registers: four blocks per CU (3: 1.58 ms, 4: 1.37 ms for the headline launch) */
 #endif
+#ifdef VT_VGPRS            /* experiment hook: hard register cap (amdgpu_num_vgpr counts in units of two) */
+#define VT_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(VT_VGPRS)))
+#else
+#define VT_KERNEL_ATTR
+#endif
 template <bool PERSP>
-__global__ __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
+__global__ VT_KERNEL_ATTR __launch_bounds__(256, VT_WAVES_EU) void reproject_vt_kernel(const AreaGeom* __restrict__ ags, const AreaTap* __restrict__ taps,
                                                            const int32_t* __restrict__ idx, const AreaRec* __restrict__ recs,
                                                            const uint8_t* __restrict__ page_small,
                                                            const uint8_t* __restrict__ frames, int64_t frame_stride, int stride,
