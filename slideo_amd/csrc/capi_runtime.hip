@@ -469,6 +469,7 @@ int32_t slideo_matcher_create(const slideo_config* cfg, int32_t device, slideo_m
     { const long v = env_long("SLIDEO_KNN_ENGINE", 0); if (v >= 0 && v <= 3) mm->knn_engine = (int)v; }
     { const long v = env_long("SLIDEO_KNN_SHARE", -1); if ((v >= -1 && v <= 1) || (v >= 3 && v <= 6)) mm->knn_share = (int)v; }
     if (const char* e = std::getenv("SLIDEO_KNN_W12_RATIO")) mm->knn_w12_ratio = std::atof(e);
+    mm->knn_nseg_force = (int)std::max(0l, std::min(64l, env_long("SLIDEO_KNN_NSEG", 0)));
     mm->async_submit = env_long("SLIDEO_ASYNC_SUBMIT", 1) != 0;
     mm->knn_dedup = env_long("SLIDEO_KNN_DEDUP", 1) != 0;
     if (const char* e = std::getenv("SLIDEO_LSH_ENGINE")) mm->lsh_gather = std::string(e) == "gather";

@@ -164,6 +164,7 @@ struct slideo_matcher {
     // (profiles/r06_experiments.txt 7: headline 197: - 2..4 %; 700 pages 275: - 1.7 %; 800 pages 314: + 5.5 %; configs[3] 392:
     // + 6.8 %; configs[4] 352: + 4.7 %).  SLIDEO_KNN_W12_RATIO overrides (0 = never).
     double knn_w12_ratio = 290.0;
+    int knn_nseg_force = 0; // SLIDEO_KNN_NSEG=n (measurement): train-stream segments of the matrix-core search instead of the plan's
     int knn_share = -1;     // search blocks per CU: -1 = one while other units are in flight, two otherwise (default); 0 = always two; 1 = always one; 3 / 4 = the 12-wave block while shared / always; 5 / 6 = the 1-tile 12-wave block (knn_tile1.hip.h) while shared / always (SLIDEO_KNN_SHARE)
     int knn_engine = 0;     // 0 = FP4 MFMA, wave shape chosen per launch (default), 1 = integer VALU popcount,
                             // 2 = FP4 MFMA, 2 waves/SIMD x 4 query tiles (knn_tile4_kernel), 3 = 4 waves/SIMD x 2 tiles (knn_tile2_kernel)

@@ -175,6 +175,7 @@ static KnnPlan knn_plan(const slideo_matcher* m, int nq, int nt, int nq_grid = 0
         // empty slots do).  Measured (r01): 236 query blocks x 1.8 M rows (64 4K frames): 1 segment 33.2 ms, 2 segments 24.2 ms,
         // 3 segments 23.5 ms; 239 query blocks x 517 k rows (128 1080p frames): 2 segments 6.24 ms, 3 segments 6.65 ms
         int nseg = p.qblocks >= (w12 ? 192 : 384) ? 1 : std::min(std::max((w12 ? 256 : 512) / std::max(p.qblocks, 1), 1), n_st);
+        if (m->knn_nseg_force > 0) nseg = std::min(m->knn_nseg_force, n_st);      // (SLIDEO_KNN_NSEG: measurement)
         p.per_seg = cdiv(n_st, std::max(nseg, 1));
         p.nseg = cdiv(n_st, p.per_seg);
         p.qblocks = cdiv(nq_grid, qpb);
