@@ -226,10 +226,12 @@ def knn_kernel_label(args):
     if args.knn == "mfma4":
         return "knn_tile4_kernel"
     share = os.environ.get("SLIDEO_KNN_SHARE", "auto")
-    t1 = "knn_tile1w12_kernel (12 waves x 1 query tile, 80 registers: three waves per SIMD beside the other stages)"
+    t1 = "knn_tile1w12_kernel (12 waves x 1 query tile, 88 registers: measurement mode)"
     t2 = "knn_tile2_kernel (8 waves x 2 query tiles)"
-    return {"auto": t1, "-1": t1, "5": t1 + " while units share the chip, else " + t2, "6": t1, "0": t2 + ", two blocks per CU",
-            "1": t2 + ", one block per CU", "3": "knn_tile2w12_kernel while units share the chip, else " + t2, "4": "knn_tile2w12_kernel"}.get(share, t2)
+    w12 = "knn_tile2w12_kernel (12 waves x 2 query tiles)"
+    auto = t2 + ": one block per CU while units share the chip, two otherwise; " + w12 + " instead while units share the chip from SLIDEO_KNN_W12_RATIO (290) pairs per frame pixel on"
+    return {"auto": auto, "-1": auto, "5": t1 + " while units share the chip, else " + t2, "6": t1, "0": t2 + ", two blocks per CU",
+            "1": t2 + ", one block per CU", "3": w12 + " while units share the chip, else " + t2, "4": w12}.get(share, t2)
 
 
 def self_launch(n):
@@ -551,7 +553,8 @@ def main():
                    "frames_projective_component": persp,
                    "parallelism": "frames sharded over %d GPU(s), page DB replicated, 1 RCCL all-gather of verdicts per step (device to device); %d batches in flight per GPU, one HIP stream each" % (world, 1 if args.no_overlap else args.inflight),
                    "inputs": "%d distinct synthetic frames per GPU, resident in HBM before the timed region; the timed region's %d frames per GPU are ONE stream (frame g = resident frame g mod %d) submitted in units of %d frames, a step = %d consecutive frames of it; every unit runs the whole hot path (the PCIe-inclusive rate with host frames is in DESIGN.md section 6)" % (pool, args.steps * B, pool, U, B),
-                   "frames_per_unit": U, "units_per_step": round(units_per_step, 3), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
+                   "frames_per_unit": U, "units_per_step": round(units_per_step, 3),
+                   "search_pairs_per_frame_pixel": round(float(wl["nfeatures"]) * float(Mu) / float(fw * fh), 1), "resident_pool_frames_per_gpu": pool, "lecture": lecture,
                    "collective": ({"backend": backend, "all_gather_of_verdicts_checked": gathered_ok} if use_dist else None),
                    "host_ms_per_step": host_ms, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "page_db_build_s": round(t_db, 2), "input_gen_s": round(t_gen, 2),

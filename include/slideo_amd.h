@@ -50,6 +50,7 @@
  *                                 co-runners' occupancy (configs[3] + 6.8 %, configs[4] + 4.7 %; headline - 2..4 %, hence the rule)
  *                      =5 / 6    measurement: the 12-wave block of ONE query tile per wave (88 registers: three waves per SIMD in the registers of two,
  *                                csrc/knn_tile1.hip.h) while other units are in flight / always
+ *   SLIDEO_KNN_NSEG n             measurement: train-stream segments of the matrix-core search instead of the plan's choice
  *   SLIDEO_KNN_DEDUP=0            search all M train rows instead of the distinct ones (slideo_matcher_unique_descriptor_count)
  *   SLIDEO_LSH_ENGINE=gather      matcher 1 by bucket gathering instead of the filtered matrix-core stream
  *   SLIDEO_ASYNC_SUBMIT=0         units through the exact-size path (one host wait for the keypoint counts in mid-unit)
