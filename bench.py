@@ -620,7 +620,7 @@ def main():
                 achieved = flops_step / step_s / 1e12
                 alg_step = 2.0 * 256 * (q_per_launch * M) * launches_per_step / step_s / 1e12
                 assert achieved <= MFMA_FP4_PEAK_TFLOPS, "executed matrix-core rate above the peak: the pair count or the timing is wrong"
-                out["roofline"] = dict({"kernel": "%s (v_mfma_scale_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4)" % knn_kernel_label(args), "bound": "mfma",
+                out["roofline"] = dict({"kernel": "%s (v_mfma_f32_32x32x64_f8f6f4, {0,1} FP4 x FP4)" % knn_kernel_label(args), "bound": "mfma",
                                         "achieved": round(achieved, 4), "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(achieved / MFMA_FP4_PEAK_TFLOPS, 7), "flops_per_pair": 512, "flops_per_step": flops_step,
                                         "counts": "executed pairs: query descriptors x DISTINCT train rows (K x Mu)",

@@ -12,7 +12,7 @@
 //
 // What changed against that engine is the operand alphabet.  There every descriptor bit b was 1 - 2b in {+1, -1} and
 // <q', t'> = 256 - 2 Hamming.  The chip clocks to its power budget, and what the FP4 multiplier array burns depends on the
-// VALUES it is fed: with 16 v_mfma_scale_f32_32x32x64_f8f6f4 + 32 VALU per wave-iteration (tools/mfma_operand_power.hip,
+// VALUES it is fed: with 16 v_mfma_scale_f32_32x32x64_f8f6f4 (r02's form; the kernel now issues the unscaled encoding, KtHamming::mfma) + 32 VALU per wave-iteration (tools/mfma_operand_power.hip,
 // profiles/r02_mfma_operand_power.txt) the chip sustains 7.3 PFLOP/s on +-1 x +-1 operands, 7.3 on {0,1} x +-1, 8.4 on
 // {0,1} x {0,1} (three of four products are zero) and 8.75 on all-zero operands.  So both operands are the raw bits,
 // b -> b in {0, 1} (FP4 e2m1: 0x0 / 0x2), the contraction is dot = popcount(q & t), and
@@ -153,7 +153,15 @@ struct KtHamming {
     static constexpr int KL = 32, QBYTES = 32;
     static __device__ __forceinline__ Acc mfma(Acc acc, const uint4& f, const Bop& b) {
         const knn_v8i v = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+        // Both scale operands are the constant 0: the compiler then selects v_mfma_f32_32x32x64_f8f6f4 — the 64-bit encoding
+        // WITHOUT the v_mfma_ld_scale half of v_mfma_scale_… (and without its two scale registers).  Same function on these operands,
+        // bit for bit (tools/mfma_unscaled_check.hip: 4.2 M accumulator values, 0 differences; the unit-scale form 0x7F7F7F7F is
+        // -DKT_SCALED), 2 - 3 % faster: search alone 7.41 -> 7.24 ms, headline step 10.92 -> 10.64 ms (profiles/r06_experiments.txt 10).
+#ifdef KT_SCALED
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#else
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v, b, acc, 4, 4, 0, 0, 0, 0);
+#endif
     }
     static __device__ __forceinline__ int raw(float x) { return __float_as_int(x); }
     // k-step s of one query row: its operand fragment and the contribution to |q|

@@ -10,9 +10,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#ifdef MF_UNSCALED      /* scale operands 0: the compiler selects v_mfma_f32_32x32x64_f8f6f4 (no scale load, 64-bit encoding) */
+#define MF_SCALE 0
+#else
+#define MF_SCALE 0x7F7F7F7F
+#endif
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-#define MF(acc, f, b) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{(int)(f).x, (int)(f).y, (int)(f).z, (int)(f).w, 0, 0, 0, 0}, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+#define MF(acc, f, b) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{(int)(f).x, (int)(f).y, (int)(f).z, (int)(f).w, 0, 0, 0, 0}, b, acc, 4, 4, 0, MF_SCALE, 0, MF_SCALE)
 __device__ __forceinline__ int tree(const v16f& a) {
     int t[5];
 #pragma unroll
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(1024) void probe(int iters, int* out) {
 // a train tile of 16 rows; per iteration 8 MFMAs of 4 passes (= the work of four 32x32x64) in four independent chains of two, the trees
 // of the other accumulator set (1 max3 + 1 max each) underneath.
 typedef float v4f __attribute__((ext_vector_type(4)));
-#define MF16(acc, f, b) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(v8i{(int)(f).x, (int)(f).y, (int)(f).z, (int)(f).w, 0, 0, 0, 0}, b, acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+#define MF16(acc, f, b) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(v8i{(int)(f).x, (int)(f).y, (int)(f).z, (int)(f).w, 0, 0, 0, 0}, b, acc, 4, 4, 0, MF_SCALE, 0, MF_SCALE)
 __device__ __forceinline__ int tree4(const v4f& a) { return max(max(max(__float_as_int(a[0]), __float_as_int(a[1])), __float_as_int(a[2])), __float_as_int(a[3])); }
 __global__ __launch_bounds__(1024) void probe16(int iters, int* out) {
     __shared__ uint4 lds[8][2][64];
