@@ -54,3 +54,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "slideo_oracle" not in txt, f
+
+
+def test_search_kernel_issues_the_unscaled_matrix_instruction():
+    """The exact-Hamming search (csrc/knn_tile.hip.h, KtHamming::mfma) is built on v_mfma_f32_32x32x64_f8f6f4 — the 64-bit encoding the
+    compiler selects when both scale operands of the builtin are the constant 0 — not on the 128-bit v_mfma_scale_… double instruction
+    (round 6, experiment 10: bit-identical, 2-3 % faster).  Read from the gfx950 code object of the built stage unit, no GPU needed."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    objdump, objcopy = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    obj = os.path.join(ROOT, "slideo_amd", "lib", "obj", "stage_knn.o")
+    if not (os.path.exists(objdump) and os.path.exists(objcopy) and os.path.exists(obj)):
+        pytest.skip("no llvm-objdump / built stage object here")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+        blob = open(fat, "rb").read()
+        elf = os.path.join(tmp, "co.elf")
+        open(elf, "wb").write(blob[blob.find(b"\x7fELF"):])
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", elf], capture_output=True, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # the kernels of the Hamming engine: every FP4 matrix instruction in the unit
+    plain = len(re.findall(r"\bv_mfma_f32_32x32x64_f8f6f4\b", asm))
+    scaled = len(re.findall(r"\bv_mfma_scale_f32_32x32x64_f8f6f4\b", asm))
+    assert plain > 0 and scaled == 0, (plain, scaled)
